@@ -1,0 +1,179 @@
+/*
+ * vstar_hip.h — C-ABI of libvstar_hip.so, the MI355X (gfx950) engine for the V* guided-visual-search
+ * hot path: per-crop VSM scoring = CLIP-ViT-L/14 -> mm_projector -> LLaMA-7B prefill -> [LOC] hidden state
+ * -> text_hidden_fcs_{det,seg} -> OWL-ViT tower + class/box heads -> SAM-style mask head.
+ *
+ * The reference (penghao-wu/vstar) is 100 % Python and has no FFI of its own; the Python call sites
+ * this library replaces are cited per entry point (paths relative to the reference repo root).
+ *
+ * Conventions
+ *   - return 0 = OK, negative = error; vstar_last_error() gives the message for the handle
+ *     (or for the calling thread when the handle is NULL / creation failed).
+ *   - The caller owns every host buffer; the engine owns every device buffer.  Pointers named dev_* are
+ *     device (HBM) pointers supplied by the caller (e.g. a torch tensor's data_ptr()); everything else is host.
+ *   - One handle per device/process, not thread-safe.  Work is stream-ordered on the handle's HIP stream;
+ *     entry points synchronise that stream before returning unless they say otherwise.
+ *   - bf16 tensors cross the ABI as uint16_t (raw bf16 bits).  No torch / Python types in any signature.
+ */
+#ifndef VSTAR_HIP_H
+#define VSTAR_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSTAR_ABI_VERSION 1
+
+/* dtype codes for vstar_load_tensor */
+enum { VSTAR_F32 = 0, VSTAR_F16 = 1, VSTAR_BF16 = 2 };
+
+/* error codes */
+enum {
+  VSTAR_OK = 0,
+  VSTAR_ERR_INVALID = -1,   /* bad argument / shape */
+  VSTAR_ERR_STATE = -2,     /* call order (e.g. score before finalize) */
+  VSTAR_ERR_MISSING = -3,   /* a required checkpoint tensor was never loaded */
+  VSTAR_ERR_HIP = -4,       /* HIP runtime error */
+  VSTAR_ERR_NOMEM = -5
+};
+
+/*
+ * Model geometry.  Mirrors what the reference reads from the HF configs:
+ *   LlavaConfig / LlamaConfig            VisualSearch/model/llava/model/language_model/llava_llama.py:31-52
+ *   CLIPVisionConfig (vision tower)      VisualSearch/model/llava/model/multimodal_encoder/clip_encoder.py:17-29
+ *   OwlViTConfig.vision_config           VisualSearch/model/owlvit/owlvit.py:21-31
+ *   SAM head hyper-parameters            VisualSearch/model/VSM.py:91-113 (fixed: 256-d, 48x48 grid, 8 heads, mlp 2048)
+ * Head dims are fixed by the kernels: CLIP/OWL-ViT 64, LLaMA 128.
+ */
+typedef struct vstar_config {
+  int32_t abi_version;        /* VSTAR_ABI_VERSION */
+  /* CLIP vision tower */
+  int32_t clip_image_size;    /* 224 (reference) or 336 (benchmark geometry) */
+  int32_t clip_patch;         /* 14 */
+  int32_t clip_hidden;        /* 1024 */
+  int32_t clip_heads;         /* 16 (hidden / 64) */
+  int32_t clip_mlp;           /* 4096 */
+  int32_t clip_layers;        /* 24 in the checkpoint; blocks 0..clip_layers+select_layer are executed */
+  int32_t clip_select_layer;  /* -2: hidden_states[-2] => clip_layers-1 blocks */
+  /* LLaMA decoder */
+  int32_t llm_hidden;         /* 4096 */
+  int32_t llm_heads;          /* 32 (hidden / 128) */
+  int32_t llm_mlp;            /* 11008 */
+  int32_t llm_layers;         /* 32 */
+  int32_t llm_vocab;          /* 32004 */
+  float   llm_rms_eps;        /* 1e-6 (vicuna-7b-v1.3) */
+  float   llm_rope_theta;     /* 10000 */
+  /* OWL-ViT vision tower + heads */
+  int32_t owl_image_size;     /* 768 */
+  int32_t owl_patch;          /* 16 */
+  int32_t owl_hidden;         /* 768 */
+  int32_t owl_heads;          /* 12 */
+  int32_t owl_mlp;            /* 3072 */
+  int32_t owl_layers;         /* 12 */
+  int32_t owl_query_dim;      /* 512 = text_hidden_fcs_det out_dim */
+  /* limits used to size the workspace */
+  int32_t max_batch;          /* crops per vstar_vsm_score_batch call */
+  int32_t max_text_len;       /* L_max: input_ids length incl. the single -200 */
+  int32_t reserved[8];
+} vstar_config;
+
+typedef struct vstar_engine vstar_handle;
+
+/* Per-crop result record.  Fixed size so that records can be all-gathered across ranks unchanged
+ * (SURVEY.md §8e).  n_patches = (owl_image_size/owl_patch)^2 = 2304, low-res mask = 192x192. */
+#define VSTAR_N_BOXES 2304
+#define VSTAR_MASK_RES 192
+#define VSTAR_MAX_VERIFY 8
+typedef struct vstar_result {
+  float   pred_logits[VSTAR_N_BOXES];            /* raw class logits (pre-sigmoid)  VSM.py:544-552 */
+  float   pred_boxes[VSTAR_N_BOXES * 4];         /* cxcywh in [0,1]                 owlvit.py:79-100 */
+  float   lowres_mask[VSTAR_MASK_RES * VSTAR_MASK_RES]; /* mask 0 logits            mask_decoder.py:138-186 */
+  int32_t tf_argmax[VSTAR_MAX_VERIFY];           /* argmax(lm_head(h_t)) at the verify positions */
+} vstar_result;
+
+/* Replaces VSMForCausalLM.from_pretrained(...) construction  (visual_search.py:143-172). */
+int vstar_create(const vstar_config* cfg, int device, vstar_handle** out);
+void vstar_destroy(vstar_handle* h);
+const char* vstar_last_error(const vstar_handle* h);
+
+/* Weight hand-over, one checkpoint tensor at a time, keyed by its HF state-dict name
+ * (VSM keys as listed in SURVEY.md §5; the CLIP tower's keys carry the prefix "clip.").
+ * host_ptr is copied; dtype is one of VSTAR_F32/F16/BF16.  Replaces the torch state-dict load
+ * inside from_pretrained (visual_search.py:157-161). */
+int vstar_load_tensor(vstar_handle* h, const char* hf_key, const void* host_ptr, int dtype,
+                      int ndim, const int64_t* shape);
+/* Packs weights into the kernels' layouts (fused QKV, interleaved gate/up, padded N/K), uploads,
+ * and frees host staging copies.  Fails with VSTAR_ERR_MISSING naming the first absent key. */
+int vstar_finalize_weights(vstar_handle* h);
+
+/*
+ * The hot path: score B crops in one pass.  Replaces VSMForCausalLM.inference / model_forward(inference=True)
+ * (VisualSearch/model/VSM.py:438-553, 201-364) called from VSM.inference (visual_search.py:198-207).
+ *   clip_pix  [B,3,I,I]      bf16, CLIP-normalised      (visual_search.py:186-189)
+ *   owl_pix   [B,3,768,768]  bf16, OWL-ViT-normalised   (visual_search.py:190-194)
+ *   ids       [B,L] int32, exactly one -200 (IMAGE_TOKEN_INDEX) per row at the same column
+ *   loc_pos   [B]   index into the SPLICED sequence (length L-1+P) of the hidden state that predicts [LOC]
+ *                   (= index([LOC]) - 1 + (P-1), VSM.py:465-473)
+ *   verify_pos [B*n_verify] spliced-sequence positions whose lm_head argmax is returned (template check,
+ *                   SURVEY.md §7 "hard parts"); n_verify may be 0.
+ *   flags     bit0: skip the OWL-ViT tower + heads (core path only; result boxes/logits/mask untouched)
+ * pixel/ids pointers are HOST pointers unless flags bit1 (VSTAR_F_DEVICE_INPUTS) is set.
+ * out: B records in host memory (or device memory when VSTAR_F_DEVICE_OUTPUT is set).
+ */
+#define VSTAR_F_SKIP_OWL       1u
+#define VSTAR_F_DEVICE_INPUTS  2u
+#define VSTAR_F_DEVICE_OUTPUT  4u
+#define VSTAR_F_NO_SYNC        8u   /* do not synchronise the stream before returning (bench inner loop) */
+int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, const uint16_t* owl_pix,
+                          const int32_t* ids, int L, const int32_t* loc_pos,
+                          const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
+
+/* Bilinear (align_corners=False) upsample of a 192x192 low-res mask to h_out x w_out fp32, then clamp(min=0).
+ * Replaces F.interpolate(...) + torch.clamp (VSM.py:534-537, visual_search.py:223-224). Host in, host out. */
+int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out);
+
+/* Debug/parity taps: copy an internal activation of the LAST score_batch call to host as fp32.
+ * name in {"clip_features","projector","llm_hidden_loc","embed_det","embed_seg","owl_feats"}.
+ * Returns the number of floats written (<= cap) or a negative error. */
+int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t cap);
+
+/* Stream handle (hipStream_t) the engine launches on, for HIP-event timing by the caller. */
+void* vstar_stream(vstar_handle* h);
+
+/* Last-call kernel timing: the engine brackets the dominant GEMM family with HIP events when enabled.
+ * Returns accumulated GEMM kernel milliseconds and launch count since the last reset. */
+int vstar_profile_enable(vstar_handle* h, int on);
+int vstar_profile_read(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (device pointers).  These are the kernels the engine is built from,
+ * exported so that parity tests can drive each one against the oracle through the same C-ABI.
+ * All tensors are dense row-major; "ld" = leading dimension in elements.  stream may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_EPI_RELU = 3, VSTAR_EPI_SILU_MUL = 4 };
+
+/* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate (MFMA), bf16 or fp32 out.
+ * Replaces every nn.Linear / conv-as-GEMM on the path (SURVEY.md §8d GEMM shape list).
+ * W must have ceil(N/128)*128 rows allocated (rows >= N are never stored) and K % 64 == 0.
+ * For VSTAR_EPI_SILU_MUL, W holds gate/up rows interleaved in blocks of 16 and the output has N/2 columns. */
+int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
+                  const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,
+                  int M, int N, int K, int epilogue);
+/* LayerNorm over the last dim (eps, affine) / LLaMA RMSNorm.  bf16 in/out. */
+int vstar_op_layernorm(void* stream, const uint16_t* dev_x, const uint16_t* dev_gamma, const uint16_t* dev_beta,
+                       uint16_t* dev_y, int rows, int cols, float eps);
+int vstar_op_rmsnorm(void* stream, const uint16_t* dev_x, const uint16_t* dev_gamma, uint16_t* dev_y,
+                     int rows, int cols, float eps);
+/* Multi-head attention softmax(Q K^T * scale [+causal]) V on a fused [B*S, 3*H*D] qkv buffer; D in {64,128}.
+ * If rope_theta > 0, rotate-half RoPE (positions 0..S-1) is applied to q and k first (LLaMA). Output [B*S, H*D]. */
+int vstar_op_attention(void* stream, uint16_t* dev_qkv, uint16_t* dev_out, void* dev_workspace, size_t workspace_bytes,
+                       int B, int S, int H, int D, int causal, float rope_theta);
+size_t vstar_op_attention_workspace(int B, int S, int H, int D);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSTAR_HIP_H */

@@ -1,0 +1,299 @@
+// attention.hip — fused softmax(Q K^T * scale [+ causal mask]) V for gfx950, plus RoPE / V-transpose prep.
+//
+// Replaces HF CLIPAttention / OwlViTAttention (non-causal, 64-d heads; reached from clip_encoder.py:53-57 and
+// owlvit.py:121-126) and HF LlamaAttention (causal, 128-d heads, rotate-half RoPE; llava_llama.py:93-102),
+// and the SAM two-way transformer's Attention (segment_anything/modeling/transformer.py:185-242).
+//
+// attn_forward: one wave64 owns 32 query rows; v_mfma_f32_32x32x16_bf16 for both products.
+//   S^T = K Q^T  (K tile as the A operand, Q^T as B): each lane ends up with ONE query column (lane&31) and 16 of
+//   the tile's 32 keys, so the online-softmax statistics are per-lane scalars (one shuffle with lane^32).
+//   O^T = V^T P^T: P^T is fed straight from the S^T accumulator registers (the contraction order over keys is
+//   permuted identically on the V^T side), so no cross-lane movement or LDS round trip for P.
+//   V^T comes from a [B,H,D,Spad] buffer written once per layer by attn_prepare (8-byte key-contiguous loads).
+//   K/V tiles are read straight from L2 (S <= 2305 keys x 64/128 dims per head fit the 4 MiB XCD L2).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+// ---------------- RoPE (in place on q and k of the fused qkv buffer) ----------------
+// HF rotate-half convention with the reference's bf16 rounding points: each product and the sum are bf16.
+__global__ void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos_sin, int rows, int S, int H, int D) {
+  const int half = D >> 1;
+  const int vec_per_head = half >> 3;                 // 8-element vectors in the first half
+  const int per_row = 2 * H * vec_per_head;           // q and k
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * per_row) return;
+  const int row = (int)(idx / per_row);
+  int rem = (int)(idx - (int64_t)row * per_row);
+  const int which = rem / (H * vec_per_head);         // 0 = q, 1 = k
+  rem -= which * H * vec_per_head;
+  const int h = rem / vec_per_head;
+  const int d0 = (rem - h * vec_per_head) * 8;
+  const int pos = row % S;
+  bf16_t* base = qkv + (int64_t)row * (3 * H * D) + which * (H * D) + h * D;
+  const bf16x8 x1 = *(const bf16x8*)(base + d0);
+  const bf16x8 x2 = *(const bf16x8*)(base + d0 + half);
+  const bf16x8 c = *(const bf16x8*)(cos_sin + (int64_t)pos * D + d0);
+  const bf16x8 sn = *(const bf16x8*)(cos_sin + (int64_t)pos * D + half + d0);
+  bf16x8 o1, o2;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float a = bf2f((bf16_t)x1[e]), b = bf2f((bf16_t)x2[e]);
+    const float cs = bf2f((bf16_t)c[e]), si = bf2f((bf16_t)sn[e]);
+    o1[e] = (short)f2bf(rbf(a * cs) + rbf(-b * si));
+    o2[e] = (short)f2bf(rbf(b * cs) + rbf(a * si));
+  }
+  *(bf16x8*)(base + d0) = o1;
+  *(bf16x8*)(base + d0 + half) = o2;
+}
+
+// ---------------- V -> V^T [B,H,D,Spad] through a padded LDS tile (64 positions x D) ----------------
+template <int D>
+__global__ __launch_bounds__(256) void vt_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt, int S, int Spad,
+                                                 int H) {
+  __shared__ bf16_t tile[64][D + 2];
+  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  constexpr int VPR = D / 8;  // 16-B vectors per row
+  for (int i = tid; i < 64 * VPR; i += 256) {
+    const int r = i / VPR, cv = i - r * VPR;
+    const int s = s0 + r;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < S) v = *(const bf16x8*)(qkv + ((int64_t)b * S + s) * (3 * H * D) + 2 * H * D + h * D + cv * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][cv * 8 + e] = (bf16_t)v[e];
+  }
+  __syncthreads();
+  // each thread writes 8 consecutive positions of one d-row: 64 positions = 8 vectors per d-row
+  for (int i = tid; i < D * 8; i += 256) {
+    const int d = i >> 3, sv = i & 7;
+    if (s0 + sv * 8 >= Spad) continue;
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)tile[sv * 8 + e][d];
+    *(bf16x8*)(vt + (((int64_t)b * H + h) * D + d) * Spad + s0 + sv * 8) = o;
+  }
+}
+
+// ---------------- flash attention forward ----------------
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
+                                                   bf16_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
+  constexpr int KS = D / 16;   // MFMA k-steps over the head dim
+  constexpr int DB = D / 32;   // 32-row blocks of O^T
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  if (q0 >= S) return;
+  const int qi = lane & 31, h2 = lane >> 5;
+  const int query = q0 + qi;
+  const int qrow = query < S ? query : S - 1;
+  const int64_t ld = 3 * (int64_t)H * D;
+  const bf16_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
+  const bf16_t* Kb = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D + h2 * 8;
+  const bf16_t* Vb = vt + (((int64_t)b * H + h) * D + qi) * Spad + 4 * h2;
+
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+
+  const int kend = CAUSAL ? min(S, q0 + 32) : S;
+  for (int kt0 = 0; kt0 < kend; kt0 += 32) {
+    // ---- S^T tile = K[kt0..kt0+31] . Q^T ----
+    int krow = kt0 + qi;
+    krow = krow < S ? krow : S - 1;
+    const bf16_t* Kp = Kb + (int64_t)krow * ld;
+    bf16x8 kf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(Kp + ks * 16);
+    // V^T fragments for this key tile (issued early; consumed after the softmax)
+    bf16x8 vf[2][DB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const bf16_t* vp = Vb + (int64_t)db * 32 * Spad + kt0 + 16 * j;
+        const bf16x4 lo = *(const bf16x4*)(vp);
+        const bf16x4 hi = *(const bf16x4*)(vp + 8);
+        vf[j][db] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
+
+    // ---- online softmax: this lane = query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2 ----
+    float p[16];
+    float mx = -1e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+      float sv = sacc[r] * scale_log2e;
+      const bool masked = (key >= S) || (CAUSAL && key > query);
+      sv = masked ? -1e30f : sv;
+      p[r] = sv;
+      mx = fmaxf(mx, sv);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m, mx);
+    const float alpha = exp2f(m - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = exp2f(p[r] - m_new);
+      rs += p[r];
+    }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T : k-slot (h2, i) of k-block j <-> key kt0 + 16j + 8(i>>2) + 4 h2 + (i&3) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      bf16x8 pb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(p[8 * j + i]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][db], pb, oacc[db], 0, 0, 0);
+    }
+  }
+
+  if (query < S) {
+    const float inv = 1.0f / l;
+    bf16_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(oacc[db][g * 4 + e] * inv);
+        *(bf16x4*)(op + db * 32 + g * 8) = o;
+      }
+  }
+}
+
+// ---------------- small generic attention (SAM head): one wave per (b, head, query) ----------------
+template <int D>
+__global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int B,
+                                                         int Nq, int Nk, int H, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)B * H * Nq) return;
+  const int qi = (int)(wid % Nq);
+  const int h = (int)((wid / Nq) % H);
+  const int b = (int)(wid / ((int64_t)Nq * H));
+  const int C = H * D;
+  float qv[D];
+  const bf16_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) qv[d] = bf2f(qp[d]);
+  // pass 1: scores for this lane's keys (kept for up to 40 keys per lane = 2560 keys)
+  constexpr int MAXK = 40;
+  float sc[MAXK];
+  float mx = -1e30f;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int key = i * 64 + lane;
+    float s = -1e30f;
+    if (key < Nk) {
+      const bf16_t* kp = k + ((int64_t)b * Nk + key) * C + h * D;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) a += qv[d] * bf2f(kp[d]);
+      s = rbf(rbf(a) * scale);     // reference: bf16 matmul, then bf16 divide by sqrt(d)
+    }
+    sc[i] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int key = i * 64 + lane;
+    if (key < Nk) {
+      const float e = __expf(sc[i] - mx);
+      sum += e;
+      sc[i] = e;
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    const int key = i * 64 + lane;
+    if (key < Nk) {
+      const float pr = rbf(sc[i] * inv);   // softmax output is bf16 in the reference
+      const bf16_t* vp = v + ((int64_t)b * Nk + key) * C + h * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] += pr * bf2f(vp[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = wave_sum(o[d]);
+  if (lane == 0) {
+    bf16_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) op[d] = f2bf(o[d]);
+  }
+}
+
+}  // namespace
+
+hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, int S, int Spad, int H, int D, hipStream_t s) {
+  if (D != 64 && D != 128) return hipErrorInvalidValue;
+  if (Spad % 64 != 0 || Spad < S) return hipErrorInvalidValue;
+  if (cos_sin) {
+    const int64_t n = (int64_t)B * S * 2 * H * (D / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_sin, B * S, S, H, D);
+  }
+  dim3 grid(Spad / 64, H, B);
+  if (D == 64) hipLaunchKernelGGL(vt_kernel<64>, grid, dim3(256), 0, s, qkv, vt, S, Spad, H);
+  else hipLaunchKernelGGL(vt_kernel<128>, grid, dim3(256), 0, s, qkv, vt, S, Spad, H);
+  return hipGetLastError();
+}
+
+hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, int D, int causal,
+                        float scale, hipStream_t s) {
+  if (D != 64 && D != 128) return hipErrorInvalidValue;
+  dim3 grid((S + 127) / 128, H, B);
+  const float sl = scale * 1.4426950408889634f;
+  if (D == 64) {
+    if (causal) hipLaunchKernelGGL((attn_kernel<64, true>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
+    else hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
+    else hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
+  }
+  return hipGetLastError();
+}
+
+hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Nq, int Nk, int H,
+                           int D, hipStream_t s) {
+  if (Nk > 40 * 64) return hipErrorInvalidValue;
+  const int64_t waves = (int64_t)B * H * Nq;
+  dim3 grid((unsigned)((waves + 3) / 4));
+  const float scale = 1.0f / sqrtf((float)D);
+  if (D == 32) hipLaunchKernelGGL(small_attn_kernel<32>, grid, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
+  else if (D == 16) hipLaunchKernelGGL(small_attn_kernel<16>, grid, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}

@@ -1,0 +1,268 @@
+// gemm.hip — bf16 MFMA GEMM for gfx950:  C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual)
+//
+// Replaces every nn.Linear / conv-as-GEMM on the VSM scoring path (SURVEY.md §8d shape list):
+// CLIP/OWL-ViT qkv/out/fc1/fc2 (HF CLIPEncoderLayer via clip_encoder.py:53-57, owlvit.py:121-126),
+// mm_projector (llava_arch.py:93-96), LLaMA q/k/v/o/gate/up/down (llava_llama.py:93-102),
+// text_hidden_fcs_* (VSM.py:120-140), OWL-ViT class/box heads (owlvit.py:79-119), SAM head linears/convs.
+//
+// Design (CDNA4): 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile = 4x4 fragments of
+// v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous ("NT"), staged HBM->LDS with 16-byte
+// global_load_lds (no VGPR round trip), two LDS buffers, next tile's DMA issued before the current tile's
+// MFMAs.  LDS rows are 128 B (8 x 16-B chunks); chunk index is XOR-swizzled with (row>>1)&7 so that every
+// ds_read_b128 lane group touches 16 distinct 16-B slots (conflict-free).  global_load_lds writes
+// lane-linear, so the swizzle is applied on the per-lane SOURCE address and again on the read address.
+// MFMA operands are swapped (W fragment as "A", activation fragment as "B") so that each lane ends up
+// with 4 consecutive output COLUMNS of one row -> 8-byte bf16x4 / 16-byte f32x4 stores, and bias/residual
+// loads of the same shape.  Workgroup ids are remapped XCD-aware (bijective) + grouped along M so that
+// blocks sharing an L2 share weight columns.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_TILE = BM * BK * 2;            // 16 KiB per operand tile
+constexpr int LDS_BUF = 2 * LDS_TILE;            // A + W
+constexpr int LDS_TOTAL = 2 * LDS_BUF;           // double buffered = 64 KiB
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, int64_t off) {
+  if (group <= 0) return (int64_t)r;
+  int g = r / group;
+  return (int64_t)g * gstride + off + (r - g * group);
+}
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- tile id: XCD-aware bijective remap, then GROUP_M ordering ----
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int t;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * tiles_n;
+  const int grp = t / in_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int rem = t - grp * in_group;
+  const int tm = first_m + rem % gsz;
+  const int tn = rem / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- per-lane staging sources (4 x 1-KiB DMA pieces per operand per wave) ----
+  const int st_r = lane >> 3;      // row within the 8-row piece
+  const int st_c = lane & 7;       // 16-B chunk within the 128-B LDS row
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * 4 + wave) * 8 + st_r;          // LDS row 0..127
+    const int cg = st_c ^ ((r >> 1) & 7);             // global chunk that lives at LDS chunk st_c
+    int ar = m0 + r;
+    ar = ar < p.M ? ar : p.M - 1;                     // clamp: rows >= M are computed but never stored
+    a_src[i] = p.A + map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8;
+    w_src[i] = p.W + (int64_t)(n0 + r) * p.K + cg * 8;   // W is padded to a multiple of BN rows
+  }
+
+  auto stage = [&](int buf, int k0) {
+    char* base = smem + buf * LDS_BUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = (i * 4 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + k0), (lptr_t)(base + piece), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + k0), (lptr_t)(base + LDS_TILE + piece), 16, 0, 0);
+    }
+  };
+
+  // ---- fragment read offsets ----
+  const int wr = wave >> 1, wc = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fq) ^ swz) * 16;
+    a_rd[kk] = (wr * 64 + fr) * 128 + ch;
+    w_rd[kk] = LDS_TILE + (wc * 64 + fr) * 128 + ch;
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nkt = p.K / BK;
+  stage(0, 0);
+  __syncthreads();   // drains the DMA (vmcnt(0)) and makes tile 0 visible
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, (kt + 1) * BK);
+    const char* base = smem + cur * LDS_BUF;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) wf[n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[m][n], 0, 0, 0);
+    }
+    __syncthreads();   // next tile landed (vmcnt(0)) + everyone done reading buf[cur]
+  }
+
+  // ---- epilogue: lane owns row (m*16+fr), columns fq*4..fq*4+3 of each 16x16 fragment ----
+  const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int row = m0 + wr * 64 + m * 16 + fr;
+    if (row >= p.M) continue;
+    const int64_t crow = map_row(row, p.c_group, p.c_gstride, p.c_off);
+    if (EPI == VSTAR_EPI_SILU_MUL) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = (n0 + wc * 64) / 2 + j * 16 + fq * 4;
+        if (col >= n_out) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = rbf(acc[m][2 * j][e]);
+          const float u = rbf(acc[m][2 * j + 1][e]);
+          o[e] = act_silu_bf16(g) * u;
+        }
+        if (OUT_F32) {
+          float* c = (float*)p.C + crow * p.ldc + col;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = o[e];
+        } else {
+          bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
+          if (col + 3 < n_out) {
+            bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
+            *(bf16x4*)c = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int col = n0 + wc * 64 + n * 16 + fq * 4;
+        if (col >= n_out) continue;
+        const bool full = (col + 3 < n_out);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[m][n][e];
+        if (p.bias) {
+          if (full) {
+            const bf16x4 b = *(const bf16x4*)(p.bias + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)b[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(p.bias[col + e]);
+          }
+        }
+        if (!OUT_F32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);       // nn.Linear output is bf16 in the reference
+        }
+        if (EPI == VSTAR_EPI_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] / (1.0f + __expf(-1.702f * o[e])) : act_quick_gelu_bf16(o[e]);
+        } else if (EPI == VSTAR_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
+        } else if (EPI == VSTAR_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+        }
+        if (p.res) {
+          const bf16_t* rp = p.res + crow * p.ldr + col;
+          if (!OUT_F32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);     // activation output rounded before the add
+          }
+          if (full) {
+            const bf16x4 rv = *(const bf16x4*)rp;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)rv[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(rp[e]);
+          }
+        }
+        if (OUT_F32) {
+          float* c = (float*)p.C + crow * p.ldc + col;
+          if (full && ((((uintptr_t)c) & 15) == 0)) {
+            *(f32x4*)c = (f32x4){o[0], o[1], o[2], o[3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = o[e];
+          }
+        } else {
+          bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
+          if (full && ((((uintptr_t)c) & 7) == 0)) {
+            bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
+            *(bf16x4*)c = v;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch(const GemmParams& p, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = gemm_bf16_kernel<EPI, OUT_F32>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_TOTAL, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+  if (p.M <= 0 || p.N <= 0) return hipSuccess;
+  if (p.K % BK != 0 || p.K <= 0) return hipErrorInvalidValue;
+  if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
+#define GEMM_CASE(E)                                                   \
+  case E:                                                              \
+    return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);
+  switch (epilogue) {
+    GEMM_CASE(VSTAR_EPI_NONE)
+    GEMM_CASE(VSTAR_EPI_QUICK_GELU)
+    GEMM_CASE(VSTAR_EPI_GELU)
+    GEMM_CASE(VSTAR_EPI_RELU)
+    GEMM_CASE(VSTAR_EPI_SILU_MUL)
+  }
+#undef GEMM_CASE
+  return hipErrorInvalidValue;
+}

@@ -1,0 +1,165 @@
+// heads.hip — OWL-ViT class/box head finishers and the SAM-style mask head's non-GEMM pieces.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+// HF OwlViTClassPredictionHead.forward with ONE query per crop (owlvit.py:102-119,150-170):
+//   e = dense0(x); e /= (||e|| + 1e-6); q /= (||q|| + 1e-6); logit = (e.q + shift(x)) * (elu(scale(x)) + 1)
+// emb row layout (fp32, from one fused GEMM): [0,Q) dense0 | Q shift | Q+1 scale.  bf16 rounding points as in the
+// bf16 reference.  One wave per image token.
+__global__ __launch_bounds__(256) void owl_class_kernel(const float* __restrict__ emb, int ld, int Q,
+                                                        const bf16_t* __restrict__ query, float* __restrict__ out,
+                                                        int out_stride_crop, int B, int rows_per_crop) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * rows_per_crop) return;
+  const int b = (int)(row / rows_per_crop), p = (int)(row % rows_per_crop);
+  const float* er = emb + row * ld;
+  const bf16_t* qr = query + (int64_t)b * Q;
+  float ee = 0.f, qq = 0.f;
+  for (int d = lane; d < Q; d += 64) {
+    const float e = rbf(er[d]), q = bf2f(qr[d]);
+    ee += e * e;
+    qq += q * q;
+  }
+  ee = wave_sum(ee);
+  qq = wave_sum(qq);
+  const float en = rbf(rbf(sqrtf(ee)) + 1e-6f), qn = rbf(rbf(sqrtf(qq)) + 1e-6f);
+  float dot = 0.f;
+  for (int d = lane; d < Q; d += 64) dot += rbf(rbf(er[d]) / en) * rbf(bf2f(qr[d]) / qn);
+  dot = rbf(wave_sum(dot));
+  if (lane == 0) {
+    const float shift = rbf(er[Q]);
+    const float sc = rbf(er[Q + 1]);
+    const float elu = sc > 0.f ? sc : (__expf(sc) - 1.0f);
+    const float scale = rbf(rbf(elu) + 1.0f);
+    out[(int64_t)b * out_stride_crop + p] = rbf(rbf(dot + shift) * scale);
+  }
+}
+
+// box_predictor: pred = sigmoid(box_head(x) + box_bias)  (owlvit.py:63-100)
+__global__ void owl_box_kernel(const float* __restrict__ raw, int ld, float* __restrict__ out, int out_stride_crop, int B,
+                               int grid) {
+  const int npatch = grid * grid;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * npatch * 4) return;
+  const int c = (int)(idx & 3);
+  const int64_t row = idx >> 2;
+  const int p = (int)(row % npatch), b = (int)(row / npatch);
+  float coord;
+  if (c == 0) coord = (float)(p % grid + 1) / (float)grid;
+  else if (c == 1) coord = (float)(p / grid + 1) / (float)grid;
+  else coord = 1.0f / (float)grid;
+  coord = fminf(fmaxf(coord, 0.f), 1.f);
+  const float bias = logf(coord + 1e-4f) - log1pf(-coord + 1e-4f);
+  const float v = rbf(rbf(raw[row * ld + c]) + bias);
+  out[(int64_t)b * out_stride_crop + p * 4 + c] = rbf(1.0f / (1.0f + __expf(-v)));
+}
+
+// mask_decoder.Upsample: F.interpolate(x.float(), scale_factor=2, "bilinear").to(bf16) then Conv2d 3x3 pad 1
+// (mask_decoder.py:15-27).  Emits the conv's im2col matrix directly: A[(b,Y,X)][(ky*3+kx)*C + c].
+__global__ void up2x_im2col_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ A, int B, int h, int w, int C) {
+  const int cv = C >> 3;
+  const int H2 = 2 * h, W2 = 2 * w;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * H2 * W2 * 9 * cv;
+  if (idx >= total) return;
+  const int v = (int)(idx % cv);
+  int64_t r = idx / cv;
+  const int tap = (int)(r % 9);
+  r /= 9;
+  const int X = (int)(r % W2);
+  const int Y = (int)((r / W2) % H2);
+  const int b = (int)(r / ((int64_t)W2 * H2));
+  const int yy = Y + tap / 3 - 1, xx = X + tap % 3 - 1;
+  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
+    const float sy = fmaxf(0.5f * (yy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (xx + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0;
+    const bf16_t* base = src + (int64_t)b * h * w * C + v * 8;
+    const bf16x8 v00 = *(const bf16x8*)(base + ((int64_t)y0 * w + x0) * C);
+    const bf16x8 v01 = *(const bf16x8*)(base + ((int64_t)y0 * w + x1) * C);
+    const bf16x8 v10 = *(const bf16x8*)(base + ((int64_t)y1 * w + x0) * C);
+    const bf16x8 v11 = *(const bf16x8*)(base + ((int64_t)y1 * w + x1) * C);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = (1.f - ly) * ((1.f - lx) * bf2f((bf16_t)v00[e]) + lx * bf2f((bf16_t)v01[e])) +
+                      ly * ((1.f - lx) * bf2f((bf16_t)v10[e]) + lx * bf2f((bf16_t)v11[e]));
+      o[e] = (short)f2bf(t);
+    }
+  }
+  *(bf16x8*)(A + idx * 8) = o;
+}
+
+// masks = hyper_in @ upscaled_embedding.view(b, c, h*w)  (mask_decoder.py:176-181), mask token 0 only
+template <int C>
+__global__ void hyper_mask_kernel(const bf16_t* __restrict__ hyper, const bf16_t* __restrict__ up, float* __restrict__ out,
+                                  int out_stride_crop, int B, int npix) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * npix) return;
+  const int b = (int)(idx / npix), pix = (int)(idx % npix);
+  const bf16_t* u = up + idx * C;
+  const bf16_t* hy = hyper + (int64_t)b * C;
+  float a = 0.f;
+#pragma unroll
+  for (int v = 0; v < C / 8; ++v) {
+    const bf16x8 x = *(const bf16x8*)(u + v * 8);
+    const bf16x8 w = *(const bf16x8*)(hy + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += bf2f((bf16_t)x[e]) * bf2f((bf16_t)w[e]);
+  }
+  out[(int64_t)b * out_stride_crop + pix] = rbf(a);
+}
+
+// F.interpolate(low_res.float(), (h, w), "bilinear", align_corners=False) + clamp(min=0)  (VSM.py:534-537, visual_search.py:223-224)
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int hin, int win, float* __restrict__ out, int hout,
+                                       int wout, float rh, float rw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)hout * wout) return;
+  const int x = (int)(idx % wout), y = (int)(idx / wout);
+  const float sy = fmaxf(rh * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(rw * (x + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+  const float ly = sy - y0, lx = sx - x0;
+  const float t = (1.f - ly) * ((1.f - lx) * in[y0 * win + x0] + lx * in[y0 * win + x1]) +
+                  ly * ((1.f - lx) * in[y1 * win + x0] + lx * in[y1 * win + x1]);
+  out[idx] = fmaxf(t, 0.f);
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t owl_class_logits(const float* emb, int ld, int Q, const bf16_t* query, float* out, int out_stride_crop, int B,
+                            int rows_per_crop, hipStream_t s) {
+  const int64_t rows = (int64_t)B * rows_per_crop;
+  hipLaunchKernelGGL(owl_class_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, emb, ld, Q, query, out,
+                     out_stride_crop, B, rows_per_crop);
+  return hipGetLastError();
+}
+hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s) {
+  hipLaunchKernelGGL(owl_box_kernel, dim3(nblk((int64_t)B * grid * grid * 4)), dim3(256), 0, s, raw, ld, out,
+                     out_stride_crop, B, grid);
+  return hipGetLastError();
+}
+hipError_t upsample2x_im2col3x3(const bf16_t* src, bf16_t* A, int B, int h, int w, int C, hipStream_t s) {
+  if (C % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(up2x_im2col_kernel, dim3(nblk((int64_t)B * 4 * h * w * 9 * (C / 8))), dim3(256), 0, s, src, A, B, h,
+                     w, C);
+  return hipGetLastError();
+}
+hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out_stride_crop, int B, int npix, int C,
+                      hipStream_t s) {
+  if (C != 32) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(hyper_mask_kernel<32>, dim3(nblk((int64_t)B * npix)), dim3(256), 0, s, hyper, up, out,
+                     out_stride_crop, B, npix);
+  return hipGetLastError();
+}
+hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s) {
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nblk((int64_t)hout * wout)), dim3(256), 0, s, in, hin, win, out, hout,
+                     wout, (float)hin / (float)hout, (float)win / (float)wout);
+  return hipGetLastError();
+}

@@ -1,0 +1,69 @@
+// kernels.hpp — host-side launch interface of the gfx950 kernels (internal; the public ABI is include/vstar_hip.h)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vstar_hip.h"
+
+typedef uint16_t bf16_t;
+
+// Row maps let a GEMM read/write a strided sub-sequence without a gather pass:
+//   mapped(r) = (r / group) * gstride + off + r % group      (group <= 0: identity)
+struct GemmParams {
+  const bf16_t* A; int64_t lda; int a_group; int64_t a_gstride; int64_t a_off;
+  const bf16_t* W;          // [ceil(N/128)*128, K], K % 64 == 0
+  const bf16_t* bias;       // [N] or null
+  const bf16_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
+  void* C; int64_t ldc; int c_group; int64_t c_gstride; int64_t c_off;
+  int M, N, K;
+};
+hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+
+// ---- norms (norm.hip) ----
+// y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
+hipError_t layernorm_bf16(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, int rows, int cols,
+                          float eps, const int32_t* row_index, int act, hipStream_t s);
+hipError_t rmsnorm_bf16(const bf16_t* x, const bf16_t* gamma, bf16_t* y, int rows, int cols, float eps,
+                        const int32_t* row_index, hipStream_t s);
+
+// ---- attention (attention.hip) ----
+// qkv: [B*S, 3*H*D] (q | k | v).  rope_and_vt: in-place rotate-half RoPE on q,k (if cs != null) and V^T -> vt[B,H,D,Spad]
+hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), bf16, or null*/,
+                        int B, int S, int Spad, int H, int D, hipStream_t s);
+hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, int D,
+                        int causal, float scale, hipStream_t s);
+// generic small attention for the SAM head: q[B,Nq,H*D] k[B,Nk,H*D] v[B,Nk,H*D] -> out[B,Nq,H*D]; D <= 32, fp32 math
+hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Nq, int Nk, int H,
+                           int D, hipStream_t s);
+
+// ---- elementwise / layout (elementwise.hip) ----
+// pix [B,3,I,I] -> A [B*P, Kpad], k = c*ps*ps + ky*ps + kx, zero padded to Kpad
+hipError_t im2col_patch(const bf16_t* pix, bf16_t* A, int B, int I, int ps, int Kpad, hipStream_t s);
+// tokens[b,0]=cls+pos[0]; tokens[b,1+p]=patch[b,p]+pos[1+p]   (bf16 add)
+hipError_t vit_assemble_tokens(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* tokens, int B, int P,
+                               int C, hipStream_t s);
+// LLaMA input embeddings for the text positions of the spliced sequence (image rows are written by the projector GEMM)
+hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const bf16_t* table, int vocab, bf16_t* x, int B,
+                          int C, hipStream_t s);
+// out[r, :] = a[r, :] + b[(r % b_rows), :]   (bf16 add; b broadcast over groups of b_rows)
+hipError_t add_bcast(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s);
+// OWL-ViT: y[b,p,:] = x[b,1+p,:] * x[b,0,:]  (x = post_layernorm output, [B,N,C]) -> [B,N-1,C]
+hipError_t owl_cls_mul(const bf16_t* x, bf16_t* y, int B, int N, int C, hipStream_t s);
+// gather rows: y[r,:] = x[idx[r],:]
+hipError_t gather_rows(const bf16_t* x, const int32_t* idx, bf16_t* y, int rows, int cols, hipStream_t s);
+// argmax over fp32 logits rows
+hipError_t argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, int out_stride, hipStream_t s);
+
+// ---- heads (heads.hip) ----
+// class head: emb [R, ldc] fp32 = dense0(512) | shift | scale ; query [B, Q] bf16; rows_per_crop = 2304
+hipError_t owl_class_logits(const float* emb, int ld, int Q, const bf16_t* query, float* out, int out_stride_crop,
+                            int B, int rows_per_crop, hipStream_t s);
+// box head final: raw [R, 4] fp32 (dense2 out incl. bias) + grid bias -> sigmoid -> out[b*stride + p*4 ..]
+hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s);
+// SAM upscaling: bilinear x2 (align_corners=False, fp32 -> bf16) fused with 3x3 im2col (zero pad):
+// src [B, h, w, C] channels-last -> A [B*(2h)*(2w), 9*C], k = (ky*3+kx)*C + c
+hipError_t upsample2x_im2col3x3(const bf16_t* src, bf16_t* A, int B, int h, int w, int C, hipStream_t s);
+// masks[b, pix] = sum_c hyper[b,c] * up[b,pix,c]  (bf16 in, fp32 accumulate, bf16-rounded like the reference matmul) -> fp32
+hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out_stride_crop, int B, int npix, int C,
+                      hipStream_t s);
+// bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0)
+hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s);
