@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py — searched crops/sec of the VSM scoring path on MI355X (BASELINE.json metric).
+
+One "step" = one batch of 32 crops per GPU through the whole per-crop path (CLIP-ViT-L/14@336 -> mm_projector ->
+LLaMA-7B prefill over S=640 -> [LOC] hidden -> fcs heads -> OWL-ViT-B/16@768 tower -> class/box heads -> SAM-style mask
+head), inputs already resident in HBM, bf16, seeded random weights of the real architecture (no network for checkpoints),
+synthetic pixels/ids of the BASELINE config-2 shape.  With N GPUs each rank scores its own 32 crops (weak scaling) and
+the fixed-size result records are all-gathered over RCCL every step, as the search loop needs them.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the bf16 MFMA GEMM,
+timed live with HIP events on the engine's stream) and `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from vstar_amd import _lib  # noqa: E402
+from vstar_amd.config import VSMConfig  # noqa: E402
+from vstar_amd.engine import VstarEngine  # noqa: E402
+from vstar_amd.weights import random_state_dict  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
+    """The oracle (a port of the reference's per-crop graph) on the host cores: ONE crop through the real-size CLIP-L
+    tower, projector, 2 of the 32 LLaMA-7B layers (time scaled x16), heads, OWL-ViT tower and SAM head, fp32."""
+    from oracle import vsm_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    n_l = 2
+    small = VSMConfig(**{**cfg.__dict__, "llm_layers": n_l, "llm_vocab": 1024})
+    sd = random_state_dict(small, seed=1, dtype=torch.float32, share_layers=True)
+    g = torch.Generator().manual_seed(0)
+    clip = torch.randn(1, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g)
+    owl = torch.randn(1, 3, cfg.owl_image_size, cfg.owl_image_size, generator=g)
+    L = text_tokens + 1
+    ids = torch.randint(3, 1000, (1, L), generator=g)
+    ids[0, 0] = 1
+    ids[0, 35] = -200
+    ids[0, L - 3] = 1023
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        feats = vsm_oracle.clip_features(sd, clip, cfg.clip_heads, cfg.clip_layers, cfg.clip_select_layer)
+        proj = vsm_oracle._lin(sd, "model.mm_projector", feats)
+        x = vsm_oracle.splice(sd, ids, proj)
+        t1 = time.perf_counter()
+        h = vsm_oracle.llama_prefill(sd, x, cfg.llm_heads, n_l, cfg.llm_rms_eps, cfg.llm_rope_theta)
+        t2 = time.perf_counter()
+        hl = h[:, -3]
+        det = vsm_oracle.text_hidden_fcs(sd, "det", hl)
+        seg = vsm_oracle.text_hidden_fcs(sd, "seg", hl)
+        fmap = vsm_oracle.owl_visual_embs(sd, owl, cfg.owl_heads, cfg.owl_layers)
+        vsm_oracle.owl_heads(sd, fmap, det.unsqueeze(1))
+        vsm_oracle.sam_mask_head(sd, fmap, seg)
+        t3 = time.perf_counter()
+    llm = (t2 - t1) * (cfg.llm_layers / n_l)
+    total = (t1 - t0) + llm + (t3 - t2)
+    return {"value": round(1.0 / total, 5), "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"1 crop fp32 on torch CPU: CLIP-L/14@{cfg.clip_image_size} + projector {t1 - t0:.2f}s, "
+                      f"{n_l} of {cfg.llm_layers} LLaMA-7B layers at S={x.shape[1]} {t2 - t1:.2f}s scaled x{cfg.llm_layers // n_l}, "
+                      f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step (BASELINE config 2: 32)")
+    ap.add_argument("--image-size", type=int, default=336)
+    ap.add_argument("--text-tokens", type=int, default=64)
+    ap.add_argument("--tiny", action="store_true", help="plumbing check with the tiny-width model (NOT a valid bench)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--skip-owl", action="store_true", help="core path only (diagnostic; NOT the headline metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+
+    B, T = args.batch, args.text_tokens
+    L = T + 1
+    if args.tiny:
+        cfg = VSMConfig.tiny(clip_image_size=args.image_size, max_batch=B, max_text_len=L)
+    else:
+        cfg = VSMConfig.seal_7b(args.image_size, max_batch=B, max_text_len=L)
+    P = cfg.n_img_tokens
+    S = P + T
+    t0 = time.perf_counter()
+    eng = VstarEngine(cfg, local_rank)
+    eng.load_state_dict(random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True))
+    t_load = time.perf_counter() - t0
+
+    # synthetic crop batch, resident in HBM before the timed region
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    clip = torch.randn(B, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g, device=dev).bfloat16()
+    owl = torch.randn(B, 3, cfg.owl_image_size, cfg.owl_image_size, generator=g, device=dev).bfloat16()
+    rng = np.random.default_rng(rank)
+    ids = rng.integers(3, cfg.llm_vocab - 5, size=(B, L), dtype=np.int32)
+    ids[:, 0] = 1
+    ids[:, 35 if L > 40 else 2] = -200
+    loc = np.full((B,), (L - 3) - 1 + (P - 1), dtype=np.int32)
+    verify = np.stack([loc, loc + 1, loc + 2], axis=1).astype(np.int32)
+    nv = verify.shape[1]
+    rec_dev = torch.empty((B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
+    flags = _lib.F_DEVICE_INPUTS | _lib.F_DEVICE_OUTPUT | (_lib.F_SKIP_OWL if args.skip_owl else 0)
+    import ctypes
+    vp = ctypes.c_void_p
+
+    def step():
+        _lib.check(eng.lib.vstar_vsm_score_batch(
+            eng.handle, B, vp(clip.data_ptr()), vp(owl.data_ptr()), ids.ctypes.data_as(vp), L, loc.ctypes.data_as(vp),
+            verify.ctypes.data_as(vp), nv, flags, vp(rec_dev.data_ptr())), eng.handle)   # synchronises the engine stream
+        if world > 1:
+            out = torch.empty((world * B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(out, rec_dev)
+            return out
+        return rec_dev
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    crops_per_s = world * B * args.steps / dt
+
+    # roofline of the dominant kernel family (bf16 MFMA GEMM): HIP events around every GEMM launch on the engine stream
+    eng.profile(True)
+    for _ in range(2):
+        step()
+    gemm_ms, gemm_n, gemm_flops = eng.profile_read()
+    eng.profile(False)
+    achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    fl = cfg.flops_per_crop(T, full=not args.skip_owl)
+    per_crop = fl["core"] if args.skip_owl else fl["full"]
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "kernel": "gemm_bf16_kernel (all epilogues)", "launches_per_step": gemm_n // 2,
+                "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
+                "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
+                "end_to_end_tflops_per_gpu": round(crops_per_s / world * per_crop / 1e12, 1),
+                "end_to_end_frac": round(crops_per_s / world * per_crop / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline and not args.tiny:
+            cpu = cpu_baseline(cfg, T)
+        line = {
+            "metric": "searched crops/sec (336x336 tiles, 7B VSM bf16)", "value": round(crops_per_s, 3), "unit": "crops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic (seeded random weights of the real architecture, N(0,1) pixels, random ids)",
+            "config": {"workload": ("TINY-plumbing " if args.tiny else "") +
+                       f"BASELINE config 2: {B}-crop batches/GPU, CLIP-ViT-L/14@{cfg.clip_image_size} (P={P}) + LLaMA-7B prefill "
+                       f"S={S} + " + ("(core only)" if args.skip_owl else "OWL-ViT-B/16@768 + det/SAM heads") +
+                       ", records all-gathered per step",
+                       "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
+                       "flops_per_crop": per_crop, "weights_load_s": round(t_load, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

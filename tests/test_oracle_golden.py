@@ -1,0 +1,51 @@
+"""Pins oracle/vsm_oracle.py against the golden vectors produced by the REFERENCE implementation
+(oracle/gen_golden.py ran the reference's own model_forward(inference=True) in the build container)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsm_oracle
+from oracle.gen_golden import make_inputs
+from vstar_amd.config import VSMConfig
+from vstar_amd.weights import random_state_dict
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def load_case(path):
+    z = np.load(path)
+    kw = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
+    return z, VSMConfig.tiny(**kw), int(z["weight_seed"]), int(z["loc_id"])
+
+
+def test_fixtures_present():
+    assert len(GOLDEN) >= 3
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_reference_golden(path):
+    z, cfg, wseed, loc_id = load_case(path)
+    sd = random_state_dict(cfg, seed=wseed, dtype=torch.float32)
+    for i, (seed, L, img_col, loc_col) in enumerate(z["crops"]):
+        clip, owl, ids = make_inputs(cfg, int(seed), int(L), int(img_col), int(loc_col), loc_id)
+        # the synthetic inputs regenerate bit-identically from their seed
+        assert abs(clip.double().sum().item() - z["in_checksum"][i][0]) < 1e-6
+        assert np.array_equal(ids[0].numpy().astype(np.int32), z["ids"][i])
+        o = vsm_oracle.vsm_forward(sd, cfg, clip, owl, ids, loc_id)
+
+        def close(name, got, tol=2e-5):
+            ref = torch.from_numpy(z[name][i])
+            err = (got.reshape(ref.shape) - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+            assert err < tol, (name, err)
+
+        close("clip_features", o["clip_features"][0])
+        close("llm_hidden_loc", o["llm_hidden_loc"][0])
+        close("embed_det", o["embed_det"][0])
+        close("embed_seg", o["embed_seg"][0])
+        close("pred_logits", o["pred_logits"][0, :, 0])
+        close("pred_boxes", o["pred_boxes"][0])
+        close("low_res_masks", o["low_res_masks"][0, 0])
+        assert int(o["loc_pos"][0]) == int(loc_col) - 1 + cfg.n_img_tokens - 1

@@ -1,0 +1,100 @@
+"""ctypes binding of libvstar_hip.so (the C-ABI declared in include/vstar_hip.h).
+
+There is deliberately no CPU / PyTorch fallback: if the HIP library is missing or no GPU is visible, every compute
+entry point raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` or `vstar_amd/csrc/build.sh`.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_uint16, c_void_p
+
+from .config import CVstarConfig, MASK_RES, MAX_VERIFY, N_BOXES
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvstar_hip.so")
+
+# every symbol include/vstar_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "vstar_create", "vstar_destroy", "vstar_last_error", "vstar_load_tensor", "vstar_finalize_weights",
+    "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
+    "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
+    "vstar_op_attention_workspace",
+]
+
+F32, F16, BF16 = 0, 1, 2
+EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
+F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC = 1, 2, 4, 8
+
+
+class VstarResult(ctypes.Structure):
+    _fields_ = [
+        ("pred_logits", c_float * N_BOXES),
+        ("pred_boxes", c_float * (N_BOXES * 4)),
+        ("lowres_mask", c_float * (MASK_RES * MASK_RES)),
+        ("tf_argmax", c_int32 * MAX_VERIFY),
+    ]
+
+
+RESULT_FLOATS = ctypes.sizeof(VstarResult) // 4
+
+
+class VstarError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads the shared library and declares the prototypes.  Raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VstarError(f"{LIB_PATH} not built — run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                         "there is no CPU fallback for the HIP engine")
+    lib = ctypes.CDLL(LIB_PATH)
+    H = c_void_p
+    lib.vstar_create.argtypes = [POINTER(CVstarConfig), c_int, POINTER(H)]
+    lib.vstar_create.restype = c_int
+    lib.vstar_destroy.argtypes = [H]
+    lib.vstar_destroy.restype = None
+    lib.vstar_last_error.argtypes = [H]
+    lib.vstar_last_error.restype = c_char_p
+    lib.vstar_load_tensor.argtypes = [H, c_char_p, c_void_p, c_int, c_int, POINTER(c_int64)]
+    lib.vstar_load_tensor.restype = c_int
+    lib.vstar_finalize_weights.argtypes = [H]
+    lib.vstar_finalize_weights.restype = c_int
+    lib.vstar_vsm_score_batch.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_uint,
+                                          c_void_p]
+    lib.vstar_vsm_score_batch.restype = c_int
+    lib.vstar_upsample_mask.argtypes = [H, c_void_p, c_int, c_int, c_void_p]
+    lib.vstar_upsample_mask.restype = c_int
+    lib.vstar_debug_read.argtypes = [H, c_char_p, c_void_p, c_int64]
+    lib.vstar_debug_read.restype = c_int64
+    lib.vstar_stream.argtypes = [H]
+    lib.vstar_stream.restype = c_void_p
+    lib.vstar_profile_enable.argtypes = [H, c_int]
+    lib.vstar_profile_enable.restype = c_int
+    lib.vstar_profile_read.argtypes = [H, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]
+    lib.vstar_profile_read.restype = c_int
+    lib.vstar_op_gemm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                  c_int, c_int, c_int, c_int, c_int]
+    lib.vstar_op_gemm.restype = c_int
+    lib.vstar_op_layernorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
+    lib.vstar_op_layernorm.restype = c_int
+    lib.vstar_op_rmsnorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
+    lib.vstar_op_rmsnorm.restype = c_int
+    lib.vstar_op_attention.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, c_int, c_int,
+                                       c_float]
+    lib.vstar_op_attention.restype = c_int
+    lib.vstar_op_attention_workspace.argtypes = [c_int, c_int, c_int, c_int]
+    lib.vstar_op_attention_workspace.restype = c_size_t
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None) -> None:
+    if rc != 0:
+        msg = load().vstar_last_error(handle)
+        raise VstarError(f"libvstar_hip error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,42 @@
+"""Data-parallel sharding of a crop batch across the GPUs of one node (no counterpart in the reference,
+whose inference is single-GPU batch-1).  One process per GPU, weights replicated, crops dealt round-robin, and ONE
+collective per search step: an all-gather of the fixed-size per-crop result records (`vstar_result`, 193,568 B) so that
+every rank can take the next-step decision deterministically.  Backend "nccl" is RCCL over xGMI on ROCm; "gloo" on CPU
+is used by the world_size-2 tests."""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Round-robin deal: item i goes to rank i % world."""
+    return list(range(rank, n_items, world))
+
+
+def pad_count(n_items: int, world: int) -> int:
+    """Records per rank after padding so that every rank contributes the same count to the all-gather."""
+    return (n_items + world - 1) // world
+
+
+def allgather_records(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
+    """local: [pad_count, R] records of this rank's shard (rows beyond the shard are padding).  Returns [n_items, R]
+    in the ORIGINAL item order on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local[:n_items]
+    per = local.shape[0]
+    gathered = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
+    gathered = gathered.view(world, per, *local.shape[1:])
+    # item i lives at [i % world, i // world]
+    idx = torch.arange(n_items, device=local.device)
+    return gathered[idx % world, idx // world]
+
+
+def allgather_numpy(local: np.ndarray, n_items: int, device: str = "cpu") -> np.ndarray:
+    t = torch.from_numpy(np.ascontiguousarray(local)).to(device)
+    return allgather_records(t, n_items).cpu().numpy()

@@ -1,0 +1,176 @@
+"""Python face of the HIP engine: weight hand-over and the batched per-crop scoring call.
+
+`VstarEngine.score_batch` is the batched, single-prefill equivalent of `VSMForCausalLM.inference(...)` /
+`model_forward(inference=True)` (VisualSearch/model/VSM.py:438-553, 201-364).  All arithmetic happens in
+libvstar_hip.so; torch is used here only to hold host/device buffers.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import IMAGE_TOKEN_INDEX, MASK_RES, MAX_VERIFY, N_BOXES, VSMConfig
+from .weights import dense_pe, state_dict_spec
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+
+
+def _as_bf16(t) -> torch.Tensor:
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    if t.dtype != torch.bfloat16:
+        t = t.to(torch.bfloat16)
+    return t.contiguous()
+
+
+class VstarEngine:
+    def __init__(self, cfg: VSMConfig, device: int = 0):
+        self.cfg = cfg
+        self.lib = _lib.load()
+        self.handle = ctypes.c_void_p()
+        c = cfg.to_c()
+        _lib.check(self.lib.vstar_create(ctypes.byref(c), device, ctypes.byref(self.handle)))
+        self.device = device
+        self.finalized = False
+
+    # ---- weights (replaces VSMForCausalLM.from_pretrained + get_vision_tower(), visual_search.py:157-161) ----
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        spec = state_dict_spec(self.cfg)
+        needed = [k for k in spec if not k.endswith("gaussian_matrix")]
+        for k in needed:
+            if k not in sd:
+                if strict:
+                    raise KeyError(f"checkpoint tensor missing: {k}")
+                continue
+            t = sd[k]
+            # layers of the CLIP tower beyond hidden_states[select_layer] are never executed
+            if k.startswith("clip.vision_model.encoder.layers."):
+                if int(k.split(".")[4]) >= self.cfg.clip_blocks:
+                    continue
+            if k.startswith("clip.vision_model.post_layernorm"):
+                continue
+            self._load(k, t)
+        gm = sd["model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
+        self._load("sam.dense_pe", dense_pe(gm.cpu()))
+        _lib.check(self.lib.vstar_finalize_weights(self.handle), self.handle)
+        self.finalized = True
+
+    def _load(self, key: str, t: torch.Tensor) -> None:
+        t = t.detach().cpu().contiguous()
+        if t.dtype not in _DT:
+            t = t.float()
+        shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+        _lib.check(self.lib.vstar_load_tensor(self.handle, key.encode(), ctypes.c_void_p(t.data_ptr()), _DT[t.dtype], t.dim(),
+                                              shape), self.handle)
+
+    # ---- the hot path ----
+    def score_batch(self, clip_pix, owl_pix, input_ids, loc_pos, verify_pos=None, skip_owl: bool = False,
+                    sync: bool = True) -> Optional[Dict[str, np.ndarray]]:
+        """clip_pix [B,3,I,I], owl_pix [B,3,768,768] (bf16-castable; CPU or cuda tensors), input_ids [B,L] with one -200,
+        loc_pos [B] spliced-sequence index of the hidden state that predicts [LOC]; verify_pos [B,V] optional."""
+        cfg = self.cfg
+        clip_pix = _as_bf16(clip_pix)
+        B = clip_pix.shape[0]
+        I = cfg.clip_image_size
+        assert tuple(clip_pix.shape) == (B, 3, I, I), clip_pix.shape
+        flags = 0
+        if skip_owl:
+            flags |= _lib.F_SKIP_OWL
+            owl_ptr = None
+        else:
+            owl_pix = _as_bf16(owl_pix)
+            assert tuple(owl_pix.shape) == (B, 3, cfg.owl_image_size, cfg.owl_image_size), owl_pix.shape
+            assert owl_pix.device == clip_pix.device
+            owl_ptr = ctypes.c_void_p(owl_pix.data_ptr())
+        if clip_pix.is_cuda:
+            flags |= _lib.F_DEVICE_INPUTS
+        if not sync:
+            flags |= _lib.F_NO_SYNC
+        ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.int32))
+        assert ids.ndim == 2 and ids.shape[0] == B
+        loc = np.ascontiguousarray(np.asarray(loc_pos, dtype=np.int32))
+        nv = 0
+        vptr = None
+        if verify_pos is not None:
+            vp = np.ascontiguousarray(np.asarray(verify_pos, dtype=np.int32)).reshape(B, -1)
+            nv = vp.shape[1]
+            assert nv <= MAX_VERIFY
+            vptr = vp.ctypes.data_as(ctypes.c_void_p)
+        out = np.empty((B, _lib.RESULT_FLOATS), dtype=np.float32)
+        self._keep = (clip_pix, owl_pix, ids, loc, out)  # keep alive for no-sync calls
+        _lib.check(self.lib.vstar_vsm_score_batch(
+            self.handle, B, ctypes.c_void_p(clip_pix.data_ptr()), owl_ptr, ids.ctypes.data_as(ctypes.c_void_p),
+            ids.shape[1], loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out.ctypes.data_as(ctypes.c_void_p)),
+            self.handle)
+        if not sync:
+            return None
+        return self.unpack(out, nv)
+
+    @staticmethod
+    def unpack(rec: np.ndarray, n_verify: int = 0) -> Dict[str, np.ndarray]:
+        B = rec.shape[0]
+        o0, o1, o2 = N_BOXES, N_BOXES * 5, N_BOXES * 5 + MASK_RES * MASK_RES
+        return {
+            "pred_logits": rec[:, :o0].reshape(B, N_BOXES, 1),
+            "pred_boxes": rec[:, o0:o1].reshape(B, N_BOXES, 4),
+            "low_res_masks": rec[:, o1:o2].reshape(B, 1, MASK_RES, MASK_RES),
+            "tf_argmax": rec[:, o2:o2 + MAX_VERIFY].view(np.int32)[:, :n_verify].copy(),
+        }
+
+    def upsample_mask(self, low_res: np.ndarray, h: int, w: int) -> np.ndarray:
+        """F.interpolate(low_res.float(), (h, w), bilinear, align_corners=False) + clamp(min=0) on the GPU."""
+        src = np.ascontiguousarray(low_res, dtype=np.float32).reshape(MASK_RES, MASK_RES)
+        out = np.empty((h, w), dtype=np.float32)
+        _lib.check(self.lib.vstar_upsample_mask(self.handle, src.ctypes.data_as(ctypes.c_void_p), h, w,
+                                                out.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        return out
+
+    def debug_read(self, name: str, count: int) -> np.ndarray:
+        out = np.empty((count,), dtype=np.float32)
+        n = self.lib.vstar_debug_read(self.handle, name.encode(), out.ctypes.data_as(ctypes.c_void_p), count)
+        if n < 0:
+            _lib.check(int(n), self.handle)
+        return out[:n]
+
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.vstar_profile_enable(self.handle, 1 if on else 0), self.handle)
+
+    def profile_read(self):
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self.lib.vstar_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.handle)
+        return ms.value, n.value, fl.value
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.vstar_stream(self.handle) or 0)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.vstar_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def loc_positions(input_ids: np.ndarray, loc_token_idx: int, n_img_tokens: int) -> np.ndarray:
+    """Spliced-sequence index of the hidden state that predicts [LOC]: idx([LOC]) - 1 + (P - 1)
+    (the `255` shift of VSM.py:230-234,466-473 generalised to P-1)."""
+    ids = np.asarray(input_ids)
+    out = np.empty((ids.shape[0],), dtype=np.int32)
+    for b in range(ids.shape[0]):
+        w = np.where(ids[b] == loc_token_idx)[0]
+        if w.size == 0:
+            raise IndexError("no [LOC] token in the sequence (the reference fails on pred_mask[-1] here too)")
+        out[b] = int(w[-1]) - 1 + (n_img_tokens - 1)
+    return out
+
+
+__all__ = ["VstarEngine", "loc_positions", "IMAGE_TOKEN_INDEX"]

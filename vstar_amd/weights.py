@@ -1,0 +1,225 @@
+"""Checkpoint key map of the VSM (what `VSMForCausalLM.from_pretrained` + the separately fetched CLIP tower hold,
+visual_search.py:157-161; key list in SURVEY.md §5) and a deterministic synthetic initialiser of that exact key set.
+
+There is no network in the build/bench environment, so benchmarks and parity fixtures use seeded random weights of
+the real architecture; `load_checkpoint_dir` is the path for a real `craigwu/seal_vsm_7b` + `openai/clip-vit-large-patch14`
+checkpoint when one is staged locally.
+"""
+from __future__ import annotations
+
+import math
+import os
+from collections import OrderedDict
+from typing import Dict, Iterable, Tuple
+
+import torch
+
+from .config import VSMConfig
+
+CLIP_PREFIX = "clip."  # the CLIP tower is NOT part of the VSM checkpoint (merge_lora_weights_and_save_hf_model.py:145-150)
+
+
+def _vit_keys(prefix: str, preln: str, hidden: int, mlp: int, layers: int, patch: int, n_tokens: int, post: bool):
+    e = prefix + "embeddings."
+    yield e + "class_embedding", (hidden,)
+    yield e + "patch_embedding.weight", (hidden, 3, patch, patch)
+    yield e + "position_embedding.weight", (n_tokens, hidden)
+    yield prefix + preln + ".weight", (hidden,)
+    yield prefix + preln + ".bias", (hidden,)
+    for i in range(layers):
+        lp = f"{prefix}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            yield lp + f"self_attn.{nm}.weight", (hidden, hidden)
+            yield lp + f"self_attn.{nm}.bias", (hidden,)
+        yield lp + "layer_norm1.weight", (hidden,)
+        yield lp + "layer_norm1.bias", (hidden,)
+        yield lp + "mlp.fc1.weight", (mlp, hidden)
+        yield lp + "mlp.fc1.bias", (mlp,)
+        yield lp + "mlp.fc2.weight", (hidden, mlp)
+        yield lp + "mlp.fc2.bias", (hidden,)
+        yield lp + "layer_norm2.weight", (hidden,)
+        yield lp + "layer_norm2.bias", (hidden,)
+    if post:
+        yield prefix + "post_layernorm.weight", (hidden,)
+        yield prefix + "post_layernorm.bias", (hidden,)
+
+
+def _sam_attn_keys(prefix: str, internal: int):
+    for nm, shp in (("q_proj", (internal, 256)), ("k_proj", (internal, 256)), ("v_proj", (internal, 256)),
+                    ("out_proj", (256, internal))):
+        yield prefix + nm + ".weight", shp
+        yield prefix + nm + ".bias", (shp[0],)
+
+
+def state_dict_spec(cfg: VSMConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Every tensor the engine consumes, with its shape, in a fixed order (the order seeds the synthetic init)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    P = cfg.n_img_tokens
+    # CLIP tower (all 24 layers + post_layernorm exist in the checkpoint; the engine uses clip_blocks of them)
+    for k, v in _vit_keys(CLIP_PREFIX + "vision_model.", "pre_layrnorm", cfg.clip_hidden, cfg.clip_mlp, cfg.clip_layers,
+                          cfg.clip_patch, P + 1, post=True):
+        s[k] = v
+    H, M = cfg.llm_hidden, cfg.llm_mlp
+    s["model.embed_tokens.weight"] = (cfg.llm_vocab, H)
+    for i in range(cfg.llm_layers):
+        lp = f"model.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            s[lp + f"self_attn.{nm}.weight"] = (H, H)
+        s[lp + "mlp.gate_proj.weight"] = (M, H)
+        s[lp + "mlp.up_proj.weight"] = (M, H)
+        s[lp + "mlp.down_proj.weight"] = (H, M)
+        s[lp + "input_layernorm.weight"] = (H,)
+        s[lp + "post_attention_layernorm.weight"] = (H,)
+    s["model.norm.weight"] = (H,)
+    s["lm_head.weight"] = (cfg.llm_vocab, H)
+    s["model.mm_projector.weight"] = (H, cfg.clip_hidden)
+    s["model.mm_projector.bias"] = (H,)
+    # OWL-ViT
+    Po = (cfg.owl_image_size // cfg.owl_patch) ** 2
+    Ho = cfg.owl_hidden
+    for k, v in _vit_keys("model.owlvit.vision_model.", "pre_layernorm", Ho, cfg.owl_mlp, cfg.owl_layers, cfg.owl_patch,
+                          Po + 1, post=True):
+        s[k] = v
+    s["model.owlvit.layer_norm.weight"] = (Ho,)
+    s["model.owlvit.layer_norm.bias"] = (Ho,)
+    Q = cfg.owl_query_dim
+    for nm, shp in (("dense0", (Q, Ho)), ("logit_shift", (1, Ho)), ("logit_scale", (1, Ho))):
+        s[f"model.owlvit.class_head.{nm}.weight"] = shp
+        s[f"model.owlvit.class_head.{nm}.bias"] = (shp[0],)
+    for nm, shp in (("dense0", (Ho, Ho)), ("dense1", (Ho, Ho)), ("dense2", (4, Ho))):
+        s[f"model.owlvit.box_head.{nm}.weight"] = shp
+        s[f"model.owlvit.box_head.{nm}.bias"] = (shp[0],)
+    # heads
+    s["model.visual_projection.weight"] = (256, Ho)
+    for br, od in (("det", Q), ("seg", 256)):
+        s[f"model.text_hidden_fcs_{br}.0.0.weight"] = (H, H)
+        s[f"model.text_hidden_fcs_{br}.0.0.bias"] = (H,)
+        s[f"model.text_hidden_fcs_{br}.0.2.weight"] = (od, H)
+        s[f"model.text_hidden_fcs_{br}.0.2.bias"] = (od,)
+    # SAM prompt encoder / mask decoder
+    s["model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"] = (2, 128)
+    s["model.prompt_encoder.no_mask_embed.weight"] = (1, 256)
+    md = "model.mask_decoder."
+    s[md + "iou_token.weight"] = (1, 256)
+    s[md + "mask_tokens.weight"] = (4, 256)
+    for i in range(2):
+        lp = f"{md}transformer.layers.{i}."
+        for k, v in _sam_attn_keys(lp + "self_attn.", 256):
+            s[k] = v
+        for k, v in _sam_attn_keys(lp + "cross_attn_token_to_image.", 128):
+            s[k] = v
+        for k, v in _sam_attn_keys(lp + "cross_attn_image_to_token.", 128):
+            s[k] = v
+        for n in (1, 2, 3, 4):
+            s[lp + f"norm{n}.weight"] = (256,)
+            s[lp + f"norm{n}.bias"] = (256,)
+        s[lp + "mlp.lin1.weight"] = (2048, 256)
+        s[lp + "mlp.lin1.bias"] = (2048,)
+        s[lp + "mlp.lin2.weight"] = (256, 2048)
+        s[lp + "mlp.lin2.bias"] = (256,)
+    for k, v in _sam_attn_keys(md + "transformer.final_attn_token_to_image.", 128):
+        s[k] = v
+    s[md + "transformer.norm_final_attn.weight"] = (256,)
+    s[md + "transformer.norm_final_attn.bias"] = (256,)
+    s[md + "output_upscaling.0.conv.weight"] = (64, 256, 3, 3)
+    s[md + "output_upscaling.0.conv.bias"] = (64,)
+    s[md + "output_upscaling.1.weight"] = (64,)
+    s[md + "output_upscaling.1.bias"] = (64,)
+    s[md + "output_upscaling.3.conv.weight"] = (32, 64, 3, 3)
+    s[md + "output_upscaling.3.conv.bias"] = (32,)
+    for j in range(3):
+        s[md + f"output_hypernetworks_mlps.0.layers.{j}.weight"] = (256 if j < 2 else 32, 256)
+        s[md + f"output_hypernetworks_mlps.0.layers.{j}.bias"] = (256 if j < 2 else 32,)
+    return s
+
+
+def _is_norm_weight(key: str) -> bool:
+    k = key.rsplit(".", 1)[0]
+    last = k.rsplit(".", 1)[-1]
+    return key.endswith(".weight") and (
+        "norm" in last or last == "pre_layrnorm" or k.endswith("output_upscaling.1"))
+
+
+def random_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16,
+                      keys: Iterable[str] | None = None, share_layers: bool = False) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights: norm gains 1+N(0,0.1), biases/embeddings N(0,0.02), matrices N(0, 1/fan_in).
+    Each tensor draws from its own generator seeded by (seed, index) so any subset reproduces bit-identically.
+    share_layers=True (throughput benchmarks only) reuses layer 0's host tensors for every other layer of a stack:
+    the engine still packs and uploads one device copy per layer, so HBM footprint and traffic are unchanged."""
+    import re
+    spec = state_dict_spec(cfg)
+    want = set(keys) if keys is not None else None
+    out: Dict[str, torch.Tensor] = {}
+    for idx, (k, shp) in enumerate(spec.items()):
+        if want is not None and k not in want:
+            continue
+        if share_layers:
+            m = re.search(r"\.layers\.(\d+)\.", k)
+            if m and int(m.group(1)) > 0:
+                k0 = k[:m.start()] + ".layers.0." + k[m.end():]
+                if k0 in out and tuple(out[k0].shape) == tuple(shp):
+                    out[k] = out[k0]
+                    continue
+        g = torch.Generator().manual_seed(seed * 1_000_003 + idx)
+        if _is_norm_weight(k):
+            t = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias") or len(shp) == 1:
+            t = 0.02 * torch.randn(shp, generator=g)
+        elif "embed_tokens" in k or "position_embedding" in k or k.endswith("_token.weight") or k.endswith("_tokens.weight") \
+                or "no_mask_embed" in k:
+            t = 0.5 * torch.randn(shp, generator=g)
+        elif "gaussian_matrix" in k:
+            t = torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            t = torch.randn(shp, generator=g) / math.sqrt(fan_in)
+        out[k] = t.to(dtype)
+    return out
+
+
+def dense_pe(gaussian: torch.Tensor, grid: int = 48) -> torch.Tensor:
+    """PositionEmbeddingRandom.forward((48,48)) in the parameter dtype, as `prompt_encoder.get_dense_pe()` computes it
+    (segment_anything/modeling/prompt_encoder.py:67-76,189-229).  Returns [grid*grid, 256] (channels-last)."""
+    dt = gaussian.dtype
+    ones = torch.ones((grid, grid), dtype=dt)
+    y = (ones.cumsum(dim=0) - 0.5) / grid
+    x = (ones.cumsum(dim=1) - 0.5) / grid
+    coords = torch.stack([x, y], dim=-1)
+    coords = 2 * coords - 1
+    coords = coords @ gaussian
+    coords = 2 * math.pi * coords
+    pe = torch.cat([torch.sin(coords), torch.cos(coords)], dim=-1)  # [g, g, 256]
+    return pe.reshape(grid * grid, 256).contiguous()
+
+
+def load_checkpoint_dir(vsm_dir: str, clip_dir: str) -> Dict[str, torch.Tensor]:
+    """Reads a HF `save_pretrained` directory of the VSM (safetensors or .bin shards) plus the CLIP tower directory and
+    returns one state dict in the engine's key space (CLIP keys prefixed with `clip.`)."""
+    sd: Dict[str, torch.Tensor] = {}
+
+    def _read(d: str) -> Dict[str, torch.Tensor]:
+        out: Dict[str, torch.Tensor] = {}
+        names = sorted(os.listdir(d))
+        st = [n for n in names if n.endswith(".safetensors")]
+        if st:
+            from safetensors.torch import load_file
+            for n in st:
+                out.update(load_file(os.path.join(d, n)))
+            return out
+        for n in names:
+            if n.endswith(".bin") and n.startswith("pytorch_model"):
+                out.update(torch.load(os.path.join(d, n), map_location="cpu", weights_only=True))
+        if not out:
+            raise FileNotFoundError(f"no weight shards in {d}")
+        return out
+
+    for k, v in _read(vsm_dir).items():
+        if ".vision_tower." in k:
+            continue
+        sd[k] = v
+    for k, v in _read(clip_dir).items():
+        if k.startswith("vision_model."):
+            sd[CLIP_PREFIX + k] = v
+    return sd
