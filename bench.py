@@ -37,7 +37,8 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
     """The oracle (a port of the reference's per-crop graph) on the host cores: ONE crop through the real-size CLIP-L
     tower, projector, 2 of the 32 LLaMA-7B layers (time scaled x16), heads, OWL-ViT tower and SAM head, fp32."""
     from oracle import vsm_oracle
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool degrades badly past a few dozen threads on these shapes (256 threads: 20x slower)
+    cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     n_l = 2
     small = VSMConfig(**{**cfg.__dict__, "llm_layers": n_l, "llm_vocab": 1024})
