@@ -1,0 +1,143 @@
+"""Drop-in for the reference's `VSM` wrapper class (visual_search.py:142-225) on top of the HIP engine.
+
+Same constructor argument (the `parse_args` namespace: version, vision_tower, conv_type, use_mm_start_end,
+model_max_length) and the same `inference(image, question, mode)` return conventions:
+  'detection'    -> (pred_boxes [2304,4] cpu, sigmoid scores [2304,1] cpu, heatmap [h,w] clamped >= 0)
+  'segmentation' -> heatmap [h,w]
+  'vqa'          -> str            (free-text decode: SURVEY.md §8f row 1, not built yet -> NotImplementedError)
+plus `inference_batch` (many crops, one engine pass) which is what the batched search scheduler calls.
+
+Difference in mechanism, not in result: the reference runs HF greedy `generate` with use_cache=False and reads the
+hidden state at the token before [LOC] from the LAST step (VSM.py:451-473).  Under causal attention that state equals
+the one from a single prefill over prompt + "Sure, [LOC]." provided greedy decoding emits exactly that template; the
+engine returns argmax(lm_head(h)) at the answer positions so that this is CHECKED per crop (`template_ok`).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .config import VSMConfig
+from .engine import VstarEngine
+from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, SyntheticTokenizer, build_prompt, clip_preprocess,
+                         owl_preprocess, tokenizer_image_token)
+from .weights import load_checkpoint_dir, random_state_dict
+
+
+class TemplateMismatch(RuntimeError):
+    """Greedy decoding would not have produced "Sure, [LOC]." for this crop (the reference would then index an empty
+    pred_mask and raise IndexError, visual_search.py:209-225)."""
+
+
+class VSM:
+    def __init__(self, args=None, *, engine: Optional[VstarEngine] = None, tokenizer=None, cfg: Optional[VSMConfig] = None,
+                 device: int = 0, synthetic_seed: Optional[int] = None, strict_template: Optional[bool] = None):
+        """`args`: the reference's argparse namespace.  If `args.version` is a local HF checkpoint directory (and
+        `args.vision_tower` a local CLIP directory) real weights + tokenizer are loaded; otherwise pass
+        `synthetic_seed` to run seeded random weights of the same architecture (benchmarks / tests)."""
+        self.conv_type = getattr(args, "conv_type", "llava_v1")
+        self.use_mm_start_end = getattr(args, "use_mm_start_end", True)
+        if self.conv_type != "llava_v1":
+            raise NotImplementedError("only the llava_v1 template (the reference default) is supported")
+        version = getattr(args, "version", None)
+        real = version is not None and os.path.isdir(str(version))
+        if engine is not None:
+            self.engine = engine
+            self.cfg = engine.cfg
+        else:
+            self.cfg = cfg or VSMConfig.seal_7b(224)
+            self.engine = VstarEngine(self.cfg, device)
+            if real:
+                sd = load_checkpoint_dir(version, getattr(args, "vision_tower"))
+            elif synthetic_seed is not None:
+                sd = random_state_dict(self.cfg, seed=synthetic_seed, dtype=torch.bfloat16, share_layers=True)
+            else:
+                raise FileNotFoundError(
+                    f"checkpoint directory {version!r} not found and no synthetic_seed given (there is no hub access here)")
+            self.engine.load_state_dict(sd)
+        if tokenizer is not None:
+            self.vsm_tokenizer = tokenizer
+        elif real:
+            from transformers import AutoTokenizer
+            self.vsm_tokenizer = AutoTokenizer.from_pretrained(version, model_max_length=getattr(args, "model_max_length", 512),
+                                                               padding_side="right", use_fast=False)
+            self.vsm_tokenizer.pad_token = self.vsm_tokenizer.unk_token
+        else:
+            self.vsm_tokenizer = SyntheticTokenizer(self.cfg.llm_vocab)
+        self.loc_token_idx = self.vsm_tokenizer("[LOC]", add_special_tokens=False).input_ids[0]
+        self.strict_template = real if strict_template is None else strict_template
+        self.last_template_ok: Optional[np.ndarray] = None
+
+    # ---- prompt -> ids with the answer teacher-forced ----
+    def _ids(self, question: str) -> Tuple[np.ndarray, int, List[int], List[int]]:
+        prompt = build_prompt(question, self.use_mm_start_end)
+        full = build_prompt(question, self.use_mm_start_end, answer=ANSWER_TEMPLATE)
+        ids_p = tokenizer_image_token(prompt, self.vsm_tokenizer)
+        ids_f = tokenizer_image_token(full, self.vsm_tokenizer)
+        if ids_f[: len(ids_p)] != ids_p:
+            # tokenisation merged across the "ASSISTANT:" boundary; tokenise the answer on its own
+            ans = self.vsm_tokenizer(" " + ANSWER_TEMPLATE, add_special_tokens=False).input_ids
+            ids_f = ids_p + list(ans)
+        if ids_f.count(self.loc_token_idx) != 1:
+            raise ValueError("the teacher-forced answer must contain exactly one [LOC] token")
+        loc_col = ids_f.index(self.loc_token_idx)
+        P = self.cfg.n_img_tokens
+        # spliced positions whose next-token argmax must reproduce the answer tokens up to and including [LOC]
+        first_ans = len(ids_p)
+        ver_cols = list(range(first_ans, loc_col + 1))
+        ver_pos = [c - 1 + (P - 1) for c in ver_cols]
+        ver_tok = [ids_f[c] for c in ver_cols]
+        return np.asarray(ids_f, dtype=np.int32), loc_col - 1 + (P - 1), ver_pos, ver_tok
+
+    @torch.inference_mode()
+    def inference_batch(self, images: Sequence[Image.Image], question: str, mode: str = "detection",
+                        upsample: bool = True):
+        """Scores all `images` (crops) for one question in engine batches of cfg.max_batch.  Returns a list of per-crop
+        results in the `inference` convention (with `upsample=False` the heatmap slot holds the 192x192 low-res logits)."""
+        assert mode in ("vqa", "segmentation", "detection")
+        if mode == "vqa":
+            raise NotImplementedError("mode='vqa' (free-text greedy decode, visual_search.py:427-443) is the next scope "
+                                      "row (SURVEY.md §8f-1); the contextual-cue branch needs a KV-cache decode path")
+        ids, loc_pos, ver_pos, ver_tok = self._ids(question)
+        nv = min(len(ver_pos), 8)
+        ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
+        out: List = []
+        ok_all = []
+        mb = self.cfg.max_batch
+        for s in range(0, len(images), mb):
+            chunk = images[s:s + mb]
+            B = len(chunk)
+            clip = torch.from_numpy(np.stack([clip_preprocess(im, self.cfg.clip_image_size) for im in chunk])).bfloat16()
+            owl = torch.from_numpy(np.stack([owl_preprocess(im, self.cfg.owl_image_size) for im in chunk])).bfloat16()
+            res = self.engine.score_batch(clip, owl, np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
+                                          verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)))
+            ok = (res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)
+            ok_all.append(ok)
+            for b, im in enumerate(chunk):
+                w, h = im.size
+                low = res["low_res_masks"][b, 0]
+                heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
+                if mode == "segmentation":
+                    out.append(heat)
+                else:
+                    boxes = torch.from_numpy(res["pred_boxes"][b].copy())
+                    scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
+                    out.append((boxes, scores, heat))
+        self.last_template_ok = np.concatenate(ok_all) if ok_all else np.zeros((0,), bool)
+        if not self.last_template_ok.all():
+            msg = (f"{int((~self.last_template_ok).sum())}/{len(images)} crops: greedy decoding would not emit "
+                   f"'{ANSWER_TEMPLATE}' (teacher-forced argmax check failed)")
+            if self.strict_template:
+                raise TemplateMismatch(msg)
+            warnings.warn(msg + " — tolerated because strict_template=False (synthetic weights)")
+        return out
+
+    @torch.inference_mode()
+    def inference(self, image: Image.Image, question: str, mode: str = "segmentation"):
+        """Same contract as the reference's VSM.inference (visual_search.py:174-225)."""
+        return self.inference_batch([image], question, mode)[0]
