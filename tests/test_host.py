@@ -1,0 +1,131 @@
+"""Host-side logic: preprocessing vs the HF processors the reference calls, prompt/tokenisation, config/FLOP tables,
+record (de)serialisation, and the world_size-2 all-gather of result records over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from vstar_amd import preprocess as pp
+from vstar_amd.config import VSMConfig
+from vstar_amd.engine import VstarEngine, loc_positions
+from vstar_amd.weights import dense_pe, random_state_dict, state_dict_spec
+
+
+def _img(w, h, seed):
+    rng = np.random.default_rng(seed)
+    return Image.fromarray(rng.integers(0, 255, size=(h, w, 3), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (300, 900), (224, 224), (1000, 1000)])
+def test_preprocess_matches_hf_processors(w, h):
+    from transformers import CLIPImageProcessor, OwlViTImageProcessor
+    img = _img(w, h, w + h)
+    clip_proc = CLIPImageProcessor(size={"shortest_edge": 224}, crop_size={"height": 224, "width": 224})
+    ref = clip_proc.preprocess(pp.expand2square(img, pp.background_color()), return_tensors="np")["pixel_values"][0]
+    got = pp.clip_preprocess(img, 224)
+    assert got.shape == (3, 224, 224)
+    assert np.abs(got - ref).max() < 1e-5
+    owl_proc = OwlViTImageProcessor()
+    ref2 = owl_proc(images=np.array(img), return_tensors="np")["pixel_values"][0]
+    got2 = pp.owl_preprocess(img, 768)
+    assert np.abs(got2 - ref2).max() < 1e-5
+
+
+def test_expand2square_top_left():
+    img = _img(30, 10, 0)
+    sq = pp.expand2square(img)
+    assert sq.size == (30, 30)
+    assert np.array_equal(np.asarray(sq)[:10], np.asarray(img))
+    assert tuple(np.asarray(sq)[20, 5]) == (122, 116, 104)
+
+
+def test_prompt_and_tokenisation():
+    tok = pp.SyntheticTokenizer(32004)
+    q = pp.LOCATE_QUESTION.format("red cup")
+    prompt = pp.build_prompt(q)
+    assert prompt.startswith(pp.LLAVA_V1_SYSTEM + " USER: <im_start><image><im_end>\nPlease locate the red cup")
+    assert prompt.endswith(" ASSISTANT:")
+    ids = pp.tokenizer_image_token(prompt, tok)
+    assert ids[0] == tok.bos_token_id and ids.count(-200) == 1 and ids.count(tok.bos_token_id) == 1
+    i = ids.index(-200)
+    assert ids[i - 1] == tok.special["<im_start>"] and ids[i + 1] == tok.special["<im_end>"]
+    full = pp.tokenizer_image_token(pp.build_prompt(q, answer=pp.ANSWER_TEMPLATE), tok)
+    assert full[: len(ids)] == ids and full.count(tok.special["[LOC]"]) == 1
+    # the hidden state that predicts [LOC] sits at idx([LOC]) - 1 + (P - 1) of the spliced sequence (VSM.py:230-234)
+    loc = loc_positions(np.asarray([full]), tok.special["[LOC]"], 256)
+    assert int(loc[0]) == full.index(tok.special["[LOC]"]) - 1 + 255
+
+
+def test_config_flops_match_baseline_tables():
+    f336 = VSMConfig.seal_7b(336).flops_per_crop(64)
+    f224 = VSMConfig.seal_7b(224).flops_per_crop(64)
+    assert abs(f336["core"] / 8.768e12 - 1) < 0.01
+    assert abs(f224["core"] / 4.329e12 - 1) < 0.01
+    assert abs(f336["full"] / 9.37e12 - 1) < 0.01
+    assert abs(f336["owl_tower"] / 590.1e9 - 1) < 0.01
+
+
+def test_state_dict_spec_and_dense_pe():
+    cfg = VSMConfig.tiny()
+    spec = state_dict_spec(cfg)
+    sd = random_state_dict(cfg, 3, torch.float32)
+    assert list(sd.keys()) == list(spec.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in spec.items())
+    sub = random_state_dict(cfg, 3, torch.float32, keys=["lm_head.weight"])
+    assert torch.equal(sub["lm_head.weight"], sd["lm_head.weight"])
+    from oracle import vsm_oracle
+    pe = dense_pe(sd["model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"])
+    ref = vsm_oracle.dense_pe(sd)[0].permute(1, 2, 0).reshape(2304, 256)
+    assert torch.allclose(pe, ref, atol=1e-6)
+
+
+def test_result_record_unpack_roundtrip():
+    from vstar_amd import _lib
+    rec = np.arange(2 * _lib.RESULT_FLOATS, dtype=np.float32).reshape(2, -1)
+    out = VstarEngine.unpack(rec, 3)
+    assert out["pred_logits"].shape == (2, 2304, 1) and out["pred_boxes"].shape == (2, 2304, 4)
+    assert out["low_res_masks"].shape == (2, 1, 192, 192) and out["tf_argmax"].shape == (2, 3)
+    assert out["pred_boxes"][1, 0, 0] == rec[1, 2304]
+    assert out["low_res_masks"][0, 0, 0, 0] == rec[0, 2304 * 5]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dist_worker(rank, world, port, n_items, q):
+    import torch.distributed as dist
+    from vstar_amd import dist as vd
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    R = 7
+    full = torch.arange(n_items * R, dtype=torch.float32).reshape(n_items, R)      # record i = row i
+    mine = vd.shard_indices(n_items, rank, world)
+    per = vd.pad_count(n_items, world)
+    local = torch.zeros(per, R)
+    local[: len(mine)] = full[mine]                                               # this rank "scored" its shard
+    got = vd.allgather_records(local, n_items)
+    q.put((rank, torch.equal(got, full)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [8, 5, 1])
+def test_allgather_records_world2_gloo(n_items):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, True), (1, True)]

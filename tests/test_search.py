@@ -1,0 +1,96 @@
+"""The batched scheduler reproduces the REFERENCE scheduler's decisions (tests/golden/search_paths.json was recorded
+by running the reference's own visual_search.py with oracle.search_oracle.FakeVSM, see oracle/gen_search_golden.py)."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.gen_search_golden import synthetic_image
+from oracle.search_oracle import FakeVSM
+from vstar_amd import search
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "search_paths.json")))
+
+
+class BatchedFake(FakeVSM):
+    """FakeVSM behind the batched interface of vstar_amd.vsm.VSM (low-res result + deferred upsample)."""
+
+    def __init__(self, max_batch, **kw):
+        super().__init__(**kw)
+        self.cfg = types.SimpleNamespace(max_batch=max_batch)
+        self.batches = []
+
+    def inference_batch(self, images, question, mode="detection", upsample=False):
+        self.batches.append(len(images))
+        out = []
+        for im in images:
+            self.calls += 1
+            g = self._rng(im)
+            low = torch.randn(1, 1, 12, 12, generator=g) * self.gain
+            boxes = torch.rand(self.n_boxes, 4, generator=g)
+            scores = torch.sigmoid(torch.randn(self.n_boxes, 1, generator=g) * 1.5 + self.conf_shift)
+            out.append((boxes, scores, low[0, 0]))
+        return out
+
+    def upsample_heatmap(self, low, h, w):
+        return torch.clamp(F.interpolate(low[None, None], (h, w), mode="bilinear", align_corners=False)[0, 0], min=0)
+
+
+def _check(res, gold):
+    final_step, path_length, ok, all_valid = res
+    assert int(path_length) == gold["path_length"]
+    assert bool(ok) == gold["success"]
+    assert [int(v) for v in final_step["bbox"]] == gold["final_bbox"]
+    assert [float(v) for v in final_step["detection_result"]] == gold["detection_result"]   # bit-identical
+    assert (None if all_valid is None else int(all_valid.shape[0])) == gold["n_all_valid"]
+
+
+@pytest.mark.parametrize("gold", GOLD, ids=[f"{g['case'][0]}x{g['case'][1]}s{g['case'][2]}" for g in GOLD])
+def test_unbatched_matches_reference(gold):
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    smallest = search.smallest_size_for(w, h, scale)
+    assert smallest == gold["smallest_size"]
+    vsm = FakeVSM(seed=vseed, conf_shift=shift)
+    _check(search.visual_search(vsm, img, "object", [0, 0, 10, 10], smallest), gold)
+    assert vsm.calls == gold["calls"]          # no speculation without a batch interface
+
+
+@pytest.mark.parametrize("max_batch", [4, 32])
+@pytest.mark.parametrize("gold", GOLD, ids=[f"{g['case'][0]}x{g['case'][1]}s{g['case'][2]}" for g in GOLD])
+def test_batched_speculative_matches_reference(gold, max_batch):
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    vsm = BatchedFake(max_batch, seed=vseed, conf_shift=shift)
+    stats = {}
+    _check(search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"], stats=stats), gold)
+    assert max(vsm.batches) <= max_batch
+    assert stats["crops_scored"] >= min(gold["calls"], stats["path_visited"])
+    # speculation reduces engine passes: never more batches than the reference made single-crop calls
+    assert stats["engine_batches"] <= gold["calls"]
+    if gold["calls"] >= 21 and max_batch == 32:
+        assert stats["engine_batches"] <= (gold["calls"] + 15) // 16
+
+
+def test_helpers_match_reference_semantics():
+    assert search.split_4subpatches([0, 0, 100, 200]) == (1, 4)
+    assert search.split_4subpatches([0, 0, 200, 100]) == (4, 1)
+    assert search.split_4subpatches([0, 0, 100, 150]) == (2, 2)
+    subs, ws, hs = search.get_sub_patches([10, 20, 101, 77], 2, 2)
+    assert subs == [[10, 20, 50, 38], [60, 20, 51, 38], [10, 58, 50, 39], [60, 58, 51, 39]] and (ws, hs) == (50, 38)
+    assert search.smallest_size_for(3840, 2160) == 540 and search.smallest_size_for(600, 400) == 224
+    z = np.zeros((4, 4, 1), np.float32)
+    assert [float(s) for s in search.get_subpatch_scores(z, [0, 0, 4, 4], [[0, 0, 2, 2]])] == [0.0]
+    assert abs(search.iou([0, 0, 10, 10], [5, 5, 10, 10]) - 25 / 175) < 1e-12
+
+
+def test_contextual_cue_branch_needs_vqa():
+    # heat.max() <= threshold sends the search into the VQA branch, which the round-1 engine does not implement
+    img = synthetic_image(1920, 1080, 0)
+    vsm = FakeVSM(seed=1, conf_shift=-6.0, gain=0.1)
+    with pytest.raises(NotImplementedError):
+        search.visual_search(vsm, img, "object", [0, 0, 1, 1], 270)

@@ -1,0 +1,268 @@
+"""The V* crop scheduler (visual_search.py:227-283, 378-516) re-driven in batches.
+
+`visual_search(...)` keeps the reference's signature and return tuple.  The reference recurses one crop at a time
+(`visual_search_queue`, batch 1); here the same best-first order is an explicit loop and the VSM
+is asked for MANY nodes per call: every node's bbox is a pure function of its parent's bbox (`get_sub_patches`), so the
+children of the current node and of the best queue entries can be scored speculatively in the same engine batch.
+Results are cached by bbox and only CONSUMED when the loop reaches that node, in exactly the reference's pop order
+(same `queue.PriorityQueue`, same `Prioritize` ordering, same float32 numpy reductions), so paths / boxes / answers are
+identical to a batch-1 run and the speculation only costs bounded extra crops.
+"""
+from __future__ import annotations
+
+import copy
+import functools
+from queue import PriorityQueue
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .preprocess import CUE_QUESTION, LOCATE_QUESTION
+
+
+# ---------------- geometry / score helpers (visual_search.py:227-283) ----------------
+def refine_bbox(bbox, image_width, image_height):
+    bbox[0] = max(0, bbox[0])
+    bbox[1] = max(0, bbox[1])
+    bbox[2] = min(bbox[2], image_width - bbox[0])
+    bbox[3] = min(bbox[3], image_height - bbox[1])
+    return bbox
+
+
+def split_4subpatches(current_patch_bbox) -> Tuple[int, int]:
+    hw_ratio = current_patch_bbox[3] / current_patch_bbox[2]
+    if hw_ratio >= 2:
+        return 1, 4
+    if hw_ratio <= 0.5:
+        return 4, 1
+    return 2, 2
+
+
+def get_sub_patches(current_patch_bbox, num_of_width_patches: int, num_of_height_patches: int):
+    width_stride = int(current_patch_bbox[2] // num_of_width_patches)
+    height_stride = int(current_patch_bbox[3] / num_of_height_patches)
+    sub_patches = []
+    for j in range(num_of_height_patches):
+        for i in range(num_of_width_patches):
+            w = current_patch_bbox[2] - i * width_stride if i == num_of_width_patches - 1 else width_stride
+            h = current_patch_bbox[3] - j * height_stride if j == num_of_height_patches - 1 else height_stride
+            sub_patches.append([current_patch_bbox[0] + i * width_stride, current_patch_bbox[1] + j * height_stride, w, h])
+    return sub_patches, width_stride, height_stride
+
+
+def get_subpatch_scores(score_heatmap: np.ndarray, current_patch_bbox, sub_patches) -> List:
+    area = current_patch_bbox[2] * current_patch_bbox[3]
+    total_sum = (score_heatmap / area).sum()
+    sub_scores = []
+    for sp in sub_patches:
+        x, y, w, h = sp[0] - current_patch_bbox[0], sp[1] - current_patch_bbox[1], sp[2], sp[3]
+        score = (score_heatmap[y:y + h, x:x + w] / area).sum()
+        if total_sum > 0:
+            score /= total_sum
+        else:
+            score *= 0
+        sub_scores.append(score)
+    return sub_scores
+
+
+def normalize_score(score_heatmap: torch.Tensor) -> torch.Tensor:
+    max_score = score_heatmap.max()
+    min_score = score_heatmap.min()
+    if max_score != min_score:
+        return (score_heatmap - min_score) / (max_score - min_score)
+    return score_heatmap * 0
+
+
+def iou(bbox1, bbox2):
+    x1 = max(bbox1[0], bbox2[0])
+    y1 = max(bbox1[1], bbox2[1])
+    x2 = min(bbox1[0] + bbox1[2], bbox2[0] + bbox2[2])
+    y2 = min(bbox1[1] + bbox1[3], bbox2[1] + bbox2[3])
+    inter_area = max(0, x2 - x1) * max(0, y2 - y1)
+    return inter_area / (bbox1[2] * bbox1[3] + bbox2[2] * bbox2[3] - inter_area)
+
+
+@functools.total_ordering
+class Prioritize:
+    """Heap entry comparing ONLY the priority (visual_search.py:378-389): ties resolve by heapq sift order."""
+
+    def __init__(self, priority, item):
+        self.priority = priority
+        self.item = item
+
+    def __eq__(self, other):
+        return self.priority == other.priority
+
+    def __lt__(self, other):
+        return self.priority < other.priority
+
+
+def smallest_size_for(image_width: int, image_height: int, minimum_size_scale: float = 4.0, minimum_size: int = 224) -> int:
+    """visual_search.py:545."""
+    return max(int(np.ceil(min(image_width, image_height) / minimum_size_scale)), minimum_size)
+
+
+def _crop(image, bbox):
+    return image.crop((int(bbox[0]), int(bbox[1]), int(bbox[0] + bbox[2]), int(bbox[1] + bbox[3])))
+
+
+class _NodeScorer:
+    """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
+
+    def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool):
+        self.vsm, self.image, self.question = vsm, image, question
+        self.smallest_size = smallest_size
+        self.batched = hasattr(vsm, "inference_batch")
+        self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) if self.batched else 1)
+        self.speculate = speculate and self.batched and self.batch_size > 1
+        self.cache: Dict[Tuple, Tuple] = {}
+        self.n_scored = 0
+        self.n_batches = 0
+
+    def _children(self, bbox):
+        if min(bbox[2], bbox[3]) <= self.smallest_size:
+            return []
+        return get_sub_patches(bbox, *split_4subpatches(bbox))[0]
+
+    def get(self, bbox, queue: PriorityQueue):
+        key = tuple(bbox)
+        if key not in self.cache:
+            todo = [list(bbox)]
+            if self.speculate:
+                # breadth-first over: the node's children, then the queue's entries best-first and their children, ...
+                frontier = self._children(bbox)
+                frontier += [e.item["bbox"] for e in sorted(queue.queue)]
+                seen = {key}
+                while frontier and len(todo) < self.batch_size:
+                    nxt = []
+                    for b in frontier:
+                        k = tuple(b)
+                        if k in seen:
+                            continue
+                        seen.add(k)
+                        if k not in self.cache:
+                            todo.append(list(b))
+                            if len(todo) >= self.batch_size:
+                                break
+                        nxt += self._children(b)
+                    frontier = nxt
+            crops = [_crop(self.image, b) for b in todo]
+            if self.batched:
+                res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False)
+            else:
+                res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
+            for b, c, r in zip(todo, crops, res):
+                self.cache[tuple(b)] = (r, c.size)
+            self.n_scored += len(todo)
+            self.n_batches += 1
+        (boxes, scores, heat), (w, h) = self.cache[key]
+        if self.batched and tuple(heat.shape) != (h, w):
+            heat = self.vsm.upsample_heatmap(heat, h, w)        # full-resolution heatmap only for COMMITTED nodes
+            self.cache[key] = ((boxes, scores, heat), (w, h))
+        return boxes, scores, heat
+
+
+def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high=0.5, confidence_low=0.3,
+                  target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
+                  visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
+                  noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None):
+    """Same contract as the reference's visual_search (visual_search.py:484-516): returns
+    (final_step, path_length, search_successful, all_valid_boxes)."""
+    if visualize:
+        raise NotImplementedError("search-path visualisation (cv2/matplotlib, visual_search.py:285-376) is out of scope")
+    init_patch = {"bbox": [0, 0, image.width, image.height], "scale_level": 1, "score": None, "parent_index": -1}
+    search_path = [init_patch]
+    queue: PriorityQueue = PriorityQueue()
+    question = LOCATE_QUESTION.format(target_object_name)
+    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate)
+
+    search_successful, all_valid_boxes = False, None
+    current_patch = init_patch
+    while True:
+        bbox = current_patch["bbox"]
+        level = current_patch["scale_level"]
+        pw, ph = int(bbox[0] + bbox[2]) - int(bbox[0]), int(bbox[1] + bbox[3]) - int(bbox[1])
+        pred_bboxes, pred_logits, target_cue_heatmap = scorer.get(bbox, queue)
+        expand = True
+        if len(pred_logits) > 0:
+            top_index = pred_logits.view(-1).argmax()
+            top_logit = pred_logits.view(-1).max()
+            final_bbox = pred_bboxes[top_index].view(4)
+            final_bbox = final_bbox * torch.Tensor([pw, ph, pw, ph])
+            final_bbox[:2] -= final_bbox[2:] / 2
+            if top_logit > confidence_high:
+                search_path[-1]["detection_result"] = final_bbox
+                if len(search_path) == 1:   # multiple instances are only returned for the whole image
+                    all_valid_boxes = pred_bboxes[pred_logits.view(-1) > 0.5].view(-1, 4)
+                    all_valid_boxes = all_valid_boxes * torch.Tensor([[pw, ph, pw, ph]])
+                    all_valid_boxes[:, :2] -= all_valid_boxes[:, 2:] / 2
+                search_successful = True
+                break
+            search_path[-1]["temp_detection_result"] = (top_logit, final_bbox)
+
+        if min(bbox[2], bbox[3]) <= smallest_size:
+            expand = False                                    # already the smallest unit: no children
+        if expand:
+            heat = target_cue_heatmap.view(bbox[3], bbox[2], 1)
+            score_max = heat.max().item()
+            threshold = max(target_cue_threshold_minimum, target_cue_threshold * target_cue_threshold_decay ** (level - 1))
+            current_patch_index = len(search_path) - 1
+            if score_max > threshold:
+                final_heatmap = normalize_score(heat)
+            else:
+                # contextual-cue branch (visual_search.py:427-443): free-text VQA -> noun phrase -> segmentation
+                patch = _crop(image, bbox)
+                vqa_results = vsm.inference(copy.deepcopy(patch), CUE_QUESTION.format(target_object_name), mode="vqa")
+                phrase = vqa_results.split("most likely to appear")[-1].strip()
+                if phrase.endswith("."):
+                    phrase = phrase[:-1]
+                phrase = phrase.split(target_object_name)[-1]
+                if noun_chunker is None:
+                    raise NotImplementedError("the contextual-cue branch needs a noun chunker (spaCy en_core_web_sm in the "
+                                              "reference, visual_search.py:54-112); pass noun_chunker=")
+                noun_chunks = noun_chunker(phrase)
+                phrase = noun_chunks[0] if len(noun_chunks) == 1 else "region {}".format(phrase)
+                ctx = vsm.inference(copy.deepcopy(patch), LOCATE_QUESTION.format(phrase), mode="segmentation")
+                final_heatmap = normalize_score(ctx.view(bbox[3], bbox[2], 1))
+                search_path[current_patch_index]["context_cue"] = vqa_results + "#" + phrase
+            search_path[current_patch_index]["final_heatmap"] = final_heatmap.cpu().numpy()
+
+            basic_sub_patches, _, _ = get_sub_patches(bbox, *split_4subpatches(bbox))
+            tmp_patch = current_patch
+            basic_sub_scores = [0] * len(basic_sub_patches)
+            while True:   # accumulate every ancestor's heatmap mass, weighted 1/4^level (visual_search.py:451-462)
+                tmp_sub_scores = get_subpatch_scores(tmp_patch["final_heatmap"], tmp_patch["bbox"], basic_sub_patches)
+                basic_sub_scores = [basic_sub_scores[i] + tmp_sub_scores[i] / (4 ** tmp_patch["scale_level"])
+                                    for i in range(len(basic_sub_scores))]
+                if tmp_patch["parent_index"] == -1:
+                    break
+                tmp_patch = search_path[tmp_patch["parent_index"]]
+            for sub_patch, sub_score in zip(basic_sub_patches, basic_sub_scores):
+                info = {"bbox": sub_patch, "scale_level": level + 1, "score": sub_score, "parent_index": current_patch_index}
+                queue.put(Prioritize(-info["score"], info))
+
+        if queue.empty():
+            break
+        current_patch = queue.get().item
+        search_path.append(current_patch)
+
+    path_length = len(search_path)
+    final_step = search_path[-1]
+    if not search_successful:
+        # no confident detection: fall back to the best temp detection seen on the path (visual_search.py:498-511)
+        max_logit = 0
+        final_step = None
+        path_length = 0
+        for i, step in enumerate(search_path):
+            if "temp_detection_result" in step and step["temp_detection_result"][0] > max_logit:
+                max_logit = step["temp_detection_result"][0]
+                final_step = step
+                path_length = i + 1
+        final_step["detection_result"] = final_step["temp_detection_result"][1]
+        if max_logit >= confidence_low:
+            search_successful = True
+    if stats is not None:
+        stats.update(crops_scored=scorer.n_scored, engine_batches=scorer.n_batches, path_visited=len(search_path),
+                     search_path=search_path)
+    return final_step, path_length, search_successful, all_valid_boxes

@@ -141,3 +141,9 @@ class VSM:
     def inference(self, image: Image.Image, question: str, mode: str = "segmentation"):
         """Same contract as the reference's VSM.inference (visual_search.py:174-225)."""
         return self.inference_batch([image], question, mode)[0]
+
+    def upsample_heatmap(self, low_res, h: int, w: int) -> torch.Tensor:
+        """192x192 mask logits -> [h, w] heatmap, bilinear align_corners=False + clamp(min=0), on the GPU
+        (VSM.py:534-537 + visual_search.py:223-224)."""
+        low = low_res.numpy() if isinstance(low_res, torch.Tensor) else np.asarray(low_res)
+        return torch.from_numpy(self.engine.upsample_mask(low, h, w))
