@@ -157,7 +157,7 @@ enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_E
 
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate (MFMA), bf16 or fp32 out.
  * Replaces every nn.Linear / conv-as-GEMM on the path (SURVEY.md §8d GEMM shape list).
- * W must have ceil(N/128)*128 rows allocated (rows >= N are never stored) and K % 64 == 0.
+ * W must have ceil(N/256)*256 rows allocated (rows >= N are never stored) and K % 64 == 0.
  * For VSTAR_EPI_SILU_MUL, W holds gate/up rows interleaved in blocks of 16 and the output has N/2 columns. */
 int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
                   const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,

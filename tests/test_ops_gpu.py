@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
 
 
-def _pad_w(w):  # library contract: W allocated to a multiple of 128 rows
-    n = (w.shape[0] + 127) // 128 * 128
+def _pad_w(w):  # library contract: W allocated to a multiple of 256 rows
+    n = (w.shape[0] + 255) // 256 * 256
     out = torch.zeros(n, w.shape[1], dtype=w.dtype, device=w.device)
     out[: w.shape[0]] = w
     return out
@@ -164,3 +164,80 @@ def test_attention(lib, cuda, B, S, H, D, causal, theta):
         rc = lib.vstar_op_attention(None, P(dq2), P(out), P(ws), ws_bytes, B, S, H, D, causal, 0.0)
         assert rc == 0
         assert (out.float().cpu() - ref2).abs().max().item() < 3e-2
+
+
+# ---- the 256x256 8-phase kernel (M >= 1024, N >= 256, K % 128 == 0): tails, long K, epilogues, race screen ----
+@pytest.mark.parametrize("M,N,K", [(1024, 256, 128), (1500, 768, 256), (1030, 300, 384), (2048, 512, 11008),
+                                   (20480, 1024, 4096), (1300, 4096, 1024)])
+def test_gemm256_f32_out(lib, cuda, M, N, K):
+    g = torch.Generator(device=cuda).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g, device=cuda).bfloat16()
+    c = _gemm(lib, a, w, bias, f32=True)
+    ref = a.float() @ w.float().T + bias.float()          # device fp32 GEMM as the large-shape checker
+    assert not torch.isnan(c).any()
+    assert _rel(c, ref) < 1e-3
+    # every element, not just the max: catches a single stale LDS tile
+    assert ((c - ref).abs() <= 1e-3 * ref.abs().max()).all()
+
+
+def test_gemm256_transpose_and_rowmajor(lib, cuda):
+    K, N = 256, 512
+    a = torch.zeros(1024, K)
+    a[:K] = torch.eye(K)
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K).remainder(251)
+    c = _gemm(lib, a.bfloat16().to(cuda), w.bfloat16().to(cuda), f32=True)
+    assert torch.equal(c[:K].cpu(), w.bfloat16().float().T)
+    assert (c[K:] == 0).all()
+
+
+@pytest.mark.parametrize("epi", [_lib.EPI_NONE, _lib.EPI_QUICK_GELU, _lib.EPI_RELU])
+def test_gemm256_bf16_epilogues(lib, cuda, epi):
+    M, N, K = 1200, 384, 128
+    g = torch.Generator().manual_seed(40 + epi)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(cuda)
+    bias = torch.randn(N, generator=g).bfloat16().to(cuda)
+    res = torch.randn(M, N, generator=g).bfloat16().to(cuda)
+    c = _gemm(lib, a, w, bias, res, epi=epi)
+    t = (a.float().cpu() @ w.float().cpu().T + bias.float().cpu()).bfloat16().float()
+    if epi == _lib.EPI_QUICK_GELU:
+        t = t * torch.sigmoid(1.702 * t)
+    elif epi == _lib.EPI_RELU:
+        t = F.relu(t)
+    ref = t.bfloat16().float() + res.float().cpu()
+    err = (c.float().cpu() - ref).abs()
+    assert (err <= ref.abs() * 2 ** -7 + 2e-2).all(), err.max()
+
+
+def test_gemm256_silu_mul(lib, cuda):
+    M, F_, K = 1100, 256, 256
+    g = torch.Generator().manual_seed(6)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    gate = (torch.randn(F_, K, generator=g) / math.sqrt(K)).bfloat16()
+    up = (torch.randn(F_, K, generator=g) / math.sqrt(K)).bfloat16()
+    idx = torch.arange(2 * F_)
+    blk, wi = idx // 32, idx % 32
+    packed = torch.where((wi < 16)[:, None], gate[(blk * 16 + wi.clamp(max=15))], up[(blk * 16 + (wi - 16).clamp(min=0))])
+    c = _gemm(lib, a, packed.to(cuda), epi=_lib.EPI_SILU_MUL)
+    gf = (a.float().cpu() @ gate.float().T).bfloat16().float()
+    uf = (a.float().cpu() @ up.float().T).bfloat16().float()
+    ref = F.silu(gf).bfloat16().float() * uf
+    assert c.shape == (M, F_)
+    assert ((c.float().cpu() - ref).abs() <= ref.abs() * 2 ** -7 + 1e-2).all()
+
+
+def test_gemm256_race_screen(lib, cuda):
+    """The DMA ring is guarded only by counted vmcnt waits and barriers: repeat a many-tile GEMM and demand
+    bit-identical results every time while the chip is busy (2 waves of tiles per CU)."""
+    M, N, K = 8192, 4096, 2048
+    g = torch.Generator(device=cuda).manual_seed(77)
+    a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    first = _gemm(lib, a, w, f32=True)
+    ref = a.float() @ w.float().T
+    assert ((first - ref).abs() <= 1e-3 * ref.abs().max()).all()
+    for _ in range(10):
+        again = _gemm(lib, a, w, f32=True)
+        assert torch.equal(again, first)

@@ -155,7 +155,7 @@ struct vstar_engine {
       N += n;
     }
     if (K_expect >= 0 && K != K_expect) { set_error("unexpected K for " + wkeys[0]); return VSTAR_ERR_INVALID; }
-    const int Kpad = (K + 63) / 64 * 64, Npad = (N + 127) / 128 * 128;
+    const int Kpad = (K + 63) / 64 * 64, Npad = (N + 255) / 256 * 256;
     std::vector<bf16_t> host((size_t)Npad * Kpad, 0);
     int r0 = 0;
     for (auto* t : ws) {

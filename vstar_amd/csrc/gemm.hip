@@ -17,6 +17,8 @@
 // blocks sharing an L2 share weight columns.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "gemm_epilogue.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -29,9 +31,7 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, int64_t off) {
-  if (group <= 0) return (int64_t)r;
-  int g = r / group;
-  return (int64_t)g * gstride + off + (r - g * group);
+  return gemm_map_row(r, group, gstride, off);
 }
 
 template <int EPI, bool OUT_F32>
@@ -137,98 +137,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const int64_t crow = map_row(row, p.c_group, p.c_gstride, p.c_off);
     if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int col = (n0 + wc * 64) / 2 + j * 16 + fq * 4;
-        if (col >= n_out) continue;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = rbf(acc[m][2 * j][e]);
-          const float u = rbf(acc[m][2 * j + 1][e]);
-          o[e] = act_silu_bf16(g) * u;
-        }
-        if (OUT_F32) {
-          float* c = (float*)p.C + crow * p.ldc + col;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = o[e];
-        } else {
-          bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
-          if (col + 3 < n_out) {
-            bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
-            *(bf16x4*)c = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
-          }
-        }
-      }
+      for (int j = 0; j < 2; ++j)
+        gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
     } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int col = n0 + wc * 64 + n * 16 + fq * 4;
-        if (col >= n_out) continue;
-        const bool full = (col + 3 < n_out);
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[m][n][e];
-        if (p.bias) {
-          if (full) {
-            const bf16x4 b = *(const bf16x4*)(p.bias + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)b[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(p.bias[col + e]);
-          }
-        }
-        if (!OUT_F32) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);       // nn.Linear output is bf16 in the reference
-        }
-        if (EPI == VSTAR_EPI_QUICK_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] / (1.0f + __expf(-1.702f * o[e])) : act_quick_gelu_bf16(o[e]);
-        } else if (EPI == VSTAR_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
-        } else if (EPI == VSTAR_EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-        }
-        if (p.res) {
-          const bf16_t* rp = p.res + crow * p.ldr + col;
-          if (!OUT_F32) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);     // activation output rounded before the add
-          }
-          if (full) {
-            const bf16x4 rv = *(const bf16x4*)rp;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)rv[e]);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(rp[e]);
-          }
-        }
-        if (OUT_F32) {
-          float* c = (float*)p.C + crow * p.ldc + col;
-          if (full && ((((uintptr_t)c) & 15) == 0)) {
-            *(f32x4*)c = (f32x4){o[0], o[1], o[2], o[3]};
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = o[e];
-          }
-        } else {
-          bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
-          if (full && ((((uintptr_t)c) & 7) == 0)) {
-            bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
-            *(bf16x4*)c = v;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
-          }
-        }
-      }
+      for (int n = 0; n < 4; ++n)
+        gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
     }
   }
 }
@@ -249,10 +163,15 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+bool gemm256_eligible(const GemmParams& p);
+hipError_t gemm256_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+
 hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % BK != 0 || p.K <= 0) return hipErrorInvalidValue;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
+  static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if (force != 128 && gemm256_eligible(p)) return gemm256_bf16(p, epilogue, out_f32, s);   // W is padded to 256 rows
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);

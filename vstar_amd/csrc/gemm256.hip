@@ -1,0 +1,262 @@
+// gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
+// 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 5 quarter-tiles ahead behind COUNTED vmcnt waits, and two
+// wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA cluster while its partner issues
+// ds_reads / DMA ("8-phase" structure of the CDNA4 guide, §5 "256^2 8-phase template", re-derived for this layout).
+//
+// Same math / epilogues / row maps as gemm.hip (which stays the kernel for small M, small N or odd K/64).
+//
+// Schedule.  A K-tile is consumed in 4 phases, each = L (LDS fragment reads + one DMA piece) | barrier | M (16 MFMA =
+// one 64x32 quadrant of the wave's tile over K=64) | barrier:
+//      phase 0: read A[m-half 0] (8 x b128) + W[n-half 0] (4)   -> quadrant (0,0)
+//      phase 1: read W[n-half 1] (4)                             -> quadrant (0,1)
+//      phase 2: read A[m-half 1] (8)                             -> quadrant (1,1)
+//      phase 3: no reads                                         -> quadrant (1,0)
+// The K-tile is DMA'd in 4 pieces in exactly that consumption order (a0, w0, w1, a1; 16 KiB = 2 x 1-KiB DMA per wave
+// each).  With global piece index s = 4*T + j and global phase index f = 4*T + i:
+//   piece s is issued in phase s - D (D = 5), consumed in phase 4T + {0,0,1,2}[j], and overwrites the LDS region of
+//   piece s - 8, whose last read (by the late group) retired (lgkmcnt(0)) before the barrier that ends phase s - 8 + ...
+//   -> WAR needs  s - D >= 4(T-2)+{1,1,2,3}[j]  <=>  D <= 6;   RAW: after issuing piece f + D each wave waits
+//   vmcnt(2*(D-2)) = vmcnt(6), i.e. pieces <= f + 2 have landed, before the barrier that precedes phase f + 1.
+// Group 1 (waves 4-7) runs one barrier behind group 0, so L of one group always overlaps M of the other.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "gemm_epilogue.hpp"
+#include <type_traits>
+
+namespace {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;               // 32 KiB
+constexpr int TILE_BYTES = 2 * A_BYTES;            // A + W = 64 KiB per K-tile
+constexpr int LDS_TOTAL = 2 * TILE_BYTES;          // 128 KiB ring
+constexpr int D = 5;                               // DMA lookahead in pieces (quarter tiles)
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define BAR()                                          \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    asm volatile("s_barrier" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#define LGKM0_BAR()                                                 \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave >> 2;                     // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
+
+  // ---- tile id: XCD-aware bijective remap, then GROUP_M ordering ----
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nwg = tiles_m * tiles_n;
+  int t;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int in_group = GROUP_M * tiles_n;
+  const int grp = t / in_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(tiles_m - first_m, GROUP_M);
+  const int rem = t - grp * in_group;
+  const int tm = first_m + rem % gsz;
+  const int tn = rem / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- DMA pieces: piece type j in {a0, w0, w1, a1}; each wave moves row-groups g = 2*wave + u (u = 0,1) ----
+  // A piece (m-half mh): 8-row group g -> tile rows (g>>3)*128 + mh*64 + (g&7)*8 ..+8
+  // W piece (n-half nh): 8-row group g -> tile rows (g>>2)*64  + nh*32 + (g&3)*8 ..+8
+  const int st_r = lane >> 3, st_c = lane & 7;
+  uint32_t src_off[4][2];   // element offset of this lane's 16-B chunk at k0 = 0, per piece type and u
+  int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int g = 2 * wave + u;
+      const bool isA = (j == 0 || j == 3);
+      const int half = (j == 0 || j == 1) ? 0 : 1;     // a0,w0 -> half 0 ; w1,a1 -> half 1
+      const int row0 = isA ? ((g >> 3) * 128 + half * 64 + (g & 7) * 8) : ((g >> 2) * 64 + half * 32 + (g & 3) * 8);
+      const int row = row0 + st_r;
+      const int cg = st_c ^ ((row >> 1) & 7);
+      lds_off[j][u] = (isA ? 0 : A_BYTES) + row0 * 128;
+      if (isA) {
+        int ar = m0 + row;
+        ar = ar < p.M ? ar : p.M - 1;
+        src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8);
+      } else {
+        src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K + cg * 8);
+      }
+    }
+  }
+  const int total_pieces = (p.K / BK) * 4;
+  // piece type J is a compile-time constant at every call site, so src_off / lds_off stay in registers
+  auto issue_piece = [&](auto jc, int T) {
+    constexpr int J = decltype(jc)::value;
+    char* base = smem + (T & 1) * TILE_BYTES;
+    const bf16_t* gb = ((J == 0 || J == 3) ? p.A : p.W) + T * BK;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb + src_off[J][u]), (lptr_t)(base + lds_off[J][u]), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets (same row-major + (row>>1)&7 chunk swizzle as gemm.hip) ----
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int swz = (fr >> 1) & 7;
+  int a_rd[2], w_rd[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fq) ^ swz) * 16;
+    a_rd[kk] = (wr * 128 + fr) * 128 + ch;
+    w_rd[kk] = A_BYTES + (wc * 64 + fr) * 128 + ch;
+  }
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: pieces 0..D-1 in flight, pieces 0,1 landed, everyone past the barrier; group 1 one barrier behind ----
+  issue_piece(std::integral_constant<int, 0>{}, 0);
+  issue_piece(std::integral_constant<int, 1>{}, 0);
+  issue_piece(std::integral_constant<int, 2>{}, 0);
+  issue_piece(std::integral_constant<int, 3>{}, 0);
+  issue_piece(std::integral_constant<int, 0>{}, 1);
+  static_assert(D == 5, "prologue issues pieces 0..4");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 2*(D-2): pieces <= 1 landed (K >= 128 guaranteed by the dispatcher)
+  BAR();
+  if (group == 1) BAR();
+
+  bf16x8 af[8], w0f[4], w1f[4];
+  const int nkt = p.K / BK;
+  for (int T = 0; T < nkt; ++T) {
+    const char* base = smem + (T & 1) * TILE_BYTES;
+    const int f0 = 4 * T;
+#define PHASE_TAIL(i)                                                                    \
+  {                                                                                      \
+    const int s_ = f0 + (i) + D;                                                         \
+    if (s_ < total_pieces) {                                                             \
+      issue_piece(std::integral_constant<int, ((i) + D) & 3>{}, T + (((i) + D) >> 2));   \
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                   \
+    } else {                                                                             \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+    }                                                                                    \
+    LGKM0_BAR();                                                                         \
+  }
+#define MFMA_QUAD(mh, WF, nh)                                                            \
+  {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                       \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                      \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                    \
+          acc[(mh) * 4 + m][(nh) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(     \
+              WF[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nh) * 2 + n], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                       \
+    BAR();                                                                               \
+  }
+    // phase 0: A[m-half 0] + W[n-half 0]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) w0f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
+    PHASE_TAIL(0)
+    MFMA_QUAD(0, w0f, 0)
+    // phase 1: W[n-half 1]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) w1f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + (2 + n) * 2048);
+    PHASE_TAIL(1)
+    MFMA_QUAD(0, w1f, 1)
+    // phase 2: A[m-half 1]
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + (4 + m) * 2048);
+    PHASE_TAIL(2)
+    MFMA_QUAD(1, w1f, 1)
+    // phase 3: no reads
+    PHASE_TAIL(3)
+    MFMA_QUAD(1, w0f, 0)
+#undef PHASE_TAIL
+#undef MFMA_QUAD
+  }
+  if (group == 0) BAR();   // every wave must execute the same number of barriers
+
+  // ---- epilogue ----
+  const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int row = m0 + wr * 128 + m * 16 + fr;
+    if (row >= p.M) continue;
+    const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
+    if (EPI == VSTAR_EPI_SILU_MUL) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
+    }
+  }
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch(const GemmParams& p, hipStream_t s) {
+  static bool attr_done = false;
+  auto kern = gemm256_kernel<EPI, OUT_F32>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_TOTAL, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// Shapes this kernel accepts: K/64 even and >= 2, operands addressable with 32-bit element offsets.
+bool gemm256_eligible(const GemmParams& p) {
+  if (p.K % 128 != 0 || p.K < 128) return false;
+  if (p.M < 1024 || p.N < 256) return false;
+  const int64_t amax = (p.a_group > 0 ? ((int64_t)(p.M / p.a_group) + 1) * p.a_gstride + p.a_off + p.a_group : (int64_t)p.M) * p.lda;
+  const int64_t npad = ((int64_t)p.N + BN - 1) / BN * BN;
+  if (amax >= (1ll << 31) || npad * p.K >= (1ll << 31)) return false;
+  return true;
+}
+
+hipError_t gemm256_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+#define GEMM_CASE(E)                                                   \
+  case E:                                                              \
+    return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);
+  switch (epilogue) {
+    GEMM_CASE(VSTAR_EPI_NONE)
+    GEMM_CASE(VSTAR_EPI_QUICK_GELU)
+    GEMM_CASE(VSTAR_EPI_GELU)
+    GEMM_CASE(VSTAR_EPI_RELU)
+    GEMM_CASE(VSTAR_EPI_SILU_MUL)
+  }
+#undef GEMM_CASE
+  return hipErrorInvalidValue;
+}
