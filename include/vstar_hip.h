@@ -153,7 +153,8 @@ int vstar_profile_read(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches,
  * exported so that parity tests can drive each one against the oracle through the same C-ABI.
  * All tensors are dense row-major; "ld" = leading dimension in elements.  stream may be NULL.
  * ---------------------------------------------------------------------------------------------- */
-enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_EPI_RELU = 3, VSTAR_EPI_SILU_MUL = 4 };
+enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_EPI_RELU = 3, VSTAR_EPI_SILU_MUL = 4,
+       VSTAR_EPI_NOSYNC = 0x100 /* OR-ed into `epilogue`: launch only, do not synchronise (micro-benchmarks) */ };
 
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate (MFMA), bf16 or fp32 out.
  * Replaces every nn.Linear / conv-as-GEMM on the path (SURVEY.md §8d GEMM shape list).
