@@ -203,20 +203,65 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   // ---- epilogue ----
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  if constexpr (OUT_F32) {
+    // fp32 outputs (lm_head / head taps): direct accumulator-layout stores
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    const int row = m0 + wr * 128 + m * 16 + fr;
-    if (row >= p.M) continue;
-    const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
-    if (EPI == VSTAR_EPI_SILU_MUL) {
+    for (int m = 0; m < 8; ++m) {
+      const int row = m0 + wr * 128 + m * 16 + fr;
+      if (row >= p.M) continue;
+      const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
+      if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
-    } else {
+        for (int j = 0; j < 2; ++j)
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
+      } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
-        gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
+        for (int n = 0; n < 4; ++n)
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
+      }
     }
+  } else {
+    // bf16 outputs: bias/activation in the accumulator layout, transpose through this wave's private LDS slab
+    // (the ring is dead: every wave is past the last barrier and every DMA has landed), then whole-line 16-B stores.
+    constexpr int WCOLS = (EPI == VSTAR_EPI_SILU_MUL) ? 32 : 64;     // output columns owned by this wave
+    constexpr int NF = WCOLS / 16;                                    // 16-column fragments
+    constexpr int RSTRIDE = WCOLS * 2 + 16;                           // padded LDS row (bytes)
+    constexpr int CH = WCOLS / 8;                                     // 16-B chunks per row
+    constexpr int RPI = 64 / CH;                                      // rows per wave-wide 16-B access
+    char* slab = smem + wave * (64 * (128 + 16));
+    const int colbase = (EPI == VSTAR_EPI_SILU_MUL) ? (n0 + wc * 64) / 2 : n0 + wc * 64;
+    auto half_pass = [&](auto mhc) {
+      constexpr int mh = decltype(mhc)::value;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          float o[4];
+          const int col = colbase + f * 16 + fq * 4;
+          if (EPI == VSTAR_EPI_SILU_MUL)
+            gemm_epilogue_values<EPI, false>(p, col, n_out, acc[mh * 4 + m][2 * f], acc[mh * 4 + m][2 * f + 1], o);
+          else   // stage 1 = bf16(acc + bias) only; the activation is applied after the transpose
+            gemm_epilogue_values<VSTAR_EPI_NONE, false>(p, col < n_out ? col : 0, n_out, acc[mh * 4 + m][f], acc[mh * 4 + m][f], o);
+          bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
+          *(bf16x4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 64 / RPI; ++it) {
+        const int rl = it * RPI + lane / CH;
+        const int ch = lane % CH;
+        const bf16x8 v = *(const bf16x8*)(slab + rl * RSTRIDE + ch * 16);
+        const int row = m0 + wr * 128 + mh * 64 + rl;
+        if (row < p.M) {
+          const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
+          gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    half_pass(std::integral_constant<int, 0>{});
+    half_pass(std::integral_constant<int, 1>{});
   }
 }
 

@@ -10,57 +10,66 @@ __device__ __forceinline__ int64_t gemm_map_row(int r, int group, int64_t gstrid
   return (int64_t)g * gstride + off + (r - g * group);
 }
 
-// a = accumulator (gate accumulator for SILU_MUL), u = up accumulator (SILU_MUL only); col = first output column
+// Stage 1 of the epilogue, in the MFMA accumulator layout: bias + activation with the reference's bf16 rounding points
+// (no residual).  a = accumulator (gate accumulator for SILU_MUL), u = up accumulator; col = first output column.
+template <int EPI, bool OUT_F32>
+__device__ __forceinline__ void gemm_epilogue_values(const GemmParams& p, int col, int n_out, const f32x4& a, const f32x4& u,
+                                                     float (&o)[4]) {
+  const bool full = (col + 3 < n_out);
+  if (EPI == VSTAR_EPI_SILU_MUL) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_silu_bf16(rbf(a[e])) * rbf(u[e]);
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = a[e];
+  if (p.bias) {
+    if (full) {
+      const bf16x4 b = *(const bf16x4*)(p.bias + col);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)b[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(p.bias[col + e]);
+    }
+  }
+  if (!OUT_F32) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);       // nn.Linear output is bf16 in the reference
+  }
+  if (EPI == VSTAR_EPI_QUICK_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] / (1.0f + __expf(-1.702f * o[e])) : act_quick_gelu_bf16(o[e]);
+  } else if (EPI == VSTAR_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
+  } else if (EPI == VSTAR_EPI_RELU) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+  }
+}
+
+// Direct epilogue (accumulator layout -> global): 4 consecutive output columns of one row per call.
 template <int EPI, bool OUT_F32>
 __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t crow, int col, int n_out, const f32x4& a,
                                                     const f32x4& u) {
   if (col >= n_out) return;
   const bool full = (col + 3 < n_out);
   float o[4];
-  if (EPI == VSTAR_EPI_SILU_MUL) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = act_silu_bf16(rbf(a[e])) * rbf(u[e]);
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = a[e];
-    if (p.bias) {
-      if (full) {
-        const bf16x4 b = *(const bf16x4*)(p.bias + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)b[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(p.bias[col + e]);
-      }
-    }
+  gemm_epilogue_values<EPI, OUT_F32>(p, col, n_out, a, u, o);
+  if (p.res) {
+    const bf16_t* rp = p.res + crow * p.ldr + col;
     if (!OUT_F32) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);       // nn.Linear output is bf16 in the reference
+      for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);     // activation output rounded before the add
     }
-    if (EPI == VSTAR_EPI_QUICK_GELU) {
+    if (full) {
+      const bf16x4 rv = *(const bf16x4*)rp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] / (1.0f + __expf(-1.702f * o[e])) : act_quick_gelu_bf16(o[e]);
-    } else if (EPI == VSTAR_EPI_GELU) {
+      for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)rv[e]);
+    } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
-    } else if (EPI == VSTAR_EPI_RELU) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
-    }
-    if (p.res) {
-      const bf16_t* rp = p.res + crow * p.ldr + col;
-      if (!OUT_F32) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);     // activation output rounded before the add
-      }
-      if (full) {
-        const bf16x4 rv = *(const bf16x4*)rp;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)rv[e]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(rp[e]);
-      }
+      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(rp[e]);
     }
   }
   if (OUT_F32) {
@@ -80,5 +89,43 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
     }
+  }
+}
+
+// Stage 2 of the LDS-transposed bf16 epilogue: 8 consecutive output columns of one row, holding bf16(acc + bias)
+// (or the finished SiLU*up product) -> activation -> + residual -> one 16-byte store.  Whole 128-byte lines per 8 lanes
+// instead of 32-byte fragments.  The transcendental activations live here (static 8-element bodies) so that the
+// accumulator-indexed stage-1 loops stay small enough to unroll (a runtime-indexed acc[] would go to scratch).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, bf16x8 v) {
+  if (col >= n_out) return;
+  if (EPI == VSTAR_EPI_QUICK_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(act_quick_gelu_bf16(bf2f((bf16_t)v[e])));
+  } else if (EPI == VSTAR_EPI_GELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(act_gelu_erf(bf2f((bf16_t)v[e])));
+  } else if (EPI == VSTAR_EPI_RELU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(fmaxf(bf2f((bf16_t)v[e]), 0.f));
+  }
+  bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
+  const bool full = (col + 7 < n_out) && ((((uintptr_t)c) & 15) == 0);
+  if (p.res) {
+    const bf16_t* rp = p.res + crow * p.ldr + col;
+    if (full && ((((uintptr_t)rp) & 15) == 0)) {
+      const bf16x8 rv = *(const bf16x8*)rp;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) if (col + e < n_out) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rp[e]));
+    }
+  }
+  if (full) {
+    *(bf16x8*)c = v;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (bf16_t)v[e];
   }
 }
