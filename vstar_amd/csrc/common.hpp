@@ -16,8 +16,13 @@ __device__ __host__ __forceinline__ float bf2f(bf16_t v) {
   x.u = ((uint32_t)v) << 16;
   return x.f;
 }
-// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16)
+// round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16).  Device code uses the gfx950 hardware
+// conversion (v_cvt_pk_bf16_f32); the bit-twiddling form is the host path (weight packing).
 __device__ __host__ __forceinline__ bf16_t f2bf(float f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+#endif
   union { uint32_t u; float f; } x;
   x.f = f;
   if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);

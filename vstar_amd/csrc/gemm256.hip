@@ -221,8 +221,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
     }
   } else {
-    // bf16 outputs: bias/activation in the accumulator layout, transpose through this wave's private LDS slab
-    // (the ring is dead: every wave is past the last barrier and every DMA has landed), then whole-line 16-B stores.
+    // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab (the ring is
+    // dead: every wave is past the last barrier and every DMA has landed), then activation / residual and whole-line
+    // 16-B stores from a ROLLED loop (keeps the epilogue's code footprint small: it runs once per tile and an
+    // unrolled 32-fragment epilogue with tail paths was ~10k instructions of cold i-cache).
     constexpr int WCOLS = (EPI == VSTAR_EPI_SILU_MUL) ? 32 : 64;     // output columns owned by this wave
     constexpr int NF = WCOLS / 16;                                    // 16-column fragments
     constexpr int RSTRIDE = WCOLS * 2 + 16;                           // padded LDS row (bytes)
@@ -230,27 +232,44 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     constexpr int RPI = 64 / CH;                                      // rows per wave-wide 16-B access
     char* slab = smem + wave * (64 * (128 + 16));
     const int colbase = (EPI == VSTAR_EPI_SILU_MUL) ? (n0 + wc * 64) / 2 : n0 + wc * 64;
+    // bias for this lane's 4-column groups (clamped: columns >= n_out are computed but never stored)
+    float bias_v[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int bc = colbase + f * 16 + fq * 4;
+      bc = bc + 4 <= n_out ? bc : (n_out - 4 > 0 ? n_out - 4 : 0);
+      if (EPI != VSTAR_EPI_SILU_MUL && p.bias) {
+        const bf16x4 b = *(const bf16x4*)(p.bias + bc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_v[f][e] = bf2f((bf16_t)b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_v[f][e] = 0.f;
+      }
+    }
+    const int rl0 = lane / CH, ch = lane % CH;
     auto half_pass = [&](auto mhc) {
       constexpr int mh = decltype(mhc)::value;
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          float o[4];
-          const int col = colbase + f * 16 + fq * 4;
-          if (EPI == VSTAR_EPI_SILU_MUL)
-            gemm_epilogue_values<EPI, false>(p, col, n_out, acc[mh * 4 + m][2 * f], acc[mh * 4 + m][2 * f + 1], o);
-          else   // stage 1 = bf16(acc + bias) only; the activation is applied after the transpose
-            gemm_epilogue_values<VSTAR_EPI_NONE, false>(p, col < n_out ? col : 0, n_out, acc[mh * 4 + m][f], acc[mh * 4 + m][f], o);
-          bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
+          bf16x4 v;
+          if (EPI == VSTAR_EPI_SILU_MUL) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = (short)f2bf(act_silu_bf16(rbf(acc[mh * 4 + m][2 * f][e])) * rbf(acc[mh * 4 + m][2 * f + 1][e]));
+          } else {   // stage 1 = bf16(acc + bias); the activation is applied after the transpose
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (short)f2bf(acc[mh * 4 + m][f][e] + bias_v[f][e]);
+          }
           *(bf16x4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
+#pragma unroll 1
       for (int it = 0; it < 64 / RPI; ++it) {
-        const int rl = it * RPI + lane / CH;
-        const int ch = lane % CH;
+        const int rl = it * RPI + rl0;
         const bf16x8 v = *(const bf16x8*)(slab + rl * RSTRIDE + ch * 16);
         const int row = m0 + wr * 128 + mh * 64 + rl;
         if (row < p.M) {
