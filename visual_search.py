@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Search-only evaluation entry point (same flags and printed metrics as the reference's visual_search.py:28-52,520-566),
+driven by the HIP engine: `VSM` from vstar_amd.vsm, batched `visual_search` from vstar_amd.search.
+
+  python visual_search.py --version /path/to/seal_vsm_7b --vision-tower /path/to/clip-vit-large-patch14 \
+         --benchmark-folder vstar_bench
+Extra (additive) flags: --device, --batch, --synthetic-seed (random weights when no checkpoint is staged).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+from vstar_amd.config import VSMConfig
+from vstar_amd.search import iou, smallest_size_for, visual_search
+from vstar_amd.vsm import VSM
+
+SPLITS = ("direct_attributes", "relative_position")
+
+
+def parse_args(argv):
+    p = argparse.ArgumentParser(description="Visual Search Evaluation")
+    p.add_argument("--version", default="craigwu/seal_vsm_7b")
+    p.add_argument("--benchmark-folder", default="vstar_bench", type=str)
+    p.add_argument("--visualization", action="store_true", default=False)
+    p.add_argument("--output_path", default="", type=str)
+    p.add_argument("--confidence_low", default=0.3, type=float)
+    p.add_argument("--confidence_high", default=0.5, type=float)
+    p.add_argument("--target_cue_threshold", default=6.0, type=float)
+    p.add_argument("--target_cue_threshold_decay", default=0.7, type=float)
+    p.add_argument("--target_cue_threshold_minimum", default=3.0, type=float)
+    p.add_argument("--minimum_size_scale", default=4.0, type=float)
+    p.add_argument("--minimum_size", default=224, type=int)
+    p.add_argument("--model_max_length", default=512, type=int)
+    p.add_argument("--vision-tower", default="openai/clip-vit-large-patch14", type=str)
+    p.add_argument("--use_mm_start_end", action="store_true", default=True)
+    p.add_argument("--conv_type", default="llava_v1", type=str, choices=["llava_v1", "llava_llama_2"])
+    # additive
+    p.add_argument("--device", default=0, type=int)
+    p.add_argument("--batch", default=32, type=int, help="crops per engine pass")
+    p.add_argument("--synthetic-seed", default=None, type=int)
+    return p.parse_args(argv)
+
+
+def iter_samples(folder):
+    for split in SPLITS:
+        d = os.path.join(folder, split)
+        for name in sorted(os.listdir(d)):
+            if name.endswith(".json"):
+                continue
+            ann = json.load(open(os.path.join(d, os.path.splitext(name)[0] + ".json")))
+            for gt_bbox, target in zip(ann["bbox"], ann["target_object"]):
+                yield split, os.path.join(d, name), gt_bbox, target
+
+
+def main(argv):
+    args = parse_args(argv)
+    if args.visualization:
+        raise SystemExit("--visualization (cv2/matplotlib rendering) is out of scope of this engine")
+    vsm = VSM(args, cfg=VSMConfig.seal_7b(224, max_batch=args.batch), device=args.device, synthetic_seed=args.synthetic_seed)
+    hits, lengths = [], []
+    for _, path, gt_bbox, target in iter_samples(args.benchmark_folder):
+        image = Image.open(path).convert("RGB")
+        smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
+        step, n_steps, ok, _ = visual_search(
+            vsm, image, target, target_bbox=gt_bbox, smallest_size=smallest, confidence_high=args.confidence_high,
+            confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
+            target_cue_threshold_decay=args.target_cue_threshold_decay,
+            target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+        if not ok:
+            hits.append(0)
+            lengths.append(0)
+            continue
+        box = step["detection_result"]
+        box[0] += step["bbox"][0]
+        box[1] += step["bbox"][1]
+        hits.append(1.0 if iou(box, gt_bbox).item() > 0.5 else 0.0)
+        lengths.append(n_steps)
+    print("Avg search path length:", np.mean([n for n, h in zip(lengths, hits) if h]))
+    print("Top 1 Acc:", np.mean(hits))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

@@ -1,0 +1,108 @@
+"""SEAL orchestration for V*Bench (reference: vstar_bench_eval.py:168-280): VQA-LLM free-form answer -> parse the
+"missing objects" list -> visual search per object on the HIP engine -> object crops + focus prompt -> option ranking.
+The VQA-LLM itself is injected (`vqa_llm` with free_form_inference / multiple_choices_inference / get_object_crop /
+image_processor, as the reference's VQA_LLM class offers); building it on the HIP kernels is SURVEY.md §8f row 2."""
+from __future__ import annotations
+
+import json
+import os
+from collections import defaultdict
+from copy import deepcopy
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from PIL import Image
+
+from .config import VSMConfig
+from .search import smallest_size_for, visual_search
+from .vsm import VSM
+
+MISSING_MSG = ("Sorry, I can not answer the question. Some visual information about the following objects is missing or "
+               "unclear:")
+FOCUS_MSG = "Additional visual information to focus on: "
+
+
+def expand2square_centered(img: Image.Image, color):
+    """The VQA-LLM side pads CENTRED and reports the offsets (vstar_bench_eval.py:25-36)."""
+    w, h = img.size
+    if w == h:
+        return img, 0, 0
+    side = max(w, h)
+    out = Image.new(img.mode, (side, side), color)
+    left, top = ((0, (w - h) // 2) if w > h else ((h - w) // 2, 0))
+    out.paste(img, (left, top))
+    return out, left, top
+
+
+def parse_missing_objects(prediction: str):
+    if MISSING_MSG not in prediction:
+        return []
+    tail = prediction.split(MISSING_MSG)[-1]
+    if tail.endswith("."):
+        tail = tail[:-1]
+    return [t.strip() for t in tail.split(",")]
+
+
+def search_objects(vsm, image_path, names, args):
+    found = []
+    for name in names:
+        image = Image.open(image_path).convert("RGB")
+        smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
+        step, _, _, all_valid = visual_search(vsm, image, name, target_bbox=None, smallest_size=smallest)
+        boxes = all_valid if all_valid is not None else [step["detection_result"]]
+        for b in boxes:
+            b[0] += step["bbox"][0]
+            b[1] += step["bbox"][1]
+            found.append({"bbox": b.tolist(), "name": name})
+    return found
+
+
+def focus_question(question, found, image, pad_left, pad_top):
+    parts = []
+    for f in found:
+        x, y, w, h = f["bbox"]
+        x, y = x + pad_left, y + pad_top
+        n = [x / image.width, y / image.height, (x + w) / image.width, (y + h) / image.height]
+        parts.append("{} <object> at location [{:.3f},{:.3f},{:.3f},{:.3f}]".format(f["name"], *n))
+    return FOCUS_MSG + "; ".join(parts) + ".\n" + question
+
+
+def eval_model(args, vqa_llm, vsm=None):
+    if vsm is None:
+        vsm_args = SimpleNamespace(version=args.vsm_model_path, vision_tower="openai/clip-vit-large-patch14",
+                                   conv_type="llava_v1", use_mm_start_end=True, model_max_length=512)
+        vsm = VSM(vsm_args, cfg=VSMConfig.seal_7b(224))
+    mean_color = tuple(int(x * 255) for x in vqa_llm.image_processor.image_mean)
+    results, per_type, everything = {}, defaultdict(list), []
+    for split in ("direct_attributes", "relative_position"):
+        results[split] = []
+        folder = os.path.join(args.benchmark_folder, split)
+        for image_file in [f for f in os.listdir(folder) if ".json" not in f]:
+            path = os.path.join(folder, image_file)
+            ann = json.load(open(path.split(".")[0] + ".json"))
+            question, options = ann["question"], ann["options"]
+            square, _, _ = expand2square_centered(Image.open(path).convert("RGB"), mean_color)
+            prediction = vqa_llm.free_form_inference(square, question)
+            missing = parse_missing_objects(prediction)
+            found = search_objects(vsm, path, missing, args) if missing else []
+            image = Image.open(path).convert("RGB")
+            if missing:
+                crops = torch.stack([vqa_llm.get_object_crop(image, deepcopy(f["bbox"]), patch_scale=1.2) for f in found], 0)
+                square, left, top = expand2square_centered(image, mean_color)
+                long_objects = [len(found) <= 2] * len(found)
+                chosen = vqa_llm.multiple_choices_inference(square, focus_question(question, found, square, left, top), options,
+                                                            crops, images_long=[False], objects_long=long_objects)
+            else:
+                chosen = vqa_llm.multiple_choices_inference(image, question, options)
+            correct = 1 if chosen == 0 else 0
+            per_type[split].append(correct)
+            everything.append(correct)
+            results[split].append({"question": question, "options": options, "image": image_file,
+                                   "prediction_freeform": prediction, "missing_objects": missing, "search_result": found,
+                                   "option_chosen": chosen, "correct": correct})
+        print(split, np.mean(per_type[split]))
+    print(np.mean(everything))
+    with open(args.output_path, "w") as f:
+        json.dump(results, f, indent=4)
+    return results
