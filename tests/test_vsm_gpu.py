@@ -1,0 +1,89 @@
+"""The drop-in VSM class and the batched search loop on the MI355X (tiny-width model, synthetic weights/tokenizer):
+return conventions of visual_search.py:208-225, parity with the oracle on the SAME preprocessed inputs, batch == single,
+and batched-speculative search == one-crop-at-a-time search."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsm_oracle
+from oracle.gen_search_golden import synthetic_image
+from vstar_amd import preprocess as pp
+from vstar_amd.config import VSMConfig
+from vstar_amd.engine import VstarEngine
+from vstar_amd.search import smallest_size_for, visual_search
+from vstar_amd.vsm import VSM
+from vstar_amd.weights import random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vsm(cuda):
+    cfg = VSMConfig.tiny(max_batch=8, max_text_len=96)
+    eng = VstarEngine(cfg, 0)
+    eng.load_state_dict(random_state_dict(cfg, seed=5, dtype=torch.bfloat16))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_inference_conventions_and_oracle(vsm):
+    img = synthetic_image(500, 300, 3)
+    q = pp.LOCATE_QUESTION.format("blue kite")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        boxes, scores, heat = vsm.inference(img, q, mode="detection")
+        seg = vsm.inference(img, q, mode="segmentation")
+    assert boxes.shape == (2304, 4) and scores.shape == (2304, 1) and heat.shape == (300, 500)
+    assert heat.dtype == torch.float32 and float(heat.min()) >= 0 and 0 < float(scores.min()) and float(scores.max()) < 1
+    assert torch.equal(seg, heat)
+    with pytest.raises(NotImplementedError):
+        vsm.inference(img, "where?", mode="vqa")
+    # oracle on the identical preprocessed tensors / ids
+    cfg = vsm.cfg
+    ids, loc_pos, _, _ = vsm._ids(q)
+    clip = torch.from_numpy(pp.clip_preprocess(img, 224)).bfloat16()[None]
+    owl = torch.from_numpy(pp.owl_preprocess(img, 768)).bfloat16()[None]
+    sd = {k: v.float() for k, v in random_state_dict(cfg, seed=5, dtype=torch.bfloat16).items()}
+    ref = vsm_oracle.vsm_forward(sd, cfg, clip.float(), owl.float(), torch.from_numpy(ids.astype(np.int64))[None], vsm.loc_token_idx)
+    assert int(ref["loc_pos"][0]) == loc_pos
+    assert np.abs(boxes.numpy() - ref["pred_boxes"][0].numpy()).max() < 1e-2
+    assert rel_l2(scores.numpy(), torch.sigmoid(ref["pred_logits"][0]).numpy()) < 2e-2
+    ref_heat = vsm_oracle.upsample_mask(ref["low_res_masks"], (300, 500))[0, 0].numpy()
+    assert rel_l2(heat.numpy(), ref_heat) < 6e-2       # bf16 noise floor of the mask head, see test_engine_gpu.py
+
+
+def test_batch_equals_single(vsm):
+    imgs = [synthetic_image(300 + 40 * i, 260, 10 + i) for i in range(5)]
+    q = pp.LOCATE_QUESTION.format("dog")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        batch = vsm.inference_batch(imgs, q, mode="detection")
+        for i in (0, 3):
+            b, s, h = vsm.inference(imgs[i], q, mode="detection")
+            assert torch.equal(b, batch[i][0]) and torch.equal(s, batch[i][1]) and torch.equal(h, batch[i][2])
+
+
+def test_batched_search_equals_sequential(vsm):
+    img = synthetic_image(1280, 720, 21)
+    smallest = smallest_size_for(1280, 720)
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        s_seq, s_bat = {}, {}
+        r_seq = visual_search(vsm, img, "kite", None, smallest, speculate=False, stats=s_seq, **kw)
+        r_bat = visual_search(vsm, img, "kite", None, smallest, speculate=True, stats=s_bat, **kw)
+    assert r_seq[1] == r_bat[1] and r_seq[2] == r_bat[2]
+    assert r_seq[0]["bbox"] == r_bat[0]["bbox"]
+    assert torch.equal(r_seq[0]["detection_result"], r_bat[0]["detection_result"])
+    assert [p["bbox"] for p in s_seq["search_path"]] == [p["bbox"] for p in s_bat["search_path"]]
+    # exhaustive search (confidence_high=2 is unreachable): 1 + 4 + 16 nodes for 1280x720 with smallest_size 224
+    assert s_seq["path_visited"] == 21 and s_seq["engine_batches"] == 21
+    assert s_bat["engine_batches"] <= 4 and s_bat["crops_scored"] == 21
