@@ -141,3 +141,40 @@ def test_errors_are_reported(cuda):
         eng.score_batch(clip, owl, ids, np.array([3], dtype=np.int32))
     with pytest.raises(IndexError):
         loc_positions(ids, 999, 256)
+
+
+def test_engine_real_widths_vs_oracle(cuda):
+    """Real 7B / CLIP-L / OWL-ViT-B WIDTHS and token counts (hidden 4096/1024/768, 32/16/12 heads, mlp 11008, S=640,
+    N=577/2305) with few layers, so that every kernel runs at the exact shapes of the benchmark and is checked against the
+    fp32 oracle; depth (32/23/12 layers) only repeats these shapes."""
+    cfg = VSMConfig.seal_7b(336, clip_layers=3, llm_layers=2, owl_layers=2, llm_vocab=4096, max_batch=2, max_text_len=65)
+    loc_id = cfg.llm_vocab - 1
+    sd = random_state_dict(cfg, seed=11, dtype=torch.bfloat16)
+    eng = VstarEngine(cfg, 0)
+    eng.load_state_dict(sd)
+    B, L = 2, 65
+    g = torch.Generator().manual_seed(4)
+    clip = torch.randn(B, 3, 336, 336, generator=g).bfloat16()
+    owl = torch.randn(B, 3, 768, 768, generator=g).bfloat16()
+    ids = torch.randint(3, loc_id - 3, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, 35] = -200
+    ids[:, L - 3] = loc_id
+    loc = loc_positions(ids.numpy(), loc_id, cfg.n_img_tokens)
+    verify = np.stack([loc, loc + 1], axis=1)
+    out = eng.score_batch(clip, owl, ids.numpy(), loc, verify_pos=verify)
+    sd32 = {k: v.float() for k, v in sd.items()}
+    ref = vsm_oracle.vsm_forward(sd32, cfg, clip.float(), owl.float(), ids, loc_id, verify_pos=torch.from_numpy(verify).long())
+    P = cfg.n_img_tokens
+    taps = {
+        "clip_features": eng.debug_read("clip_features", B * (P + 1) * cfg.clip_hidden).reshape(B, P + 1, -1)[:, 1:],
+        "llm_hidden_loc": eng.debug_read("llm_hidden_loc", B * cfg.llm_hidden).reshape(B, -1),
+        "embed_det": eng.debug_read("embed_det", B * 512).reshape(B, -1),
+        "pred_logits": out["pred_logits"], "pred_boxes": out["pred_boxes"], "low_res_masks": out["low_res_masks"],
+    }
+    errs = {k: rel_l2(v, ref[k].numpy()) for k, v in taps.items()}
+    print("\nreal-width rel-L2 vs fp32 oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert np.isfinite(v) and v < (6e-2 if k == "low_res_masks" else 3e-2), (k, v)
+    assert np.abs(out["pred_boxes"] - ref["pred_boxes"].numpy()).max() < 2e-2
+    eng.close()

@@ -59,9 +59,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   const int tiles_m = (p.M + BM - 1) / BM;
   const int tiles_n = (p.N + BN - 1) / BN;
   const int nwg = tiles_m * tiles_n;
+  // persistent: this workgroup walks tiles blockIdx.x, +gridDim.x, ... (gridDim.x = #CUs, a multiple of 8, so a
+  // workgroup's tiles keep its XCD in the remap below).  The previous tile's output stores drain while the next
+  // tile's first DMA pieces are in flight, and there is no per-tile workgroup launch.
+  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
   int t;
   {
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: pieces 0..D-1 in flight, pieces 0,1 landed, everyone past the barrier; group 1 one barrier behind ----
+  BAR();   // every wave has finished reading its epilogue slab of the previous tile: the ring may be overwritten
   issue_piece(std::integral_constant<int, 0>{}, 0);
   issue_piece(std::integral_constant<int, 1>{}, 0);
   issue_piece(std::integral_constant<int, 2>{}, 0);
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     half_pass(std::integral_constant<int, 0>{});
     half_pass(std::integral_constant<int, 1>{});
   }
+  }  // persistent tile loop
 }
 
 template <int EPI, bool OUT_F32>
@@ -293,8 +298,16 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu <= 0) n_cu = 8;
+  }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError();
 }
 
