@@ -861,6 +861,7 @@ int vstar_op_gemm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* 
   GemmParams p{};
   p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
+  { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   const bool nosync = (epilogue & VSTAR_EPI_NOSYNC) != 0;
   hipError_t e = gemm_bf16(p, epilogue & 0xff, out_f32 != 0, (hipStream_t)stream);
   if (e == hipSuccess && !nosync) e = hipStreamSynchronize((hipStream_t)stream);

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   if (group == 0) BAR();   // every wave must execute the same number of barriers
 
   // ---- epilogue ----
+  if (p.debug_flags & 2) continue;
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
   if constexpr (OUT_F32) {
     // fp32 outputs (lm_head / head taps): direct accumulator-layout stores
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const int rl = it * RPI + rl0;
         const bf16x8 v = *(const bf16x8*)(slab + rl * RSTRIDE + ch * 16);
         const int row = m0 + wr * 128 + mh * 64 + rl;
-        if (row < p.M) {
+        if (row < p.M && !(p.debug_flags & 1)) {
           const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
           gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
         }

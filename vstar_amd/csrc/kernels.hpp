@@ -15,6 +15,7 @@ struct GemmParams {
   const bf16_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
   void* C; int64_t ldc; int c_group; int64_t c_gstride; int64_t c_off;
   int M, N, K;
+  int debug_flags;   // diagnostics only: bit0 = skip the epilogue's global stores, bit1 = skip the whole epilogue
 };
 hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 
