@@ -330,3 +330,13 @@ def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.T
         out["pred_logits"], out["pred_boxes"] = logits, boxes
         out["low_res_masks"] = sam_mask_head(sd, fmap, out["embed_seg"])
     return out
+
+
+def greedy_next_logits(sd: SD, cfg, images_clip: torch.Tensor, input_ids: torch.Tensor) -> torch.Tensor:
+    """One step of the reference's no-cache greedy decoding (VSM.py:451-458 with use_cache=False, VSM.py:151): a full
+    forward over the sequence so far; returns lm_head logits of the LAST position, [B, vocab] fp32."""
+    dt = sd["model.norm.weight"].dtype
+    feats = clip_features(sd, images_clip.to(dt), cfg.clip_heads, cfg.clip_layers, cfg.clip_select_layer)
+    x = splice(sd, input_ids, _lin(sd, "model.mm_projector", feats))
+    hidden = llama_prefill(sd, x, cfg.llm_heads, cfg.llm_layers, cfg.llm_rms_eps, cfg.llm_rope_theta)
+    return F.linear(hidden[:, -1], sd["lm_head.weight"]).float()

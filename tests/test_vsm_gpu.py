@@ -87,3 +87,23 @@ def test_batched_search_equals_sequential(vsm):
     # exhaustive search (confidence_high=2 is unreachable): 1 + 4 + 16 nodes for 1280x720 with smallest_size 224
     assert s_seq["path_visited"] == 21 and s_seq["engine_batches"] == 21
     assert s_bat["engine_batches"] <= 4 and s_bat["crops_scored"] == 21
+
+
+def test_vqa_mode_greedy_decode_matches_oracle(vsm):
+    """mode='vqa' = the reference's no-cache greedy loop: every engine-chosen token must be the oracle's arg-max given the
+    same prefix (or within bf16 noise of it when the top-2 logits are nearly tied)."""
+    img = synthetic_image(400, 300, 8)
+    q = pp.CUE_QUESTION.format("kite")
+    new = vsm.generate_ids(img, q, max_new_tokens=6)
+    assert 1 <= len(new) <= 6
+    text = vsm.inference(img, q, mode="vqa")
+    assert isinstance(text, str)
+    cfg = vsm.cfg
+    sd = {k: v.float() for k, v in random_state_dict(cfg, seed=5, dtype=torch.bfloat16).items()}
+    clip = torch.from_numpy(pp.clip_preprocess(img, 224)).bfloat16().float()[None]
+    ids = pp.tokenizer_image_token(pp.build_prompt(q), vsm.vsm_tokenizer)
+    for tok in new:
+        logits = vsm_oracle.greedy_next_logits(sd, cfg, clip, torch.tensor([ids]))[0]
+        span = float(logits.max() - logits.min())
+        assert float(logits.max() - logits[tok]) <= 0.02 * span, (tok, int(logits.argmax()))
+        ids.append(tok)

@@ -153,13 +153,13 @@ class _NodeScorer:
             else:
                 res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
             for b, c, r in zip(todo, crops, res):
-                self.cache[tuple(b)] = (r, c.size)
+                self.cache[tuple(b)] = [r, c.size, not self.batched]     # [result, (w, h), heatmap already full-res?]
             self.n_scored += len(todo)
             self.n_batches += 1
-        (boxes, scores, heat), (w, h) = self.cache[key]
-        if self.batched and tuple(heat.shape) != (h, w):
+        (boxes, scores, heat), (w, h), full = self.cache[key]
+        if not full:
             heat = self.vsm.upsample_heatmap(heat, h, w)        # full-resolution heatmap only for COMMITTED nodes
-            self.cache[key] = ((boxes, scores, heat), (w, h))
+            self.cache[key] = [(boxes, scores, heat), (w, h), True]
         return boxes, scores, heat
 
 
@@ -219,8 +219,8 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                     phrase = phrase[:-1]
                 phrase = phrase.split(target_object_name)[-1]
                 if noun_chunker is None:
-                    raise NotImplementedError("the contextual-cue branch needs a noun chunker (spaCy en_core_web_sm in the "
-                                              "reference, visual_search.py:54-112); pass noun_chunker=")
+                    from .noun_chunks import get_noun_chunker
+                    noun_chunker = get_noun_chunker()     # spaCy if installed, else the rule-based fallback
                 noun_chunks = noun_chunker(phrase)
                 phrase = noun_chunks[0] if len(noun_chunks) == 1 else "region {}".format(phrase)
                 ctx = vsm.inference(copy.deepcopy(patch), LOCATE_QUESTION.format(phrase), mode="segmentation")

@@ -4,7 +4,8 @@ Same constructor argument (the `parse_args` namespace: version, vision_tower, co
 model_max_length) and the same `inference(image, question, mode)` return conventions:
   'detection'    -> (pred_boxes [2304,4] cpu, sigmoid scores [2304,1] cpu, heatmap [h,w] clamped >= 0)
   'segmentation' -> heatmap [h,w]
-  'vqa'          -> str            (free-text decode: SURVEY.md §8f row 1, not built yet -> NotImplementedError)
+  'vqa'          -> str            (greedy decode WITHOUT a KV cache, exactly like the reference: one full prefill per
+                                    generated token, VSM.py:151 `use_cache=False`; used only by the contextual-cue branch)
 plus `inference_batch` (many crops, one engine pass) which is what the batched search scheduler calls.
 
 Difference in mechanism, not in result: the reference runs HF greedy `generate` with use_cache=False and reads the
@@ -101,8 +102,7 @@ class VSM:
         results in the `inference` convention (with `upsample=False` the heatmap slot holds the 192x192 low-res logits)."""
         assert mode in ("vqa", "segmentation", "detection")
         if mode == "vqa":
-            raise NotImplementedError("mode='vqa' (free-text greedy decode, visual_search.py:427-443) is the next scope "
-                                      "row (SURVEY.md §8f-1); the contextual-cue branch needs a KV-cache decode path")
+            return [self.generate(im, question) for im in images]
         ids, loc_pos, ver_pos, ver_tok = self._ids(question)
         nv = min(len(ver_pos), 8)
         ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
@@ -136,6 +136,35 @@ class VSM:
                 raise TemplateMismatch(msg)
             warnings.warn(msg + " — tolerated because strict_template=False (synthetic weights)")
         return out
+
+    @torch.inference_mode()
+    def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100) -> List[int]:
+        """Greedy decoding as the reference runs it for mode='vqa' (VSM.py:451-458 with use_cache=False,
+        max_new_tokens=100 from visual_search.py:204): every new token costs one full CLIP + LLaMA prefill over the
+        sequence so far; the engine returns argmax(lm_head(h_last)).  Stops at EOS.  Returns the generated ids."""
+        ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end), self.vsm_tokenizer)
+        clip = torch.from_numpy(clip_preprocess(image, self.cfg.clip_image_size)).bfloat16()[None]
+        P = self.cfg.n_img_tokens
+        eos = getattr(self.vsm_tokenizer, "eos_token_id", 2)
+        new: List[int] = []
+        for _ in range(max_new_tokens):
+            if len(ids) >= self.cfg.max_text_len:
+                break
+            last = len(ids) - 1 + (P - 1)          # spliced position of the last token
+            res = self.engine.score_batch(clip, None, np.asarray([ids], np.int32), np.asarray([last], np.int32),
+                                          verify_pos=np.asarray([[last]], np.int32), skip_owl=True)
+            nxt = int(res["tf_argmax"][0, 0])
+            ids.append(nxt)
+            new.append(nxt)
+            if nxt == eos:
+                break
+        return new
+
+    @torch.inference_mode()
+    def generate(self, image: Image.Image, question: str, max_new_tokens: int = 100) -> str:
+        new = self.generate_ids(image, question, max_new_tokens)
+        text = self.vsm_tokenizer.batch_decode([new], skip_special_tokens=True)[0]
+        return text.replace("\n", "").replace("  ", " ").strip()      # visual_search.py:217-219
 
     @torch.inference_mode()
     def inference(self, image: Image.Image, question: str, mode: str = "segmentation"):
