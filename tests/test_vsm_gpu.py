@@ -44,8 +44,6 @@ def test_inference_conventions_and_oracle(vsm):
     assert boxes.shape == (2304, 4) and scores.shape == (2304, 1) and heat.shape == (300, 500)
     assert heat.dtype == torch.float32 and float(heat.min()) >= 0 and 0 < float(scores.min()) and float(scores.max()) < 1
     assert torch.equal(seg, heat)
-    with pytest.raises(NotImplementedError):
-        vsm.inference(img, "where?", mode="vqa")
     # oracle on the identical preprocessed tensors / ids
     cfg = vsm.cfg
     ids, loc_pos, _, _ = vsm._ids(q)
