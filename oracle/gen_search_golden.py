@@ -26,14 +26,25 @@ def synthetic_image(w, h, seed):
     return Image.fromarray(low).resize((w, h), Image.BILINEAR)
 
 
-def run_case(search_fn, case):
+CUE_TEXT = "The object is most likely to appear on the wooden table near the window."
+
+
+def run_case(search_fn, case, cue=False):
     w, h, iseed, vseed, shift, scale = case
     img = synthetic_image(w, h, iseed)
     smallest = max(int(np.ceil(min(w, h) / scale)), 224)
-    vsm = FakeVSM(seed=vseed, conf_shift=shift)
+    # cue=True: detection heatmaps stay below the cue threshold, so every expanded node takes the contextual-cue branch
+    # (VQA text -> phrase -> segmentation heatmap); the reference's spaCy is stubbed to return no tokens, so its
+    # noun-chunk list is empty and the phrase becomes "region <phrase>" (visual_search.py:437-440)
+    vsm = FakeVSM(seed=vseed, conf_shift=shift, gain=0.1 if cue else 9.0, vqa_text=CUE_TEXT if cue else None)
     # gain 9 keeps heat.max() above the decayed cue threshold so the (unbuilt) contextual-cue branch is not taken
     final_step, path_length, ok, all_valid = search_fn(vsm, img, "object", [0, 0, 10, 10], smallest)
-    return {"case": list(case), "smallest_size": smallest, "calls": vsm.calls, "path_length": int(path_length), "success": bool(ok),
+    if cue:
+        extra = {"cue": True, "n_vqa": sum(1 for m, _ in vsm.questions if m == "vqa"),
+                 "seg_questions": sorted({q for m, q in vsm.questions if m == "segmentation"})}
+    else:
+        extra = {"cue": False}
+    return {**extra, "case": list(case), "smallest_size": smallest, "calls": vsm.calls, "path_length": int(path_length), "success": bool(ok),
             "final_bbox": [int(v) for v in final_step["bbox"]],
             "detection_result": [float(v) for v in final_step["detection_result"]],
             "n_all_valid": None if all_valid is None else int(all_valid.shape[0])}
@@ -42,6 +53,7 @@ def run_case(search_fn, case):
 def main():
     ref = load_reference_search()
     out = [run_case(ref.visual_search, c) for c in CASES]
+    out += [run_case(ref.visual_search, c, cue=True) for c in CASES[1:3]]
     json.dump(out, open(OUT, "w"), indent=1)
     for o in out:
         print(o)

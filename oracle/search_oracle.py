@@ -23,9 +23,11 @@ REF = os.environ.get("VSTAR_REFERENCE", "/root/reference")
 class FakeVSM:
     """inference(image, question, mode) -> same conventions as visual_search.py:208-225."""
 
-    def __init__(self, seed: int = 0, n_boxes: int = 64, gain: float = 9.0, conf_shift: float = -2.5):
+    def __init__(self, seed: int = 0, n_boxes: int = 64, gain: float = 9.0, conf_shift: float = -2.5, vqa_text=None):
         self.seed, self.n_boxes, self.gain, self.conf_shift = seed, n_boxes, gain, conf_shift
+        self.vqa_text = vqa_text
         self.calls = 0
+        self.questions = []
 
     def _rng(self, image):
         w, h = image.size
@@ -34,14 +36,17 @@ class FakeVSM:
 
     def inference(self, image, question, mode="segmentation"):
         self.calls += 1
+        self.questions.append((mode, question))
         g = self._rng(image)
         w, h = image.size
-        low = torch.randn(1, 1, 12, 12, generator=g) * self.gain
+        if mode == "vqa":
+            if self.vqa_text is None:
+                raise NotImplementedError
+            return self.vqa_text
+        low = torch.randn(1, 1, 12, 12, generator=g) * (self.gain if mode == "detection" else 9.0)
         heat = torch.clamp(F.interpolate(low, (h, w), mode="bilinear", align_corners=False)[0, 0], min=0)
         if mode == "segmentation":
             return heat
-        if mode == "vqa":
-            raise NotImplementedError
         boxes = torch.rand(self.n_boxes, 4, generator=g)
         scores = torch.sigmoid(torch.randn(self.n_boxes, 1, generator=g) * 1.5 + self.conf_shift)
         return boxes, scores, heat

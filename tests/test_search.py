@@ -13,7 +13,9 @@ from oracle.gen_search_golden import synthetic_image
 from oracle.search_oracle import FakeVSM
 from vstar_amd import search
 
-GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "search_paths.json")))
+ALL_GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "search_paths.json")))
+GOLD = [g for g in ALL_GOLD if not g.get("cue")]
+CUE_GOLD = [g for g in ALL_GOLD if g.get("cue")]
 
 
 class BatchedFake(FakeVSM):
@@ -86,6 +88,23 @@ def test_helpers_match_reference_semantics():
     z = np.zeros((4, 4, 1), np.float32)
     assert [float(s) for s in search.get_subpatch_scores(z, [0, 0, 4, 4], [[0, 0, 2, 2]])] == [0.0]
     assert abs(search.iou([0, 0, 10, 10], [5, 5, 10, 10]) - 25 / 175) < 1e-12
+
+
+@pytest.mark.parametrize("gold", CUE_GOLD, ids=[f"cue{g['case'][0]}x{g['case'][1]}" for g in CUE_GOLD])
+def test_contextual_cue_branch_matches_reference(gold):
+    """score_max <= threshold: VQA text -> location phrase -> segmentation heatmap (visual_search.py:427-443), recorded from
+    the reference with spaCy stubbed to an empty parse (=> "region <phrase>")."""
+    from oracle.gen_search_golden import CUE_TEXT
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    vsm = FakeVSM(seed=vseed, conf_shift=shift, gain=0.1, vqa_text=CUE_TEXT)
+    stats = {}
+    _check(search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"], noun_chunker=lambda s: [],
+                                stats=stats), gold)
+    assert vsm.calls == gold["calls"]
+    assert sum(1 for m, _ in vsm.questions if m == "vqa") == gold["n_vqa"]
+    assert sorted({q for m, q in vsm.questions if m == "segmentation"}) == gold["seg_questions"]
+    assert stats["search_path"][0]["context_cue"].startswith(CUE_TEXT + "#region")
 
 
 def test_contextual_cue_branch_needs_vqa():
