@@ -129,3 +129,76 @@ def test_allgather_records_world2_gloo(n_items):
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, True), (1, True)]
+
+
+# ---- data-parallel VSM.inference_batch / visual_search over 2 ranks (gloo), with a deterministic fake engine ----
+class _FakeEngine:
+    """Stands in for VstarEngine on CPU: a record is a deterministic function of the crop's preprocessed pixels."""
+    device = 0
+
+    def __init__(self, max_batch=3):
+        from vstar_amd.config import VSMConfig
+        self.cfg = VSMConfig.tiny(max_batch=max_batch, max_text_len=96)
+        self.calls = []
+
+    def score_batch(self, clip, owl, ids, loc, verify_pos=None, skip_owl=False, sync=True, raw=False):
+        from vstar_amd import _lib
+        B = clip.shape[0]
+        self.calls.append(B)
+        rec = np.zeros((B, _lib.RESULT_FLOATS), np.float32)
+        for b in range(B):
+            seed = int(abs(float(clip[b].float().sum()) * 1000 + float(owl[b].float().sum()))) % (2 ** 31)
+            g = torch.Generator().manual_seed(seed)
+            rec[b, :2304] = (torch.randn(2304, generator=g) * 1.5 - 6).numpy()
+            rec[b, 2304:2304 * 5] = torch.rand(2304 * 4, generator=g).numpy()
+            low = torch.nn.functional.interpolate(torch.randn(1, 1, 12, 12, generator=g) * 9, (192, 192), mode="bilinear")
+            rec[b, 2304 * 5:2304 * 5 + 192 * 192] = low.reshape(-1).numpy()
+        return rec if raw else VstarEngine.unpack(rec, 0)
+
+    unpack = staticmethod(VstarEngine.unpack)
+
+    def upsample_mask(self, low, h, w):
+        t = torch.from_numpy(np.asarray(low, np.float32)).reshape(1, 1, 192, 192)
+        return torch.clamp(torch.nn.functional.interpolate(t, (h, w), mode="bilinear", align_corners=False), min=0)[0, 0].numpy()
+
+
+def _search_once():
+    import warnings
+    from oracle.gen_search_golden import synthetic_image
+    from vstar_amd.search import smallest_size_for, visual_search
+    from vstar_amd.vsm import VSM
+    eng = _FakeEngine()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(eng.cfg.llm_vocab), strict_template=False)
+        img = synthetic_image(1280, 720, 5)
+        stats = {}
+        step, n, ok, _ = visual_search(vsm, img, "kite", None, smallest_size_for(1280, 720), confidence_high=2.0,
+                                       target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0, stats=stats)
+    return ([int(v) for v in step["bbox"]], [float(v) for v in step["detection_result"]], int(n), bool(ok),
+            [p["bbox"] for p in stats["search_path"]], sum(eng.calls))
+
+
+def _dp_search_worker(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    q.put((rank, _search_once()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_search_world2_equals_single_process():
+    import torch.multiprocessing as mp
+    single = _search_once()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_search_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+    for r in (0, 1):
+        assert res[r][:5] == single[:5]                    # same path, boxes and decisions on every rank
+    assert res[0][5] + res[1][5] == single[5]              # the crops were split between the ranks, none scored twice
+    assert min(res[0][5], res[1][5]) >= single[5] // 2 - 2

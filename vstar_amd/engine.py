@@ -69,7 +69,7 @@ class VstarEngine:
 
     # ---- the hot path ----
     def score_batch(self, clip_pix, owl_pix, input_ids, loc_pos, verify_pos=None, skip_owl: bool = False,
-                    sync: bool = True) -> Optional[Dict[str, np.ndarray]]:
+                    sync: bool = True, raw: bool = False):
         """clip_pix [B,3,I,I], owl_pix [B,3,768,768] (bf16-castable; CPU or cuda tensors), input_ids [B,L] with one -200,
         loc_pos [B] spliced-sequence index of the hidden state that predicts [LOC]; verify_pos [B,V] optional."""
         cfg = self.cfg
@@ -108,7 +108,7 @@ class VstarEngine:
             self.handle)
         if not sync:
             return None
-        return self.unpack(out, nv)
+        return out if raw else self.unpack(out, nv)
 
     @staticmethod
     def unpack(rec: np.ndarray, n_verify: int = 0) -> Dict[str, np.ndarray]:

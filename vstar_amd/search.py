@@ -114,7 +114,8 @@ class _NodeScorer:
         self.vsm, self.image, self.question = vsm, image, question
         self.smallest_size = smallest_size
         self.batched = hasattr(vsm, "inference_batch")
-        self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) if self.batched else 1)
+        world = vsm._dist()[0] if hasattr(vsm, "_dist") else 1    # one engine batch per rank and step
+        self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) * world if self.batched else 1)
         self.speculate = speculate and self.batched and self.batch_size > 1
         self.cache: Dict[Tuple, Tuple] = {}
         self.n_scored = 0

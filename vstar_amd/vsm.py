@@ -23,7 +23,9 @@ import numpy as np
 import torch
 from PIL import Image
 
+from ._lib import RESULT_FLOATS
 from .config import VSMConfig
+from .dist import allgather_numpy, pad_count, shard_indices
 from .engine import VstarEngine
 from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, SyntheticTokenizer, build_prompt, clip_preprocess,
                          owl_preprocess, tokenizer_image_token)
@@ -74,6 +76,19 @@ class VSM:
         self.strict_template = real if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
 
+    # ---- multi-GPU plumbing ----
+    @staticmethod
+    def _dist():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(), dist.get_rank()
+        return 1, 0
+
+    def _allgather(self, local: np.ndarray, n_items: int) -> np.ndarray:
+        import torch.distributed as dist
+        dev = f"cuda:{self.engine.device}" if dist.get_backend() == "nccl" else "cpu"
+        return allgather_numpy(local, n_items, device=dev)
+
     # ---- prompt -> ids with the answer teacher-forced ----
     def _ids(self, question: str) -> Tuple[np.ndarray, int, List[int], List[int]]:
         prompt = build_prompt(question, self.use_mm_start_end)
@@ -106,28 +121,37 @@ class VSM:
         ids, loc_pos, ver_pos, ver_tok = self._ids(question)
         nv = min(len(ver_pos), 8)
         ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
-        out: List = []
-        ok_all = []
+        # ---- data-parallel sharding: crop i is scored by rank i % world; the fixed-size records are
+        # all-gathered (RCCL over xGMI with the nccl backend) so that every rank continues with identical results ----
+        world, rank = self._dist()
+        n = len(images)
+        mine = shard_indices(n, rank, world)
+        per = pad_count(n, world)
+        local = np.zeros((per, RESULT_FLOATS), dtype=np.float32)
         mb = self.cfg.max_batch
-        for s in range(0, len(images), mb):
-            chunk = images[s:s + mb]
+        for s0 in range(0, len(mine), mb):
+            sel = mine[s0:s0 + mb]
+            chunk = [images[i] for i in sel]
             B = len(chunk)
             clip = torch.from_numpy(np.stack([clip_preprocess(im, self.cfg.clip_image_size) for im in chunk])).bfloat16()
             owl = torch.from_numpy(np.stack([owl_preprocess(im, self.cfg.owl_image_size) for im in chunk])).bfloat16()
-            res = self.engine.score_batch(clip, owl, np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
-                                          verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)))
-            ok = (res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)
-            ok_all.append(ok)
-            for b, im in enumerate(chunk):
-                w, h = im.size
-                low = res["low_res_masks"][b, 0]
-                heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
-                if mode == "segmentation":
-                    out.append(heat)
-                else:
-                    boxes = torch.from_numpy(res["pred_boxes"][b].copy())
-                    scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
-                    out.append((boxes, scores, heat))
+            local[s0:s0 + B] = self.engine.score_batch(
+                clip, owl, np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
+                verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True)
+        records = self._allgather(local, n) if world > 1 else local[:n]
+        res = self.engine.unpack(records, nv)
+        ok_all = [(res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)] if n else []
+        out: List = []
+        for b, im in enumerate(images):
+            w, h = im.size
+            low = res["low_res_masks"][b, 0]
+            heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
+            if mode == "segmentation":
+                out.append(heat)
+            else:
+                boxes = torch.from_numpy(res["pred_boxes"][b].copy())
+                scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
+                out.append((boxes, scores, heat))
         self.last_template_ok = np.concatenate(ok_all) if ok_all else np.zeros((0,), bool)
         if not self.last_template_ok.all():
             msg = (f"{int((~self.last_template_ok).sum())}/{len(images)} crops: greedy decoding would not emit "
