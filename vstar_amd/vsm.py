@@ -16,6 +16,7 @@ engine returns argmax(lm_head(h)) at the answer positions so that this is CHECKE
 from __future__ import annotations
 
 import os
+import time
 import warnings
 from typing import List, Optional, Sequence, Tuple
 
@@ -75,6 +76,7 @@ class VSM:
         self.loc_token_idx = self.vsm_tokenizer("[LOC]", add_special_tokens=False).input_ids[0]
         self.strict_template = real if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
+        self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0}
 
     # ---- multi-GPU plumbing ----
     @staticmethod
@@ -133,12 +135,19 @@ class VSM:
             sel = mine[s0:s0 + mb]
             chunk = [images[i] for i in sel]
             B = len(chunk)
+            t0 = time.perf_counter()
             clip = torch.from_numpy(np.stack([clip_preprocess(im, self.cfg.clip_image_size) for im in chunk])).bfloat16()
             owl = torch.from_numpy(np.stack([owl_preprocess(im, self.cfg.owl_image_size) for im in chunk])).bfloat16()
+            t1 = time.perf_counter()
             local[s0:s0 + B] = self.engine.score_batch(
                 clip, owl, np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
                 verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True)
+            self.timers["preprocess_s"] += t1 - t0
+            self.timers["engine_s"] += time.perf_counter() - t1
+            self.timers["crops"] += B
+        t2 = time.perf_counter()
         records = self._allgather(local, n) if world > 1 else local[:n]
+        self.timers["gather_s"] += time.perf_counter() - t2
         res = self.engine.unpack(records, nv)
         ok_all = [(res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)] if n else []
         out: List = []
@@ -199,4 +208,7 @@ class VSM:
         """192x192 mask logits -> [h, w] heatmap, bilinear align_corners=False + clamp(min=0), on the GPU
         (VSM.py:534-537 + visual_search.py:223-224)."""
         low = low_res.numpy() if isinstance(low_res, torch.Tensor) else np.asarray(low_res)
-        return torch.from_numpy(self.engine.upsample_mask(low, h, w))
+        t0 = time.perf_counter()
+        out = torch.from_numpy(self.engine.upsample_mask(low, h, w))
+        self.timers["post_s"] += time.perf_counter() - t0
+        return out
