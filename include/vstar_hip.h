@@ -127,9 +127,18 @@ int vstar_finalize_weights(vstar_handle* h);
 #define VSTAR_F_DEVICE_INPUTS  2u
 #define VSTAR_F_DEVICE_OUTPUT  4u
 #define VSTAR_F_NO_SYNC        8u   /* do not synchronise the stream before returning (bench inner loop) */
+#define VSTAR_F_INTERNAL_PIXELS 16u /* pixels were produced on the device by vstar_preprocess_crops (clip_pix/owl_pix ignored) */
 int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, const uint16_t* owl_pix,
                           const int32_t* ids, int L, const int32_t* loc_pos,
                           const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
+
+/* GPU-side preprocessing.  vstar_image_set uploads the full RGB uint8 image [height,width,3] once;
+ * vstar_preprocess_crops turns B crop boxes (x0,y0,x1,y1 exactly as passed to PIL `image.crop`, visual_search.py:394)
+ * into the engine's CLIP and OWL-ViT input tensors: expand2square (top-left, CLIP-mean colour) + resize IxI, and resize to
+ * 768x768, both bit-identical to PIL.Image.resize(BICUBIC) on uint8, then the HF rescale/normalise -> bf16
+ * (replaces visual_search.py:186-194).  Follow with vstar_vsm_score_batch(..., VSTAR_F_INTERNAL_PIXELS). */
+int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width);
+int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy);
 
 /* Bilinear (align_corners=False) upsample of a 192x192 low-res mask to h_out x w_out fp32, then clamp(min=0).
  * Replaces F.interpolate(...) + torch.clamp (VSM.py:534-537, visual_search.py:223-224). Host in, host out. */

@@ -28,11 +28,21 @@ def test_preprocess_matches_hf_processors(w, h):
     ref = clip_proc.preprocess(pp.expand2square(img, pp.background_color()), return_tensors="np")["pixel_values"][0]
     got = pp.clip_preprocess(img, 224)
     assert got.shape == (3, 224, 224)
-    assert np.abs(got - ref).max() < 1e-5
+    assert np.array_equal(got, ref)                     # bit-identical to the HF processor
     owl_proc = OwlViTImageProcessor()
     ref2 = owl_proc(images=np.array(img), return_tensors="np")["pixel_values"][0]
     got2 = pp.owl_preprocess(img, 768)
-    assert np.abs(got2 - ref2).max() < 1e-5
+    assert np.array_equal(got2, ref2)
+
+
+@pytest.mark.parametrize("w,h,ow,oh", [(640, 480, 336, 336), (300, 900, 768, 768), (1000, 700, 224, 224), (200, 150, 768, 768),
+                                        (768, 768, 768, 768), (1920, 1080, 336, 336)])
+def test_pil_resize_oracle_is_bit_exact(w, h, ow, oh):
+    """oracle/pil_resize_oracle.py (the algorithm the GPU preprocessing kernels implement) == Pillow, bit for bit."""
+    from oracle.pil_resize_oracle import resize_u8
+    img = np.asarray(_img(w, h, w * 3 + h))
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=Image.BICUBIC))
+    assert np.array_equal(resize_u8(img, ow, oh), ref)
 
 
 def test_expand2square_top_left():

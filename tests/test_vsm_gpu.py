@@ -105,3 +105,42 @@ def test_vqa_mode_greedy_decode_matches_oracle(vsm):
         span = float(logits.max() - logits.min())
         assert float(logits.max() - logits[tok]) <= 0.02 * span, (tok, int(logits.argmax()))
         ids.append(tok)
+
+
+def test_gpu_preprocess_is_bit_identical_to_pil_hf_path(vsm):
+    """vstar_preprocess_crops (crop + top-left pad + Pillow-exact bicubic + HF normalise, on the GPU) produces exactly the
+    bf16 tensors that the host path (PIL + preprocess.py, itself bit-identical to the HF processors) feeds the engine."""
+    img = synthetic_image(1400, 900, 17)
+    # noisy high-frequency content exercises the antialiasing window
+    arr = np.asarray(img).copy()
+    arr ^= np.random.default_rng(1).integers(0, 64, size=arr.shape, dtype=np.uint8)
+    from PIL import Image
+    img = Image.fromarray(arr)
+    vsm.set_image(img)
+    boxes = [[0, 0, 1400, 900], [700, 450, 700, 450], [13, 27, 301, 555], [1000, 100, 400, 224], [5, 5, 224, 224],
+             [100, 200, 768, 768], [0, 0, 150, 120]]
+    xyxy = [[int(x), int(y), int(x + w), int(y + h)] for x, y, w, h in boxes]
+    clip_gpu, owl_gpu = vsm.engine.preprocess_only(xyxy)
+    for i, b in enumerate(xyxy):
+        crop = img.crop(tuple(b))
+        ref_c = torch.from_numpy(pp.clip_preprocess(crop, vsm.cfg.clip_image_size)).bfloat16().float().numpy()
+        ref_o = torch.from_numpy(pp.owl_preprocess(crop, 768)).bfloat16().float().numpy()
+        assert np.array_equal(clip_gpu[i], ref_c), ("clip", i, np.abs(clip_gpu[i] - ref_c).max())
+        assert np.array_equal(owl_gpu[i], ref_o), ("owl", i, np.abs(owl_gpu[i] - ref_o).max())
+
+
+def test_search_with_gpu_preprocess_equals_host_preprocess(vsm):
+    img = synthetic_image(1280, 720, 33)
+    smallest = smallest_size_for(1280, 720)
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, b = {}, {}
+        r_host = visual_search(vsm, img, "kite", None, smallest, stats=a, gpu_preprocess=False, **kw)
+        r_gpu = visual_search(vsm, img, "kite", None, smallest, stats=b, gpu_preprocess=True, **kw)
+    assert r_host[1] == r_gpu[1] and r_host[0]["bbox"] == r_gpu[0]["bbox"]
+    assert torch.equal(r_host[0]["detection_result"], r_gpu[0]["detection_result"])
+    assert [p["bbox"] for p in a["search_path"]] == [p["bbox"] for p in b["search_path"]]
+    for pa, pb in zip(a["search_path"], b["search_path"]):
+        if "final_heatmap" in pa:
+            assert np.array_equal(pa["final_heatmap"], pb["final_heatmap"])

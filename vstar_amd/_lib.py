@@ -18,12 +18,12 @@ EXPORTS = [
     "vstar_create", "vstar_destroy", "vstar_last_error", "vstar_load_tensor", "vstar_finalize_weights",
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
-    "vstar_op_attention_workspace",
+    "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops",
 ]
 
 F32, F16, BF16 = 0, 1, 2
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
-F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC = 1, 2, 4, 8
+F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS = 1, 2, 4, 8, 16
 
 
 class VstarResult(ctypes.Structure):
@@ -68,6 +68,10 @@ def load() -> ctypes.CDLL:
     lib.vstar_vsm_score_batch.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_uint,
                                           c_void_p]
     lib.vstar_vsm_score_batch.restype = c_int
+    lib.vstar_image_set.argtypes = [H, c_void_p, c_int, c_int]
+    lib.vstar_image_set.restype = c_int
+    lib.vstar_preprocess_crops.argtypes = [H, c_int, c_void_p]
+    lib.vstar_preprocess_crops.restype = c_int
     lib.vstar_upsample_mask.argtypes = [H, c_void_p, c_int, c_int, c_void_p]
     lib.vstar_upsample_mask.restype = c_int
     lib.vstar_debug_read.argtypes = [H, c_char_p, c_void_p, c_int64]

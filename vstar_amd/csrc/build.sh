@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
 mkdir -p build
 pids=()
-for f in gemm gemm256 norm attention elementwise heads engine; do
+for f in gemm gemm256 norm attention elementwise heads preprocess engine; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ kernels.hpp -nt build/$f.o ] || [ gemm_epilogue.hpp -nt build/$f.o ] || [ ../../include/vstar_hip.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

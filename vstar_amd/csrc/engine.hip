@@ -96,6 +96,16 @@ struct vstar_engine {
   int32_t* d_tokidx = nullptr;
   vstar_result* d_results = nullptr;
   int last_B = 0, last_S = 0;
+  // GPU-side preprocessing state
+  uint8_t* d_image = nullptr; size_t image_cap = 0; int img_H = 0, img_W = 0;
+  uint8_t* d_temp = nullptr; size_t temp_cap = 0;
+  int32_t* d_tables = nullptr; size_t tables_cap = 0;
+  PreJob* d_jobs = nullptr;
+  bf16_t* d_lut = nullptr;
+  std::vector<int32_t> h_tables;
+  std::vector<PreJob> h_jobs;
+  struct AxisTab { int off_b, off_c, ks; };
+  int preprocess(int B, const int32_t* boxes);
   std::vector<int32_t> h_rowidx;
 
   // profiling
@@ -496,9 +506,81 @@ int vstar_engine::finalize() {
     for (int b = 0; b < maxB; ++b) tix[b] = b * 6 + 1;   // mask token 0 = token row 1 of each crop
     HIPCHK(hipMemcpy(d_tokidx, tix.data(), (size_t)maxB * 4, hipMemcpyHostToDevice));
   }
+  RC(dalloc(&d_jobs, (size_t)maxB * 2));
+  RC(dalloc(&d_lut, (size_t)3 * 256));
+  {
+    bf16_t lut[3 * 256];
+    clip_norm_lut(lut);
+    HIPCHK(hipMemcpy(d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+  }
   HIPCHK(hipDeviceSynchronize());
   staged.clear();
   finalized = true;
+  return 0;
+}
+
+// crop + pad + Pillow-exact resize + normalise for B boxes of the resident image -> d_clip_pix / d_owl_pix
+int vstar_engine::preprocess(int B, const int32_t* boxes) {
+  if (!finalized) { set_error("vstar_finalize_weights has not been called"); return VSTAR_ERR_STATE; }
+  if (!d_image) { set_error("no image resident: call vstar_image_set first"); return VSTAR_ERR_STATE; }
+  if (B <= 0 || B > cfg.max_batch || !boxes) { set_error("bad preprocess arguments"); return VSTAR_ERR_INVALID; }
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamSynchronize(stream));   // the staging vectors below are reused across calls
+  const int I = cfg.clip_image_size, O = cfg.owl_image_size;
+  h_tables.clear();
+  h_jobs.assign((size_t)B * 2, PreJob{});
+  std::map<std::pair<int, int>, AxisTab> cache;
+  auto axis = [&](int in_size, int out_size) -> AxisTab {
+    auto key = std::make_pair(in_size, out_size);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    std::vector<int32_t> bnd, cf;
+    int ks = 0;
+    pil_bicubic_coeffs(in_size, out_size, &bnd, &cf, &ks);
+    AxisTab t{(int)h_tables.size(), 0, ks};
+    h_tables.insert(h_tables.end(), bnd.begin(), bnd.end());
+    t.off_c = (int)h_tables.size();
+    h_tables.insert(h_tables.end(), cf.begin(), cf.end());
+    cache[key] = t;
+    return t;
+  };
+  size_t temp_bytes = 0;
+  int max_h_clip = 0, max_h_owl = 0;
+  for (int b = 0; b < B; ++b) {
+    const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
+    const int cw = x1 - x0, ch = y1 - y0;
+    if (x0 < 0 || y0 < 0 || cw <= 0 || ch <= 0 || x1 > img_W || y1 > img_H) { set_error("crop box outside the image"); return VSTAR_ERR_INVALID; }
+    const int side = cw > ch ? cw : ch;
+    for (int which = 0; which < 2; ++which) {
+      PreJob& j = h_jobs[(size_t)b * 2 + which];
+      j.x0 = x0; j.y0 = y0; j.cw = cw; j.ch = ch;
+      j.in_w = which == 0 ? side : cw;
+      j.in_h = which == 0 ? side : ch;
+      j.out = which == 0 ? I : O;
+      const AxisTab hx = axis(j.in_w, j.out), vy = axis(j.in_h, j.out);
+      j.hb_off = hx.off_b; j.hc_off = hx.off_c; j.hks = hx.ks;
+      j.vb_off = vy.off_b; j.vc_off = vy.off_c; j.vks = vy.ks;
+      j.temp_off = (int64_t)temp_bytes;
+      temp_bytes += ((size_t)j.in_h * j.out * 3 + 255) / 256 * 256;
+      j.out_off = (int64_t)b * 3 * j.out * j.out;
+      if (which == 0) max_h_clip = j.in_h > max_h_clip ? j.in_h : max_h_clip;
+      else max_h_owl = j.in_h > max_h_owl ? j.in_h : max_h_owl;
+    }
+  }
+  if (temp_bytes > temp_cap) {
+    if (d_temp) HIPCHK(hipFree(d_temp));
+    temp_cap = temp_bytes + temp_bytes / 4;
+    HIPCHK(hipMalloc((void**)&d_temp, temp_cap));
+  }
+  if (h_tables.size() > tables_cap) {
+    if (d_tables) HIPCHK(hipFree(d_tables));
+    tables_cap = h_tables.size() * 2;
+    HIPCHK(hipMalloc((void**)&d_tables, tables_cap * 4));
+  }
+  HIPCHK(hipMemcpyAsync(d_tables, h_tables.data(), h_tables.size() * 4, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_jobs, h_jobs.data(), h_jobs.size() * sizeof(PreJob), hipMemcpyHostToDevice, stream));
+  KCHK(preprocess_launch(d_image, img_W, d_jobs, d_tables, d_temp, d_lut, d_clip_pix, 0, B, I, max_h_clip, stream));
+  KCHK(preprocess_launch(d_image, img_W, d_jobs, d_tables, d_temp, d_lut, d_owl_pix, 1, B, O, max_h_owl, stream));
   return 0;
 }
 
@@ -531,9 +613,10 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
   if (B <= 0 || B > c.max_batch) { set_error("B out of range"); return VSTAR_ERR_INVALID; }
   if (L < 2 || L > c.max_text_len) { set_error("L out of range"); return VSTAR_ERR_INVALID; }
   if (n_verify < 0 || n_verify > VSTAR_MAX_VERIFY) { set_error("n_verify out of range"); return VSTAR_ERR_INVALID; }
-  if (!ids || !loc_pos || !clip_pix || (n_verify && !verify_pos)) { set_error("null input"); return VSTAR_ERR_INVALID; }
+  const bool internal_pix = flags & VSTAR_F_INTERNAL_PIXELS;
+  if (!ids || !loc_pos || (!clip_pix && !internal_pix) || (n_verify && !verify_pos)) { set_error("null input"); return VSTAR_ERR_INVALID; }
   const bool skip_owl = flags & VSTAR_F_SKIP_OWL;
-  if (!skip_owl && !owl_pix) { set_error("null owl_pix"); return VSTAR_ERR_INVALID; }
+  if (!skip_owl && !owl_pix && !internal_pix) { set_error("null owl_pix"); return VSTAR_ERR_INVALID; }
   HIPCHK(hipSetDevice(device));
   // exactly one IMAGE_TOKEN_INDEX (-200) per row, same column in every row
   int img_col = -1;
@@ -560,7 +643,10 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
   HIPCHK(hipMemcpyAsync(d_ids, ids, (size_t)B * L * 4, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
   const bf16_t *cpix = clip_pix, *opix = owl_pix;
-  if (!(flags & VSTAR_F_DEVICE_INPUTS)) {
+  if (internal_pix) {
+    cpix = d_clip_pix;   // filled by vstar_preprocess_crops on this stream
+    opix = d_owl_pix;
+  } else if (!(flags & VSTAR_F_DEVICE_INPUTS)) {
     const size_t cn = (size_t)B * 3 * c.clip_image_size * c.clip_image_size;
     HIPCHK(hipMemcpyAsync(d_clip_pix, clip_pix, cn * 2, hipMemcpyHostToDevice, stream));
     cpix = d_clip_pix;
@@ -728,6 +814,9 @@ void vstar_destroy(vstar_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) hipFree(p);
+  if (h->d_image) hipFree(h->d_image);
+  if (h->d_temp) hipFree(h->d_temp);
+  if (h->d_tables) hipFree(h->d_tables);
   for (auto e : h->ev) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
   delete h;
@@ -779,6 +868,28 @@ int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, cons
   return h->score(B, clip_pix, owl_pix, ids, L, loc_pos, verify_pos, n_verify, flags, out);
 }
 
+int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) {
+  if (!h || !rgb || height <= 0 || width <= 0) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
+  hipSetDevice(h->device);
+  const size_t bytes = (size_t)height * width * 3;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
+  if (bytes > h->image_cap) {
+    if (h->d_image) hipFree(h->d_image);
+    h->d_image = nullptr;
+    if (hipMalloc((void**)&h->d_image, bytes) != hipSuccess) { h->set_error("hipMalloc(image) failed"); return VSTAR_ERR_NOMEM; }
+    h->image_cap = bytes;
+  }
+  if (hipMemcpy(h->d_image, rgb, bytes, hipMemcpyHostToDevice) != hipSuccess) { h->set_error("image upload failed"); return VSTAR_ERR_HIP; }
+  h->img_H = height;
+  h->img_W = width;
+  return VSTAR_OK;
+}
+
+int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy) {
+  if (!h) { g_tls_error = "null handle"; return VSTAR_ERR_INVALID; }
+  return h->preprocess(B, boxes_xyxy);
+}
+
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out) {
   if (!h || !lowres || !out || h_out <= 0 || w_out <= 0) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
@@ -804,13 +915,17 @@ int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_o
 
 int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t cap) {
   if (!h || !name || !out) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
-  if (!h->finalized || h->last_B == 0) { h->set_error("no forward has run"); return VSTAR_ERR_STATE; }
+  if (!h->finalized) { h->set_error("weights not finalized"); return VSTAR_ERR_STATE; }
   hipSetDevice(h->device);
-  const int B = h->last_B;
+  const bool pix = !strcmp(name, "clip_pixels") || !strcmp(name, "owl_pixels");
+  if (!pix && h->last_B == 0) { h->set_error("no forward has run"); return VSTAR_ERR_STATE; }
+  const int B = pix ? (int)h->h_jobs.size() / 2 : h->last_B;
   const std::string n(name);
   const bf16_t* src = nullptr;
   int64_t cnt = 0;
-  if (n == "clip_features") { src = h->clip.x; cnt = (int64_t)B * h->clip.N * h->clip.hidden; }
+  if (n == "clip_pixels") { src = h->d_clip_pix; cnt = (int64_t)B * 3 * h->cfg.clip_image_size * h->cfg.clip_image_size; }
+  else if (n == "owl_pixels") { src = h->d_owl_pix; cnt = (int64_t)B * 3 * h->cfg.owl_image_size * h->cfg.owl_image_size; }
+  else if (n == "clip_features") { src = h->clip.x; cnt = (int64_t)B * h->clip.N * h->clip.hidden; }
   else if (n == "llm_input") { src = h->lx; cnt = 0; }
   else if (n == "llm_hidden_loc") { src = h->hsel; cnt = (int64_t)B * h->cfg.llm_hidden; }
   else if (n == "embed_det") { src = h->emb_det; cnt = (int64_t)B * h->det1.N; }

@@ -68,3 +68,20 @@ hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out
                       hipStream_t s);
 // bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0)
 hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s);
+
+// ---- GPU-side crop preprocessing (preprocess.hip) ----
+#include <vector>
+struct PreJob {            // one (crop, target) pair; jobs are stored as [crop][0 = CLIP, 1 = OWL-ViT]
+  int x0, y0, cw, ch;      // crop box inside the resident image
+  int in_w, in_h;          // resampled extent (CLIP: the padded square side; OWL: cw, ch)
+  int out;                 // output side (I or 768)
+  int hb_off, hc_off, hks; // horizontal bounds / coefficients offsets (int32 units) and kernel size
+  int vb_off, vc_off, vks;
+  int pad0;
+  int64_t temp_off;        // byte offset of this job's uint8 intermediate [in_h][out][3]
+  int64_t out_off;         // element offset into the bf16 pixel buffer [3][out][out]
+};
+void pil_bicubic_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize);
+void clip_norm_lut(bf16_t* lut);
+hipError_t preprocess_launch(const uint8_t* img, int W, const PreJob* jobs, const int32_t* tables, uint8_t* temp,
+                             const bf16_t* lut, bf16_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s);

@@ -110,6 +110,44 @@ class VstarEngine:
             return None
         return out if raw else self.unpack(out, nv)
 
+    # ---- GPU-side preprocessing ----
+    def set_image(self, image) -> None:
+        """Uploads the full RGB image (PIL.Image or uint8 [H,W,3]) once; crops are then just boxes."""
+        arr = np.ascontiguousarray(np.asarray(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8))
+        assert arr.ndim == 3 and arr.shape[2] == 3
+        self._image_hw = arr.shape[:2]
+        _lib.check(self.lib.vstar_image_set(self.handle, arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
+                   self.handle)
+
+    def score_boxes(self, boxes_xyxy, input_ids, loc_pos, verify_pos=None, raw: bool = False):
+        """Crop + pad + PIL-exact resize + normalise on the GPU for `boxes_xyxy` [B,4] (ints, as passed to image.crop),
+        then the same scoring pass as `score_batch`."""
+        boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
+        B = boxes.shape[0]
+        _lib.check(self.lib.vstar_preprocess_crops(self.handle, B, boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.int32))
+        loc = np.ascontiguousarray(np.asarray(loc_pos, dtype=np.int32))
+        nv, vptr = 0, None
+        if verify_pos is not None:
+            vp = np.ascontiguousarray(np.asarray(verify_pos, dtype=np.int32)).reshape(B, -1)
+            nv = vp.shape[1]
+            vptr = vp.ctypes.data_as(ctypes.c_void_p)
+        out = np.empty((B, _lib.RESULT_FLOATS), dtype=np.float32)
+        _lib.check(self.lib.vstar_vsm_score_batch(
+            self.handle, B, None, None, ids.ctypes.data_as(ctypes.c_void_p), ids.shape[1],
+            loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, _lib.F_INTERNAL_PIXELS, out.ctypes.data_as(ctypes.c_void_p)),
+            self.handle)
+        return out if raw else self.unpack(out, nv)
+
+    def preprocess_only(self, boxes_xyxy):
+        """(clip [B,3,I,I], owl [B,3,768,768]) float32 views of the device-side preprocessing result (tests)."""
+        boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
+        B = boxes.shape[0]
+        _lib.check(self.lib.vstar_preprocess_crops(self.handle, B, boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        I, O = self.cfg.clip_image_size, self.cfg.owl_image_size
+        return (self.debug_read("clip_pixels", B * 3 * I * I).reshape(B, 3, I, I),
+                self.debug_read("owl_pixels", B * 3 * O * O).reshape(B, 3, O, O))
+
     @staticmethod
     def unpack(rec: np.ndarray, n_verify: int = 0) -> Dict[str, np.ndarray]:
         B = rec.shape[0]

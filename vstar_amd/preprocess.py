@@ -50,7 +50,8 @@ def expand2square(img: Image.Image, color=None) -> Image.Image:
 
 
 def _normalise(arr_u8: np.ndarray) -> np.ndarray:
-    x = arr_u8.astype(np.float32) * np.float32(1.0 / 255.0)
+    # HF rescale multiplies in float64 and casts to float32, then normalises in float32 (image_transforms.rescale/normalize)
+    x = (arr_u8.astype(np.float64) * (1 / 255)).astype(np.float32)
     x = (x - np.asarray(CLIP_MEAN, np.float32)) / np.asarray(CLIP_STD, np.float32)
     return np.ascontiguousarray(x.transpose(2, 0, 1))
 

@@ -110,10 +110,15 @@ def _crop(image, bbox):
 class _NodeScorer:
     """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
 
-    def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool):
+    def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool,
+                 gpu_preprocess: bool = True):
         self.vsm, self.image, self.question = vsm, image, question
         self.smallest_size = smallest_size
         self.batched = hasattr(vsm, "inference_batch")
+        # device-side crop/resize when the VSM offers it: the full image is uploaded once, crops travel as boxes
+        self.on_device = gpu_preprocess and bool(getattr(vsm, "supports_gpu_preprocess", False))
+        if self.on_device:
+            vsm.set_image(image)
         world = vsm._dist()[0] if hasattr(vsm, "_dist") else 1    # one engine batch per rank and step
         self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) * world if self.batched else 1)
         self.speculate = speculate and self.batched and self.batch_size > 1
@@ -148,13 +153,18 @@ class _NodeScorer:
                                 break
                         nxt += self._children(b)
                     frontier = nxt
-            crops = [_crop(self.image, b) for b in todo]
-            if self.batched:
-                res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False)
+            if self.on_device:
+                res = self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False)
+                sizes = [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1])) for b in todo]
             else:
-                res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
-            for b, c, r in zip(todo, crops, res):
-                self.cache[tuple(b)] = [r, c.size, not self.batched]     # [result, (w, h), heatmap already full-res?]
+                crops = [_crop(self.image, b) for b in todo]
+                sizes = [c.size for c in crops]
+                if self.batched:
+                    res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False)
+                else:
+                    res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
+            for b, sz, r in zip(todo, sizes, res):
+                self.cache[tuple(b)] = [r, sz, not self.batched]     # [result, (w, h), heatmap already full-res?]
             self.n_scored += len(todo)
             self.n_batches += 1
         (boxes, scores, heat), (w, h), full = self.cache[key]
@@ -167,7 +177,8 @@ class _NodeScorer:
 def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high=0.5, confidence_low=0.3,
                   target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
                   visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
-                  noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None):
+                  noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
+                  gpu_preprocess: bool = True):
     """Same contract as the reference's visual_search (visual_search.py:484-516): returns
     (final_step, path_length, search_successful, all_valid_boxes)."""
     if visualize:
@@ -176,7 +187,7 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
     search_path = [init_patch]
     queue: PriorityQueue = PriorityQueue()
     question = LOCATE_QUESTION.format(target_object_name)
-    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate)
+    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate, gpu_preprocess)
 
     search_successful, all_valid_boxes = False, None
     current_patch = init_patch

@@ -162,13 +162,67 @@ class VSM:
                 scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
                 out.append((boxes, scores, heat))
         self.last_template_ok = np.concatenate(ok_all) if ok_all else np.zeros((0,), bool)
-        if not self.last_template_ok.all():
-            msg = (f"{int((~self.last_template_ok).sum())}/{len(images)} crops: greedy decoding would not emit "
+        self._check_template(len(images))
+        return out
+
+    # ---- GPU-side preprocessing path: the image lives in HBM, crops are boxes ----
+    @property
+    def supports_gpu_preprocess(self) -> bool:
+        return hasattr(self.engine, "score_boxes") and hasattr(self.engine, "set_image")
+
+    def set_image(self, image: Image.Image) -> None:
+        self._image = image
+        self.engine.set_image(image)
+
+    @torch.inference_mode()
+    def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question: str, mode: str = "detection",
+                        upsample: bool = True):
+        """Like inference_batch for crops `image.crop((int(x), int(y), int(x+w), int(y+h)))` of the image given to
+        set_image(), but crop / pad / resize / normalise run on the GPU (bit-identical to the PIL + HF-processor path)."""
+        assert mode in ("segmentation", "detection")
+        ids, loc_pos, ver_pos, ver_tok = self._ids(question)
+        nv = min(len(ver_pos), 8)
+        ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
+        xyxy = np.asarray([[int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])] for b in boxes_xywh], np.int32)
+        world, rank = self._dist()
+        n = len(xyxy)
+        mine = shard_indices(n, rank, world)
+        local = np.zeros((pad_count(n, world), RESULT_FLOATS), dtype=np.float32)
+        mb = self.cfg.max_batch
+        for s0 in range(0, len(mine), mb):
+            sel = mine[s0:s0 + mb]
+            B = len(sel)
+            t1 = time.perf_counter()
+            local[s0:s0 + B] = self.engine.score_boxes(
+                xyxy[sel], np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
+                verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True)
+            self.timers["engine_s"] += time.perf_counter() - t1
+            self.timers["crops"] += B
+        t2 = time.perf_counter()
+        records = self._allgather(local, n) if world > 1 else local[:n]
+        self.timers["gather_s"] += time.perf_counter() - t2
+        res = self.engine.unpack(records, nv)
+        self.last_template_ok = (res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)
+        self._check_template(n)
+        out: List = []
+        for b in range(n):
+            w, h = int(xyxy[b, 2] - xyxy[b, 0]), int(xyxy[b, 3] - xyxy[b, 1])
+            low = res["low_res_masks"][b, 0]
+            heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
+            if mode == "segmentation":
+                out.append(heat)
+            else:
+                out.append((torch.from_numpy(res["pred_boxes"][b].copy()),
+                            torch.from_numpy(res["pred_logits"][b].copy()).sigmoid(), heat))
+        return out
+
+    def _check_template(self, n: int) -> None:
+        if self.last_template_ok is not None and not self.last_template_ok.all():
+            msg = (f"{int((~self.last_template_ok).sum())}/{n} crops: greedy decoding would not emit "
                    f"'{ANSWER_TEMPLATE}' (teacher-forced argmax check failed)")
             if self.strict_template:
                 raise TemplateMismatch(msg)
             warnings.warn(msg + " — tolerated because strict_template=False (synthetic weights)")
-        return out
 
     @torch.inference_mode()
     def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100) -> List[int]:
