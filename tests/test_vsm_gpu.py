@@ -118,7 +118,7 @@ def test_gpu_preprocess_is_bit_identical_to_pil_hf_path(vsm):
     img = Image.fromarray(arr)
     vsm.set_image(img)
     boxes = [[0, 0, 1400, 900], [700, 450, 700, 450], [13, 27, 301, 555], [1000, 100, 400, 224], [5, 5, 224, 224],
-             [100, 200, 768, 768], [0, 0, 150, 120]]
+             [100, 100, 768, 768], [0, 0, 150, 120]]
     xyxy = [[int(x), int(y), int(x + w), int(y + h)] for x, y, w, h in boxes]
     clip_gpu, owl_gpu = vsm.engine.preprocess_only(xyxy)
     for i, b in enumerate(xyxy):
