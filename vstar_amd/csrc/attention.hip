@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
           sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
         }
         // ---- online softmax (this lane: query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2) ----
+        // The running reference max m is only raised when some row's tile max exceeds it by more than RESCALE_THR
+        // (log2 units): exp2(s - m) then stays <= 2^THR, harmless for the fp32 row sum and for bf16 P (relative
+        // precision), and the O/l rescale (the widest VALU block) becomes rare instead of per-tile.
+        constexpr float RESCALE_THR = 6.0f;
         float p[16];
         float mx = -1e30f;
         const bool need_mask = (kt0 + 32 > S) || (CAUSAL && kt0 + 31 > q0);
@@ -305,32 +309,30 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
             const bool masked = (key >= S) || (CAUSAL && key > query);
-            p[r] = masked ? -1e30f : sacc[r] * scale_log2e;
-            mx = fmaxf(mx, p[r]);
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            p[r] = sacc[r] * scale_log2e;
-            mx = fmaxf(mx, p[r]);
+            sacc[r] = masked ? -1e30f : sacc[r];
           }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f(m - m_new);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;       // scale > 0: max commutes with the scaling
+        if (__any(mx > m + RESCALE_THR)) {                            // wave-uniform
+          const float m_new = fmaxf(m, mx);
+          const float alpha = exp2f(m - m_new);
+          l *= alpha;
+          m = m_new;
+#pragma unroll
+          for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = exp2f(p[r] - m_new);
+          p[r] = exp2f(fmaf(sacc[r], scale_log2e, -m));               // masked: exp2(-1e30*c - m) = 0
           rs += p[r];
         }
         rs += __shfl_xor(rs, 32, 64);
-        l = l * alpha + rs;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        l += rs;
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -440,6 +442,76 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restric
   }
 }
 
+// few-keys variant (image -> token cross attention of the SAM head: 2304 queries x 6 keys): one THREAD per (b, head, query)
+template <int D, int MAXK>
+__global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+                                                                 int B, int Nq, int Nk, int H, float scale) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * Nq) return;
+  const int h = (int)(idx % H);                      // heads fastest: neighbouring threads read neighbouring 32-byte slices
+  const int qi = (int)((idx / H) % Nq);
+  const int b = (int)(idx / ((int64_t)H * Nq));
+  const int C = H * D;
+  const bf16_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
+  float qv[D];
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    const bf16x8 t = *(const bf16x8*)(qp + d0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[d0 + e] = bf2f((bf16_t)t[e]);
+  }
+  float sc[MAXK];
+  float mx = -1e30f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = -1e30f;
+    if (j < Nk) {
+      const bf16_t* kp = k + ((int64_t)b * Nk + j) * C + h * D;
+      float a = 0.f;
+#pragma unroll
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        const bf16x8 t = *(const bf16x8*)(kp + d0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += qv[d0 + e] * bf2f((bf16_t)t[e]);
+      }
+      sc[j] = rbf(rbf(a) * scale);
+      mx = fmaxf(mx, sc[j]);
+    }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    sc[j] = j < Nk ? __expf(sc[j] - mx) : 0.f;
+    sum += sc[j];
+  }
+  const float inv = 1.0f / sum;
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXK; ++j) {
+    if (j < Nk) {
+      const float pr = rbf(sc[j] * inv);
+      const bf16_t* vp = v + ((int64_t)b * Nk + j) * C + h * D;
+#pragma unroll
+      for (int d0 = 0; d0 < D; d0 += 8) {
+        const bf16x8 t = *(const bf16x8*)(vp + d0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[d0 + e] += pr * bf2f((bf16_t)t[e]);
+      }
+    }
+  }
+  bf16_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
+#pragma unroll
+  for (int d0 = 0; d0 < D; d0 += 8) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(o[d0 + e]);
+    *(bf16x8*)(op + d0) = t;
+  }
+}
+
 }  // namespace
 
 hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, int S, int Spad, int H, int D, hipStream_t s) {
@@ -499,6 +571,13 @@ hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf
   const int64_t waves = (int64_t)B * H * Nq;
   dim3 grid((unsigned)((waves + 3) / 4));
   const float scale = 1.0f / sqrtf((float)D);
+  if (Nk <= 8 && (D == 16 || D == 32)) {
+    const int64_t threads = (int64_t)B * H * Nq;
+    dim3 g((unsigned)((threads + 255) / 256));
+    if (D == 16) hipLaunchKernelGGL((small_attn_fewkeys_kernel<16, 8>), g, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
+    else hipLaunchKernelGGL((small_attn_fewkeys_kernel<32, 8>), g, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
+    return hipGetLastError();
+  }
   if (D == 32) hipLaunchKernelGGL(small_attn_kernel<32>, grid, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
   else if (D == 16) hipLaunchKernelGGL(small_attn_kernel<16>, grid, dim3(256), 0, s, q, k, v, out, B, Nq, Nk, H, scale);
   else return hipErrorInvalidValue;
