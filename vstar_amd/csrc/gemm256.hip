@@ -1,4 +1,4 @@
-// gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each = 4x2 fragments of v_mfma_f32_32x32x16_bf16),
+// gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
 // 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 5 quarter-tiles ahead behind COUNTED vmcnt waits, and two
 // wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA cluster while its partner issues
 // ds_reads / DMA ("8-phase" structure of the CDNA4 guide, §5 "256^2 8-phase template", re-derived for this layout).
@@ -115,26 +115,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       __builtin_amdgcn_global_load_lds((gptr_t)(gb + src_off[J][u]), (lptr_t)(base + lds_off[J][u]), 16, 0, 0);
   };
 
-  // ---- fragment read offsets: v_mfma_f32_32x32x16_bf16 operands = lane (row = lane&31, k-chunk = 2*ks + (lane>>5)) of a
-  // row-major 128-B-row tile with the (row>>1)&7 chunk swizzle (conflict-free for the b128 lane groups) ----
+  // ---- fragment read offsets (same row-major + (row>>1)&7 chunk swizzle as gemm.hip) ----
   const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 31, h2 = lane >> 5;
+  const int fr = lane & 15, fq = lane >> 4;
   const int swz = (fr >> 1) & 7;
-  int a_rd[4], w_rd[4];
+  int a_rd[2], w_rd[2];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    const int ch = ((ks * 2 + h2) ^ swz) * 16;
-    a_rd[ks] = (wr * 128 + fr) * 128 + ch;
-    w_rd[ks] = A_BYTES + (wc * 64 + fr) * 128 + ch;
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ch = ((kk * 4 + fq) ^ swz) * 16;
+    a_rd[kk] = (wr * 128 + fr) * 128 + ch;
+    w_rd[kk] = A_BYTES + (wc * 64 + fr) * 128 + ch;
   }
 
-  f32x16 acc[4][2];   // [m-fragment 0..3][n-fragment 0..1] of 32x32
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < 8; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- prologue: pieces 0..D-1 in flight, pieces 0,1 landed, everyone past the barrier; group 1 one barrier behind ----
   BAR();   // every wave has finished reading its epilogue slab of the previous tile: the ring may be overwritten
@@ -148,7 +145,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   BAR();
   if (group == 1) BAR();
 
-  bf16x8 af[8], w0f[4], w1f[4];   // af[ks*2 + m], w?f[ks]
+  bf16x8 af[8], w0f[4], w1f[4];
   const int nkt = p.K / BK;
   for (int T = 0; T < nkt; ++T) {
     const char* base = smem + (T & 1) * TILE_BYTES;
@@ -167,32 +164,37 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #define MFMA_QUAD(mh, WF, nh)                                                            \
   {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                       \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                     \
-      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                      \
-        acc[(mh) * 2 + m][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                 \
-            WF[ks], af[ks * 2 + m], acc[(mh) * 2 + m][nh], 0, 0, 0);                     \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m)                                      \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                    \
+          acc[(mh) * 4 + m][(nh) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(     \
+              WF[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nh) * 2 + n], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                       \
     BAR();                                                                               \
   }
-    // phase 0: A[m-half 0] (2 fragments x 4 k-steps) + W[n-half 0] (1 fragment x 4 k-steps)
+    // phase 0: A[m-half 0] + W[n-half 0]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) w0f[ks] = *(const bf16x8*)(base + w_rd[ks]);
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+      for (int n = 0; n < 2; ++n) w0f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[ks * 2 + m] = *(const bf16x8*)(base + a_rd[ks] + m * 4096);
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
     PHASE_TAIL(0)
     MFMA_QUAD(0, w0f, 0)
     // phase 1: W[n-half 1]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) w1f[ks] = *(const bf16x8*)(base + w_rd[ks] + 4096);
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) w1f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + (2 + n) * 2048);
     PHASE_TAIL(1)
     MFMA_QUAD(0, w1f, 1)
     // phase 2: A[m-half 1]
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) af[ks * 2 + m] = *(const bf16x8*)(base + a_rd[ks] + (2 + m) * 4096);
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + (4 + m) * 2048);
     PHASE_TAIL(2)
     MFMA_QUAD(1, w1f, 1)
     // phase 3: no reads
@@ -206,78 +208,67 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // ---- epilogue ----
   if (p.debug_flags & 2) continue;
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
-  // accumulator layout of a 32x32 fragment (operands swapped): this lane owns output row (lane&31) of the m-fragment and,
-  // for register group g = r>>2, the 4 consecutive columns 8g + 4*(lane>>5) + (r&3) of the n-fragment.
   if constexpr (OUT_F32) {
     // fp32 outputs (lm_head / head taps): direct accumulator-layout stores
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = m0 + wr * 128 + m * 32 + fr;
+    for (int m = 0; m < 8; ++m) {
+      const int row = m0 + wr * 128 + m * 16 + fr;
       if (row >= p.M) continue;
       const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
+      if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        if (EPI == VSTAR_EPI_SILU_MUL) {
+        for (int j = 0; j < 2; ++j)
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
+      } else {
 #pragma unroll
-          for (int gq = 0; gq < 2; ++gq) {   // gate group gq pairs with up group gq + 2 (rows i and i + 16 of the packed W)
-            const f32x4 ga = {acc[m][n][4 * gq], acc[m][n][4 * gq + 1], acc[m][n][4 * gq + 2], acc[m][n][4 * gq + 3]};
-            const f32x4 ua = {acc[m][n][4 * gq + 8], acc[m][n][4 * gq + 9], acc[m][n][4 * gq + 10], acc[m][n][4 * gq + 11]};
-            gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + n * 16 + 8 * gq + 4 * h2, n_out, ga, ua);
-          }
-        } else {
-#pragma unroll
-          for (int gq = 0; gq < 4; ++gq) {
-            const f32x4 va = {acc[m][n][4 * gq], acc[m][n][4 * gq + 1], acc[m][n][4 * gq + 2], acc[m][n][4 * gq + 3]};
-            gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 32 + 8 * gq + 4 * h2, n_out, va, va);
-          }
-        }
+        for (int n = 0; n < 4; ++n)
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
       }
     }
   } else {
     // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab (the ring is
     // dead: every wave is past the last barrier and every DMA has landed), then activation / residual and whole-line
     // 16-B stores from a ROLLED loop (keeps the epilogue's code footprint small: it runs once per tile and an
-    // unrolled epilogue with tail paths was ~10k instructions of cold i-cache).
+    // unrolled 32-fragment epilogue with tail paths was ~10k instructions of cold i-cache).
     constexpr int WCOLS = (EPI == VSTAR_EPI_SILU_MUL) ? 32 : 64;     // output columns owned by this wave
+    constexpr int NF = WCOLS / 16;                                    // 16-column fragments
     constexpr int RSTRIDE = WCOLS * 2 + 16;                           // padded LDS row (bytes)
     constexpr int CH = WCOLS / 8;                                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                                      // rows per wave-wide 16-B access
     char* slab = smem + wave * (64 * (128 + 16));
     const int colbase = (EPI == VSTAR_EPI_SILU_MUL) ? (n0 + wc * 64) / 2 : n0 + wc * 64;
+    // bias for this lane's 4-column groups (clamped: columns >= n_out are computed but never stored)
+    float bias_v[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      int bc = colbase + f * 16 + fq * 4;
+      bc = bc + 4 <= n_out ? bc : (n_out - 4 > 0 ? n_out - 4 : 0);
+      if (EPI != VSTAR_EPI_SILU_MUL && p.bias) {
+        const bf16x4 b = *(const bf16x4*)(p.bias + bc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_v[f][e] = bf2f((bf16_t)b[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias_v[f][e] = 0.f;
+      }
+    }
     const int rl0 = lane / CH, ch = lane % CH;
     auto half_pass = [&](auto mhc) {
       constexpr int mh = decltype(mhc)::value;
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-          const f32x16& a = acc[mh * 2 + m][n];
+        for (int f = 0; f < NF; ++f) {
+          bf16x4 v;
           if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
-            for (int gq = 0; gq < 2; ++gq) {
-              bf16x4 v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (short)f2bf(act_silu_bf16(rbf(a[4 * gq + e])) * rbf(a[4 * gq + 8 + e]));
-              *(bf16x4*)(slab + (m * 32 + fr) * RSTRIDE + (n * 16 + 8 * gq + 4 * h2) * 2) = v;
-            }
+            for (int e = 0; e < 4; ++e)
+              v[e] = (short)f2bf(act_silu_bf16(rbf(acc[mh * 4 + m][2 * f][e])) * rbf(acc[mh * 4 + m][2 * f + 1][e]));
           } else {   // stage 1 = bf16(acc + bias); the activation is applied after the transpose
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-              const int wcol = n * 32 + 8 * gq + 4 * h2;
-              float bv[4] = {0.f, 0.f, 0.f, 0.f};
-              if (p.bias) {
-                int bc = colbase + wcol;
-                bc = bc + 4 <= n_out ? bc : (n_out - 4 > 0 ? n_out - 4 : 0);   // clamped: columns >= n_out are never stored
-                const bf16x4 b = *(const bf16x4*)(p.bias + bc);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[e] = bf2f((bf16_t)b[e]);
-              }
-              bf16x4 v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = (short)f2bf(a[4 * gq + e] + bv[e]);
-              *(bf16x4*)(slab + (m * 32 + fr) * RSTRIDE + wcol * 2) = v;
-            }
+            for (int e = 0; e < 4; ++e) v[e] = (short)f2bf(acc[mh * 4 + m][f][e] + bias_v[f][e]);
           }
+          *(bf16x4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
