@@ -144,6 +144,13 @@ int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy);
  * Replaces F.interpolate(...) + torch.clamp (VSM.py:534-537, visual_search.py:223-224). Host in, host out. */
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out);
 
+/* Decision statistics of a heat map without materialising it: with H = clamp(bilinear(lowres 192x192 ->
+ * h_out x w_out, align_corners=False), 0) writes out[0] = min H, out[1] = max H, out[2] = sum H, out[3+k] = sum of H over
+ * rectangle k (x, y, w, h in output pixels; n_rects <= 8).  fp64 accumulation.  These are the quantities
+ * visual_search.py:420-426 (max, min-max normalisation) and :255-266 (get_subpatch_scores) consume. Host in, host out. */
+int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_out, int n_rects, const int32_t* rects_xywh,
+                        double* out);
+
 /* Debug/parity taps: copy an internal activation of the LAST score_batch call to host as fp32.
  * name in {"clip_features","projector","llm_hidden_loc","embed_det","embed_seg","owl_feats"}.
  * Returns the number of floats written (<= cap) or a negative error. */

@@ -41,6 +41,14 @@ class BatchedFake(FakeVSM):
     def upsample_heatmap(self, low, h, w):
         return torch.clamp(F.interpolate(low[None, None], (h, w), mode="bilinear", align_corners=False)[0, 0], min=0)
 
+    def heatmap_stats(self, low, h, w, rects=None):
+        """What vstar_heatmap_stats returns, computed in float64 from the same up-sampled map."""
+        H = self.upsample_heatmap(low, h, w).double().numpy()
+        out = [H.min(), H.max(), H.sum()]
+        for x, y, rw, rh in (rects or []):
+            out.append(H[y:y + rh, x:x + rw].sum())
+        return np.asarray(out, np.float64)
+
 
 def _check(res, gold):
     final_step, path_length, ok, all_valid = res
@@ -76,6 +84,28 @@ def test_batched_speculative_matches_reference(gold, max_batch):
     assert stats["engine_batches"] <= gold["calls"]
     if gold["calls"] >= 21 and max_batch == 32:
         assert stats["engine_batches"] <= (gold["calls"] + 15) // 16
+
+
+@pytest.mark.parametrize("gold", GOLD, ids=[f"{g['case'][0]}x{g['case'][1]}s{g['case'][2]}" for g in GOLD])
+def test_device_reductions_path_matches_reference(gold):
+    """The algebraic form of the decision math used with on-device heat-map statistics (min-max normalisation folded into
+    rectangle sums, fp64) takes the same decisions as the reference's float32 numpy reductions."""
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    vsm = BatchedFake(32, seed=vseed, conf_shift=shift)
+    _check(search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"], device_reductions=True), gold)
+
+
+def test_device_reductions_child_scores_close_to_numpy_path():
+    img = synthetic_image(1920, 1080, 1)
+    a, b = {}, {}
+    kw = dict(confidence_high=2.0)
+    search.visual_search(BatchedFake(32, seed=1, conf_shift=-6.0), img, "o", None, 270, stats=a, **kw)
+    search.visual_search(BatchedFake(32, seed=1, conf_shift=-6.0), img, "o", None, 270, stats=b, device_reductions=True, **kw)
+    sa = [float(p["score"]) for p in a["search_path"][1:]]
+    sb = [float(p["score"]) for p in b["search_path"][1:]]
+    assert len(sa) == len(sb) == 20
+    assert np.allclose(sa, sb, rtol=1e-5, atol=1e-7)
 
 
 def test_helpers_match_reference_semantics():

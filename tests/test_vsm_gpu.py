@@ -144,3 +144,33 @@ def test_search_with_gpu_preprocess_equals_host_preprocess(vsm):
     for pa, pb in zip(a["search_path"], b["search_path"]):
         if "final_heatmap" in pa:
             assert np.array_equal(pa["final_heatmap"], pb["final_heatmap"])
+
+
+def test_heatmap_stats_kernel_matches_host_reductions(vsm):
+    g = torch.Generator().manual_seed(3)
+    low = (torch.randn(192, 192, generator=g) * 4).numpy()
+    for (h, w) in [(540, 960), (2160, 3840), (224, 301)]:
+        rects = [[0, 0, w // 2, h // 2], [w // 2, 0, w - w // 2, h // 2], [0, h // 2, w // 2, h - h // 2], [w // 3, h // 5, 17, 9]]
+        st = vsm.heatmap_stats(low, h, w, rects)
+        H = vsm.upsample_heatmap(low, h, w).double().numpy()
+        assert st[0] == H.min() and st[1] == H.max()                  # exact: same interpolation code on the GPU
+        assert abs(st[2] - H.sum()) <= 1e-9 * H.sum()
+        for k, (x, y, rw, rh) in enumerate(rects):
+            assert abs(st[3 + k] - H[y:y + rh, x:x + rw].sum()) <= 1e-9 * max(H.sum(), 1.0)
+
+
+def test_search_with_device_reductions_equals_host_path(vsm):
+    img = synthetic_image(1280, 720, 33)
+    smallest = smallest_size_for(1280, 720)
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a, b = {}, {}
+        r_host = visual_search(vsm, img, "kite", None, smallest, stats=a, **kw)
+        r_dev = visual_search(vsm, img, "kite", None, smallest, stats=b, device_reductions=True, **kw)
+    assert r_host[1] == r_dev[1] and r_host[0]["bbox"] == r_dev[0]["bbox"]
+    assert torch.equal(r_host[0]["detection_result"], r_dev[0]["detection_result"])
+    assert [p["bbox"] for p in a["search_path"]] == [p["bbox"] for p in b["search_path"]]
+    sa = [float(p["score"]) for p in a["search_path"][1:]]
+    sb = [float(p["score"]) for p in b["search_path"][1:]]
+    assert np.allclose(sa, sb, rtol=1e-5, atol=1e-7)

@@ -24,6 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--targets", type=int, default=4)
 ap.add_argument("--image-size", type=int, default=336)
 ap.add_argument("--tiny", action="store_true")
+ap.add_argument("--device-reductions", action="store_true")
+ap.add_argument("--host-preprocess", action="store_true")
 args = ap.parse_args()
 cfg = (VSMConfig.tiny if args.tiny else VSMConfig.seal_7b)(clip_image_size=args.image_size, max_batch=32, max_text_len=128) \
     if args.tiny else VSMConfig.seal_7b(args.image_size, max_batch=32, max_text_len=128)
@@ -32,7 +34,8 @@ with warnings.catch_warnings():
     vsm = VSM(None, cfg=cfg, tokenizer=SyntheticTokenizer(cfg.llm_vocab), synthetic_seed=0, strict_template=False)
     img = synthetic_image(3840, 2160, 0)
     smallest = smallest_size_for(3840, 2160)
-    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0,
+              device_reductions=args.device_reductions, gpu_preprocess=not args.host_preprocess)
     visual_search(vsm, img, "warmup", None, smallest, **kw)
     for k in vsm.timers:
         vsm.timers[k] = 0
@@ -44,6 +47,7 @@ with warnings.catch_warnings():
         for k in tot:
             tot[k] += st[k]
     dt = time.perf_counter() - t0
-print(json.dumps({"search_crops_per_s": round(tot["crops_scored"] / dt, 2), "wall_s": round(dt, 3), **tot,
+print(json.dumps({"mode": {"gpu_preprocess": not args.host_preprocess, "device_reductions": args.device_reductions},
+                  "search_crops_per_s": round(tot["crops_scored"] / dt, 2), "wall_s": round(dt, 3), **tot,
                   "timers": {k: round(v, 3) if isinstance(v, float) else v for k, v in vsm.timers.items()},
                   "decision_and_other_s": round(dt - sum(v for k, v in vsm.timers.items() if k.endswith("_s")), 3)}))

@@ -96,6 +96,7 @@ struct vstar_engine {
   int32_t* d_tokidx = nullptr;
   vstar_result* d_results = nullptr;
   int last_B = 0, last_S = 0;
+  void* d_stats = nullptr;
   // GPU-side preprocessing state
   uint8_t* d_image = nullptr; size_t image_cap = 0; int img_H = 0, img_W = 0;
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
@@ -814,6 +815,7 @@ void vstar_destroy(vstar_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) hipFree(p);
+  if (h->d_stats) hipFree(h->d_stats);
   if (h->d_image) hipFree(h->d_image);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
@@ -874,7 +876,8 @@ int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) 
   const size_t bytes = (size_t)height * width * 3;
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
   if (bytes > h->image_cap) {
-    if (h->d_image) hipFree(h->d_image);
+    if (h->d_stats) hipFree(h->d_stats);
+  if (h->d_image) hipFree(h->d_image);
     h->d_image = nullptr;
     if (hipMalloc((void**)&h->d_image, bytes) != hipSuccess) { h->set_error("hipMalloc(image) failed"); return VSTAR_ERR_NOMEM; }
     h->image_cap = bytes;
@@ -888,6 +891,27 @@ int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) 
 int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy) {
   if (!h) { g_tls_error = "null handle"; return VSTAR_ERR_INVALID; }
   return h->preprocess(B, boxes_xyxy);
+}
+
+int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_out, int n_rects, const int32_t* rects_xywh,
+                        double* out) {
+  if (!h || !lowres || !out || h_out <= 0 || w_out <= 0 || n_rects < 0 || n_rects > 8 || (n_rects && !rects_xywh)) {
+    g_tls_error = "bad argument";
+    return VSTAR_ERR_INVALID;
+  }
+  hipSetDevice(h->device);
+  struct Scratch { float low[VSTAR_MASK_RES * VSTAR_MASK_RES]; double out[3 + 8]; int rects[32]; unsigned mm[2]; };
+  if (!h->d_stats) {
+    if (hipMalloc(&h->d_stats, sizeof(Scratch)) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats"); return VSTAR_ERR_NOMEM; }
+  }
+  Scratch* sc = (Scratch*)h->d_stats;
+  bool ok = hipMemcpyAsync(sc->low, lowres, sizeof(sc->low), hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  if (ok && n_rects) ok = hipMemcpyAsync(sc->rects, rects_xywh, (size_t)n_rects * 16, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  ok = ok && heat_stats(sc->low, VSTAR_MASK_RES, VSTAR_MASK_RES, h_out, w_out, sc->rects, n_rects, sc->out, sc->mm, h->stream) == hipSuccess;
+  ok = ok && hipMemcpyAsync(out, sc->out, sizeof(double) * (3 + n_rects), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+  ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+  if (!ok) { h->set_error("vstar_heatmap_stats: HIP failure"); return VSTAR_ERR_HIP; }
+  return VSTAR_OK;
 }
 
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out) {

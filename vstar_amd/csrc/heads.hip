@@ -129,9 +129,81 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, int hin, in
   out[idx] = fmaxf(t, 0.f);
 }
 
+// Decision statistics of one heat map WITHOUT materialising it (visual_search.py:255-275,420-426):
+// H = clamp(bilinear(low_res -> hout x wout), 0); out = {min H, max H, sum H, sum H over each of n_rects rectangles}.
+// Same interpolation code as resize_bilinear_kernel; fp64 accumulation.
+constexpr int MAX_RECTS = 8;
+__global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict__ in, int hin, int win, int hout, int wout,
+                                                         float rh, float rw, const int* __restrict__ rects, int n_rects,
+                                                         double* __restrict__ out /*[3 + MAX_RECTS]*/, unsigned* __restrict__ mm) {
+  const int64_t total = (int64_t)hout * wout;
+  float mn = INFINITY, mx = 0.f;
+  double sum = 0.0, rs[MAX_RECTS];
+#pragma unroll
+  for (int k = 0; k < MAX_RECTS; ++k) rs[k] = 0.0;
+  int rx[MAX_RECTS], ry[MAX_RECTS], rx1[MAX_RECTS], ry1[MAX_RECTS];
+#pragma unroll
+  for (int k = 0; k < MAX_RECTS; ++k) {
+    const bool on = k < n_rects;
+    rx[k] = on ? rects[k * 4] : 0; ry[k] = on ? rects[k * 4 + 1] : 0;
+    rx1[k] = on ? rx[k] + rects[k * 4 + 2] : 0; ry1[k] = on ? ry[k] + rects[k * 4 + 3] : 0;
+  }
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % wout), y = (int)(idx / wout);
+    const float sy = fmaxf(rh * (y + 0.5f) - 0.5f, 0.f), sx = fmaxf(rw * (x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < hin - 1 ? 1 : 0), x1 = x0 + (x0 < win - 1 ? 1 : 0);
+    const float ly = sy - y0, lx = sx - x0;
+    const float t = (1.f - ly) * ((1.f - lx) * in[y0 * win + x0] + lx * in[y0 * win + x1]) +
+                    ly * ((1.f - lx) * in[y1 * win + x0] + lx * in[y1 * win + x1]);
+    const float hv = fmaxf(t, 0.f);
+    mn = fminf(mn, hv);
+    mx = fmaxf(mx, hv);
+    sum += hv;
+#pragma unroll
+    for (int k = 0; k < MAX_RECTS; ++k)
+      if (x >= rx[k] && x < rx1[k] && y >= ry[k] && y < ry1[k]) rs[k] += hv;
+  }
+  // wave reduce, then one atomic per wave
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+    for (int k = 0; k < MAX_RECTS; ++k) rs[k] += __shfl_xor(rs[k], o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMin(&mm[0], __float_as_uint(mn));     // H >= 0: uint order == float order
+    atomicMax(&mm[1], __float_as_uint(mx));
+    atomicAdd(&out[2], sum);
+    for (int k = 0; k < n_rects; ++k) atomicAdd(&out[3 + k], rs[k]);
+  }
+}
+__global__ void heat_stats_finish(double* out, const unsigned* mm) {
+  out[0] = (double)__uint_as_float(mm[0]);
+  out[1] = (double)__uint_as_float(mm[1]);
+}
+
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
+
+hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,
+                      unsigned* mm_scratch, hipStream_t s) {
+  if (n_rects < 0 || n_rects > MAX_RECTS) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * (3 + MAX_RECTS), s);
+  if (e != hipSuccess) return e;
+  static const unsigned init[2] = {0x7f800000u, 0u};
+  e = hipMemcpyAsync(mm_scratch, init, sizeof(init), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  const int64_t total = (int64_t)hout * wout;
+  unsigned blocks = (unsigned)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(heat_stats_kernel, dim3(blocks), dim3(256), 0, s, lowres, hin, win, hout, wout, (float)hin / (float)hout,
+                     (float)win / (float)wout, rects, n_rects, out, mm_scratch);
+  hipLaunchKernelGGL(heat_stats_finish, dim3(1), dim3(1), 0, s, out, mm_scratch);
+  return hipGetLastError();
+}
 
 hipError_t owl_class_logits(const float* emb, int ld, int Q, const bf16_t* query, float* out, int out_stride_crop, int B,
                             int rows_per_crop, hipStream_t s) {

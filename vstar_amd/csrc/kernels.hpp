@@ -69,6 +69,10 @@ hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out
 // bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0)
 hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s);
 
+// min / max / total / rectangle sums of clamp(bilinear(lowres -> hout x wout), 0); out = double[3 + 8], mm_scratch = unsigned[2]
+hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,
+                      unsigned* mm_scratch, hipStream_t s);
+
 // ---- GPU-side crop preprocessing (preprocess.hip) ----
 #include <vector>
 struct PreJob {            // one (crop, target) pair; jobs are stored as [crop][0 = CLIP, 1 = OWL-ViT]

@@ -167,6 +167,16 @@ class VstarEngine:
                                                 out.ctypes.data_as(ctypes.c_void_p)), self.handle)
         return out
 
+    def heatmap_stats(self, low_res: np.ndarray, h: int, w: int, rects_xywh=None) -> np.ndarray:
+        """[min, max, sum, sum over each rect] of clamp(bilinear(low_res -> h x w), 0), computed on the GPU in fp64."""
+        src = np.ascontiguousarray(low_res, dtype=np.float32).reshape(MASK_RES, MASK_RES)
+        rects = np.zeros((0, 4), np.int32) if rects_xywh is None else np.ascontiguousarray(np.asarray(rects_xywh, np.int32)).reshape(-1, 4)
+        out = np.zeros((3 + len(rects),), dtype=np.float64)
+        _lib.check(self.lib.vstar_heatmap_stats(self.handle, src.ctypes.data_as(ctypes.c_void_p), h, w, len(rects),
+                                                rects.ctypes.data_as(ctypes.c_void_p) if len(rects) else None,
+                                                out.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        return out
+
     def debug_read(self, name: str, count: int) -> np.ndarray:
         out = np.empty((count,), dtype=np.float32)
         n = self.lib.vstar_debug_read(self.handle, name.encode(), out.ctypes.data_as(ctypes.c_void_p), count)

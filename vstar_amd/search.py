@@ -111,8 +111,9 @@ class _NodeScorer:
     """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
 
     def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool,
-                 gpu_preprocess: bool = True):
+                 gpu_preprocess: bool = True, device_reductions: bool = False):
         self.vsm, self.image, self.question = vsm, image, question
+        self.device_reductions = device_reductions and hasattr(vsm, "heatmap_stats") and hasattr(vsm, "inference_batch")
         self.smallest_size = smallest_size
         self.batched = hasattr(vsm, "inference_batch")
         # device-side crop/resize when the VSM offers it: the full image is uploaded once, crops travel as boxes
@@ -168,6 +169,8 @@ class _NodeScorer:
             self.n_scored += len(todo)
             self.n_batches += 1
         (boxes, scores, heat), (w, h), full = self.cache[key]
+        if not full and self.device_reductions:
+            return boxes, scores, heat                          # 192x192 low-res logits; statistics are taken on the GPU
         if not full:
             heat = self.vsm.upsample_heatmap(heat, h, w)        # full-resolution heatmap only for COMMITTED nodes
             self.cache[key] = [(boxes, scores, heat), (w, h), True]
@@ -178,7 +181,7 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                   target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
                   visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
                   noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
-                  gpu_preprocess: bool = True):
+                  gpu_preprocess: bool = True, device_reductions: bool = False):
     """Same contract as the reference's visual_search (visual_search.py:484-516): returns
     (final_step, path_length, search_successful, all_valid_boxes)."""
     if visualize:
@@ -187,7 +190,8 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
     search_path = [init_patch]
     queue: PriorityQueue = PriorityQueue()
     question = LOCATE_QUESTION.format(target_object_name)
-    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate, gpu_preprocess)
+    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate, gpu_preprocess, device_reductions)
+    on_dev = scorer.device_reductions
 
     search_successful, all_valid_boxes = False, None
     current_patch = init_patch
@@ -215,7 +219,60 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
 
         if min(bbox[2], bbox[3]) <= smallest_size:
             expand = False                                    # already the smallest unit: no children
-        if expand:
+        if expand and on_dev:
+            # ---- the heat map never leaves the GPU.  One kernel returns min / max / sum and the sums over
+            # the four child rectangles of clamp(bilinear(low_res)); min-max normalisation is applied algebraically:
+            #   sum_rect (H - mn)/(mx - mn) = (sum_rect H - mn*|rect|)/(mx - mn).   fp64 accumulation (the reference sums
+            # float32 with numpy's pairwise order; results agree to ~1e-7 relative, so only exact ties could reorder). ----
+            basic_sub_patches, _, _ = get_sub_patches(bbox, *split_4subpatches(bbox))
+            current_patch_index = len(search_path) - 1
+            threshold = max(target_cue_threshold_minimum, target_cue_threshold * target_cue_threshold_decay ** (level - 1))
+            rel = lambda owner: [[sp[0] - owner[0], sp[1] - owner[1], sp[2], sp[3]] for sp in basic_sub_patches]  # noqa: E731
+            st = vsm.heatmap_stats(target_cue_heatmap, bbox[3], bbox[2], rel(bbox))
+            low = target_cue_heatmap
+            if not st[1] > threshold:
+                patch = _crop(image, bbox)
+                vqa_results = vsm.inference(copy.deepcopy(patch), CUE_QUESTION.format(target_object_name), mode="vqa")
+                phrase = vqa_results.split("most likely to appear")[-1].strip()
+                if phrase.endswith("."):
+                    phrase = phrase[:-1]
+                phrase = phrase.split(target_object_name)[-1]
+                if noun_chunker is None:
+                    from .noun_chunks import get_noun_chunker
+                    noun_chunker = get_noun_chunker()
+                noun_chunks = noun_chunker(phrase)
+                phrase = noun_chunks[0] if len(noun_chunks) == 1 else "region {}".format(phrase)
+                low = vsm.inference_batch([patch], LOCATE_QUESTION.format(phrase), mode="segmentation", upsample=False)[0]
+                st = vsm.heatmap_stats(low, bbox[3], bbox[2], rel(bbox))
+                search_path[current_patch_index]["context_cue"] = vqa_results + "#" + phrase
+            current_patch["heat_stats"] = {"low_res": low, "min": st[0], "max": st[1], "sum": st[2]}
+
+            def rect_scores(owner, stats):
+                hs = owner["heat_stats"]
+                mn, mx = hs["min"], hs["max"]
+                if not mx != mn:
+                    return [0.0] * len(basic_sub_patches)
+                area = owner["bbox"][2] * owner["bbox"][3]
+                total = (hs["sum"] - mn * area) / (mx - mn)
+                if not total > 0:
+                    return [0.0] * len(basic_sub_patches)
+                return [((stats[3 + k] - mn * sp[2] * sp[3]) / (mx - mn)) / total for k, sp in enumerate(basic_sub_patches)]
+
+            basic_sub_scores = [0.0] * len(basic_sub_patches)
+            tmp_patch, tmp_stats = current_patch, st
+            while True:
+                sc = rect_scores(tmp_patch, tmp_stats)
+                basic_sub_scores = [basic_sub_scores[i] + sc[i] / (4 ** tmp_patch["scale_level"]) for i in range(len(sc))]
+                if tmp_patch["parent_index"] == -1:
+                    break
+                tmp_patch = search_path[tmp_patch["parent_index"]]
+                tb = tmp_patch["bbox"]
+                tmp_stats = vsm.heatmap_stats(tmp_patch["heat_stats"]["low_res"], tb[3], tb[2], rel(tb))
+            for sub_patch, sub_score in zip(basic_sub_patches, basic_sub_scores):
+                info = {"bbox": sub_patch, "scale_level": level + 1, "score": np.float32(sub_score),
+                        "parent_index": current_patch_index}
+                queue.put(Prioritize(-info["score"], info))
+        elif expand:
             heat = target_cue_heatmap.view(bbox[3], bbox[2], 1)
             score_max = heat.max().item()
             threshold = max(target_cue_threshold_minimum, target_cue_threshold * target_cue_threshold_decay ** (level - 1))

@@ -216,6 +216,14 @@ class VSM:
                             torch.from_numpy(res["pred_logits"][b].copy()).sigmoid(), heat))
         return out
 
+    def heatmap_stats(self, low_res, h: int, w: int, rects_xywh=None) -> np.ndarray:
+        """On-device decision statistics of a heat map (no full-resolution materialisation)."""
+        low = low_res.numpy() if isinstance(low_res, torch.Tensor) else np.asarray(low_res)
+        t0 = time.perf_counter()
+        out = self.engine.heatmap_stats(low, h, w, rects_xywh)
+        self.timers["post_s"] += time.perf_counter() - t0
+        return out
+
     def _check_template(self, n: int) -> None:
         if self.last_template_ok is not None and not self.last_template_ok.all():
             msg = (f"{int((~self.last_template_ok).sum())}/{n} crops: greedy decoding would not emit "
