@@ -53,6 +53,9 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise VstarError(f"{LIB_PATH} not built — run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                          "there is no CPU fallback for the HIP engine")
+    # torch first: the process must end up with ONE HIP runtime (torch bundles its own libamdhip64; loading ours against
+    # /opt/rocm before torch leaves the engine on a runtime that sees no device once torch is imported)
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     H = c_void_p
     lib.vstar_create.argtypes = [POINTER(CVstarConfig), c_int, POINTER(H)]
