@@ -81,6 +81,7 @@ struct vstar_engine {
   int Smax = 0, llm_spad = 0;
   bf16_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr, *lvt = nullptr;
   bf16_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
+  bf16_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
   float* vlogits = nullptr;    // [B*V, vocab]
   bf16_t *fc_tmp = nullptr, *emb_det = nullptr, *emb_seg = nullptr;
   int32_t *d_ids = nullptr, *d_rowidx = nullptr, *d_argmax = nullptr;
@@ -412,6 +413,10 @@ int vstar_engine::finalize() {
   RC(dalloc(&lact, lrows * c.llm_mlp));
   RC(dalloc(&lvt, (size_t)maxB * H * llm_spad));
   RC(dalloc(&hsel, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
+  RC(dalloc(&sel_att, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
+  RC(dalloc(&sel_x, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
+  RC(dalloc(&sel_h, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
+  RC(dalloc(&sel_act, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * c.llm_mlp));
   RC(dalloc(&vlogits, (size_t)maxB * VSTAR_MAX_VERIFY * c.llm_vocab));
   RC(dalloc(&d_ids, (size_t)maxB * c.max_text_len));
   RC(dalloc(&d_rowidx, (size_t)maxB * (1 + VSTAR_MAX_VERIFY)));
@@ -675,20 +680,31 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
   const int rows = B * S;
   const int Spad = (S + 63) / 64 * 64;
   const float att_scale = 1.0f / sqrtf(128.0f);
+  const int nsel = B * (1 + n_verify);
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
     KCHK(rmsnorm_bf16(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
     KCHK(attn_prepare(lqkv, lvt, rope, B, S, Spad, c.llm_heads, 128, stream));
     KCHK(attn_forward(lqkv, lvt, latt, B, S, Spad, c.llm_heads, 128, 1, att_scale, stream));
+    if (i + 1 == c.llm_layers) {
+      // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
+      // attention is row-wise, so o_proj / MLP run on those B*(1+V) gathered rows only (row-wise ops: bit-identical).
+      KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
+      KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
+      RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
+      KCHK(rmsnorm_bf16(sel_x, b.post_norm, sel_h, nsel, H, c.llm_rms_eps, nullptr, stream));
+      RC(lin(sel_h, H, b.gate_up, sel_act, c.llm_mlp, nsel, VSTAR_EPI_SILU_MUL));
+      RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
+      break;
+    }
     RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
     KCHK(rmsnorm_bf16(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
     RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
   }
   // ---- a6/a7: final norm on the needed rows only, lm_head argmax at the verify rows, [LOC]-1 gather ----
-  const int nsel = B * (1 + n_verify);
-  KCHK(rmsnorm_bf16(lx, final_norm, hsel, nsel, H, c.llm_rms_eps, d_rowidx, stream));
+  KCHK(rmsnorm_bf16(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));
   if (n_verify > 0) {
     RC(lin(hsel + (size_t)B * H, H, lm_head, vlogits, c.llm_vocab, B * n_verify, VSTAR_EPI_NONE, nullptr, 0, true));
     KCHK(argmax_rows(vlogits, B * n_verify, c.llm_vocab, c.llm_vocab, d_argmax, 1, stream));
