@@ -373,6 +373,189 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   }
 }
 
+// ---------------- flash attention forward, v3: as v2, but each wave consumes the whole 64-key tile at once ----------------
+// Two independent S^T accumulators (keys 0-31 / 32-63) give the MFMA pipe two chains, the K-fragment reads are issued as
+// one batch, and the online-softmax bookkeeping (row max, shuffle, rescale test, row sum) runs once per 64 keys.
+// Same per-wave math as attn_kernel, but the 64-key K tile [64][D] and V^T tile [D][64] are DMA'd once per block
+// (global_load_lds, whole 128/256-byte lines) into a double-buffered LDS ring and shared by the block's 4 waves, instead of
+// every wave issuing fragment-shaped global loads (32 cache lines per instruction).  XOR chunk swizzles (applied on the
+// DMA source address and on the read address) keep the ds_read_b128 K-fragment reads conflict-free and the ds_read_b64
+// V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
+                                                    bf16_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
+  constexpr int KS = D / 16, DB = D / 32;
+  constexpr int KBYTES = 64 * D * 2;               // K tile = V^T tile bytes
+  constexpr int KCH = D / 8;                        // 16-B chunks per K row
+  constexpr int KROWS_PER_INST = 64 / KCH;          // K rows covered by one wave-wide DMA instruction
+  constexpr int K_INST = 64 / KROWS_PER_INST / 4;   // K DMA instructions per wave per tile (4 waves)
+  constexpr int V_INST = D / 8 / 4;                 // V^T: D rows x 8 chunks, 8 rows per instruction
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0b = blockIdx.x * 128;
+  const int q0 = q0b + wave * 32;
+  const bool active = q0 < S;
+  const int qi = lane & 31, h2 = lane >> 5;
+  const int query = q0 + qi;
+  const int qrow = query < S ? query : S - 1;
+  const int64_t ld = 3 * (int64_t)H * D;
+  const bf16_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
+  const bf16_t* Vg = vt + ((int64_t)b * H + h) * D * (int64_t)Spad;
+
+  // per-lane DMA sources
+  const bf16_t* ksrc[K_INST];
+  int krow_l[K_INST];
+#pragma unroll
+  for (int i = 0; i < K_INST; ++i) {
+    const int row = (i * 4 + wave) * KROWS_PER_INST + lane / KCH;       // key row inside the tile
+    const int ch = lane % KCH;
+    const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
+    krow_l[i] = row;
+    ksrc[i] = Kg + (ch ^ sw) * 8;
+  }
+  const bf16_t* vsrc[V_INST];
+#pragma unroll
+  for (int i = 0; i < V_INST; ++i) {
+    const int d = (i * 4 + wave) * 8 + (lane >> 3);
+    const int ch = lane & 7;
+    vsrc[i] = Vg + (int64_t)d * Spad + (ch ^ ((d >> 1) & 7)) * 8;
+  }
+  auto stage = [&](int t) {
+    char* base = smem + (t & 1) * 2 * KBYTES;
+    const int kt0 = t * 64;
+#pragma unroll
+    for (int i = 0; i < K_INST; ++i) {
+      int kr = kt0 + krow_l[i];
+      kr = kr < S ? kr : S - 1;
+      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[i] + (int64_t)kr * ld), (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < V_INST; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + kt0), (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  const bf16_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
+  bf16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+  f32x16 oacc[DB];
+#pragma unroll
+  for (int db = 0; db < DB; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m = -1e30f, l = 0.f;
+
+  const int kend = CAUSAL ? min(S, q0b + 128) : S;
+  const int nkt = (kend + 63) / 64;
+  const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
+
+  stage(0);
+  for (int t = 0; t < nkt; ++t) {
+    if (t + 1 < nkt) {
+      stage(t + 1);
+      if (K_INST + V_INST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const char* kb = smem + (t & 1) * 2 * KBYTES;
+    const char* vb = kb + KBYTES;
+    const int kt0 = t * 64;
+    if (active && !(CAUSAL && kt0 > q0 + 31)) {            // wave-uniform: tile entirely above this wave's diagonal
+      // ---- S^T = K . Q^T for both 32-key halves ----
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      const char* krow0 = kb + qi * (D * 2);
+      const char* krow1 = krow0 + 32 * (D * 2);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = ((ks * 2 + h2) ^ kswz) * 16;
+        const bf16x8 kf0 = *(const bf16x8*)(krow0 + off);
+        const bf16x8 kf1 = *(const bf16x8*)(krow1 + off);
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
+      }
+      // ---- online softmax over 64 keys (this lane: query `query`; s0[r] = key kt0 + (r&3) + 8*(r>>2) + 4*h2, s1: +32) ----
+      constexpr float RESCALE_THR = 6.0f;
+      const bool need_mask = (kt0 + 64 > S) || (CAUSAL && kt0 + 63 > q0);
+      if (need_mask) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+          if ((key >= S) || (CAUSAL && key > query)) s0[r] = -1e30f;
+          if ((key + 32 >= S) || (CAUSAL && key + 32 > query)) s1[r] = -1e30f;
+        }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
+      if (__any(mx > m + RESCALE_THR)) {
+        const float m_new = fmaxf(m, mx);
+        const float alpha = exp2f(m - m_new);
+        l *= alpha;
+        m = m_new;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = exp2f(fmaf(s0[r], scale_log2e, -m));
+        s1[r] = exp2f(fmaf(s1[r], scale_log2e, -m));
+        rs += s0[r] + s1[r];
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l += rs;
+      // ---- O^T += V^T . P^T over the four 16-key k-blocks ----
+#pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk) {
+        bf16x8 pb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(kbk < 2 ? s0[8 * (kbk & 1) + i] : s1[8 * (kbk & 1) + i]);
+        const int u0 = (kbk >> 1) * 8 + 4 * (kbk & 1) + h2;        // 8-byte key unit of the first group; second = u0 + 2
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+          const int d = db * 32 + qi;
+          const int sw = (d >> 1) & 7;
+          const char* vrow = vb + d * 128;
+          const bf16x4 lo = *(const bf16x4*)(vrow + (((u0 >> 1) ^ sw) * 16) + (u0 & 1) * 8);
+          const bf16x4 hi = *(const bf16x4*)(vrow + ((((u0 + 2) >> 1) ^ sw) * 16) + (u0 & 1) * 8);
+          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, oacc[db], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if (active && query < S) {
+    const float inv = 1.0f / l;
+    bf16_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(oacc[db][g * 4 + e] * inv);
+        *(bf16x4*)(op + db * 32 + g * 8) = o;
+      }
+  }
+}
+
 // ---------------- small generic attention (SAM head): one wave per (b, head, query) ----------------
 template <int D>
 __global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
@@ -527,12 +710,12 @@ hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, i
   return hipGetLastError();
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool V3>
 static hipError_t launch_attn2(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, float sl,
                                hipStream_t s) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
-  auto kern = attn2_kernel<D, CAUSAL>;
+  auto kern = V3 ? attn3_kernel<D, CAUSAL> : attn2_kernel<D, CAUSAL>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -547,12 +730,18 @@ hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B,
                         float scale, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
-  static const int ver = [] { const char* e = getenv("VSTAR_ATTN"); return e ? atoi(e) : 2; }();
+  static const int ver = [] { const char* e = getenv("VSTAR_ATTN"); return e ? atoi(e) : 3; }();
+  if (ver == 3) {
+    if (D == 64) return causal ? launch_attn2<64, true, true>(qkv, vt, out, B, S, Spad, H, sl, s)
+                               : launch_attn2<64, false, true>(qkv, vt, out, B, S, Spad, H, sl, s);
+    return causal ? launch_attn2<128, true, true>(qkv, vt, out, B, S, Spad, H, sl, s)
+                  : launch_attn2<128, false, true>(qkv, vt, out, B, S, Spad, H, sl, s);
+  }
   if (ver == 2) {
-    if (D == 64) return causal ? launch_attn2<64, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                               : launch_attn2<64, false>(qkv, vt, out, B, S, Spad, H, sl, s);
-    return causal ? launch_attn2<128, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                  : launch_attn2<128, false>(qkv, vt, out, B, S, Spad, H, sl, s);
+    if (D == 64) return causal ? launch_attn2<64, true, false>(qkv, vt, out, B, S, Spad, H, sl, s)
+                               : launch_attn2<64, false, false>(qkv, vt, out, B, S, Spad, H, sl, s);
+    return causal ? launch_attn2<128, true, false>(qkv, vt, out, B, S, Spad, H, sl, s)
+                  : launch_attn2<128, false, false>(qkv, vt, out, B, S, Spad, H, sl, s);
   }
   dim3 grid((S + 127) / 128, H, B);
   if (D == 64) {
