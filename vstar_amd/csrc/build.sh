@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libvstar_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p build
 pids=()
 for f in gemm gemm256 norm attention elementwise heads preprocess engine; do
