@@ -730,7 +730,7 @@ hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B,
                         float scale, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
-  static const int ver = [] { const char* e = getenv("VSTAR_ATTN"); return e ? atoi(e) : 3; }();
+  static const int ver = [] { const char* e = getenv("VSTAR_ATTN"); return e ? atoi(e) : 2; }();
   if (ver == 3) {
     if (D == 64) return causal ? launch_attn2<64, true, true>(qkv, vt, out, B, S, Spad, H, sl, s)
                                : launch_attn2<64, false, true>(qkv, vt, out, B, S, Spad, H, sl, s);
