@@ -19,24 +19,26 @@ lib = _lib.load()
 dev = torch.device("cuda:0")
 B = args.batch
 S, Nc, No = 640, 577, 2305
-shapes = [("llama qkv", B * S, 12288, 4096, 0), ("llama o", B * S, 4096, 4096, 0), ("llama gate_up silu", B * S, 22016, 4096, 4),
-          ("llama down", B * S, 4096, 11008, 0), ("clip qkv", B * Nc, 3072, 1024, 0), ("clip out", B * Nc, 1024, 1024, 0),
-          ("clip fc1 qgelu", B * Nc, 4096, 1024, 1), ("clip fc2", B * Nc, 1024, 4096, 0), ("owl qkv", B * No, 2304, 768, 0),
-          ("owl out", B * No, 768, 768, 0), ("owl fc1 qgelu", B * No, 3072, 768, 1), ("owl fc2", B * No, 768, 3072, 0),
-          ("sam conv1", B * 9216, 64, 2304, 0), ("sam conv2 gelu", B * 36864, 32, 576, 2), ("square 8192", 8192, 8192, 8192, 0)]
+# (name, M, N, K, epilogue, residual?) exactly as the engine launches them
+shapes = [("llama qkv", B * S, 12288, 4096, 0, 0), ("llama o +res", B * S, 4096, 4096, 0, 1), ("llama gate_up silu", B * S, 22016, 4096, 4, 0),
+          ("llama down +res", B * S, 4096, 11008, 0, 1), ("clip qkv", B * Nc, 3072, 1024, 0, 0), ("clip out +res", B * Nc, 1024, 1024, 0, 1),
+          ("clip fc1 qgelu", B * Nc, 4096, 1024, 1, 0), ("clip fc2 +res", B * Nc, 1024, 4096, 0, 1), ("owl qkv", B * No, 2304, 768, 0, 0),
+          ("owl out +res", B * No, 768, 768, 0, 1), ("owl fc1 qgelu", B * No, 3072, 768, 1, 0), ("owl fc2 +res", B * No, 768, 3072, 0, 1),
+          ("sam conv1", B * 9216, 64, 2304, 0, 0), ("sam conv2 gelu", B * 36864, 32, 576, 2, 0), ("square 8192", 8192, 8192, 8192, 0, 0)]
 P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 print(f"{'shape':<22s} {'M':>7s} {'N':>6s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s}")
-for name, M, N, K, epi in shapes:
+for name, M, N, K, epi, has_res in shapes:
     a = torch.randn(M, K, device=dev).bfloat16()
     npad = (N + 255) // 256 * 256
     w = torch.zeros(npad, K, device=dev, dtype=torch.bfloat16)
     w[:N] = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     n_out = N // 2 if epi == 4 else N
     c = torch.empty(M, n_out, device=dev, dtype=torch.bfloat16)
-    res = torch.randn(M, n_out, device=dev).bfloat16() if epi == 0 else None
+    res = torch.randn(M, n_out, device=dev).bfloat16() if has_res else None
+    bias = torch.randn(npad, device=dev).bfloat16() if name.split()[0] in ("clip", "owl", "sam") else None
 
     def run():
-        rc = lib.vstar_op_gemm(None, P(a), K, P(w), None, P(res) if res is not None else None, n_out, P(c), n_out, 0, M, N, K,
+        rc = lib.vstar_op_gemm(None, P(a), K, P(w), P(bias) if bias is not None else None, P(res) if res is not None else None, n_out, P(c), n_out, 0, M, N, K,
                                epi | 0x100)
         assert rc == 0
 
