@@ -29,7 +29,6 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int A_BYTES = BM * BK * 2;               // 32 KiB
 constexpr int TILE_BYTES = 2 * A_BYTES;            // A + W = 64 KiB per K-tile
 constexpr int LDS_TOTAL = 2 * TILE_BYTES;          // 128 KiB ring
-constexpr int D = 5;                               // DMA lookahead in pieces (quarter tiles)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -133,75 +132,79 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: pieces 0..D-1 in flight, pieces 0,1 landed, everyone past the barrier; group 1 one barrier behind ----
+  // ---- prologue: pieces 0..5 in flight, pieces 0..2 (a0, w0, w1 of K-tile 0) landed, everyone past the barrier; group 1
+  // runs one barrier behind group 0 ----
   BAR();   // every wave has finished reading its epilogue slab of the previous tile: the ring may be overwritten
   issue_piece(std::integral_constant<int, 0>{}, 0);
   issue_piece(std::integral_constant<int, 1>{}, 0);
   issue_piece(std::integral_constant<int, 2>{}, 0);
   issue_piece(std::integral_constant<int, 3>{}, 0);
   issue_piece(std::integral_constant<int, 0>{}, 1);
-  static_assert(D == 5, "prologue issues pieces 0..4");
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // 2*(D-2): pieces <= 1 landed (K >= 128 guaranteed by the dispatcher)
+  issue_piece(std::integral_constant<int, 1>{}, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // pieces 3,4,5 may still be in flight (K >= 128: they exist)
   BAR();
   if (group == 1) BAR();
 
+  // Two phases per K-tile (4 barrier rendezvous instead of 8; a barrier interval costs ~100 cycles of pure sync):
+  //   phase A: read A[m-half 0], W[n-half 0], W[n-half 1] (16 x b128) -> quadrants (0,0),(0,1)   = 32 MFMA
+  //   phase B: read A[m-half 1] (8 x b128)                            -> quadrants (1,1),(1,0)   = 32 MFMA
+  // DMA: phase A(T) issues pieces 4T+6, 4T+7 (w1, a1 of tile T+1), phase B(T) issues 4T+8, 4T+9 (a0, w0 of tile T+2) —
+  // each overwrites a region whose last reader retired at least one phase (= one barrier on both groups) earlier — and
+  // waits until everything the NEXT phase reads has landed: vmcnt(8) in A (4 pieces may stay in flight), vmcnt(6) in B.
   bf16x8 af[8], w0f[4], w1f[4];
   const int nkt = p.K / BK;
   for (int T = 0; T < nkt; ++T) {
     const char* base = smem + (T & 1) * TILE_BYTES;
-    const int f0 = 4 * T;
-#define PHASE_TAIL(i)                                                                    \
-  {                                                                                      \
-    const int s_ = f0 + (i) + D;                                                         \
-    if (s_ < total_pieces) {                                                             \
-      issue_piece(std::integral_constant<int, ((i) + D) & 3>{}, T + (((i) + D) >> 2));   \
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                   \
-    } else {                                                                             \
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-    }                                                                                    \
-    LGKM0_BAR();                                                                         \
-  }
-#define MFMA_QUAD(mh, WF, nh)                                                            \
+#define MFMA_PAIR(mh, WFA, nha, WFB, nhb)                                                \
   {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                       \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
       _Pragma("unroll") for (int m = 0; m < 4; ++m)                                      \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                    \
-          acc[(mh) * 4 + m][(nh) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(     \
-              WF[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nh) * 2 + n], 0, 0, 0); \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                  \
+          acc[(mh) * 4 + m][(nha) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
+              WFA[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nha) * 2 + n], 0, 0, 0); \
+          acc[(mh) * 4 + m][(nhb) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
+              WFB[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n], 0, 0, 0); \
+        }                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                       \
     BAR();                                                                               \
   }
-    // phase 0: A[m-half 0] + W[n-half 0]
+    // ---- phase A ----
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) w0f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
+      for (int n = 0; n < 2; ++n) {
+        w0f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
+        w1f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + (2 + n) * 2048);
+      }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
-    PHASE_TAIL(0)
-    MFMA_QUAD(0, w0f, 0)
-    // phase 1: W[n-half 1]
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) w1f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + (2 + n) * 2048);
-    PHASE_TAIL(1)
-    MFMA_QUAD(0, w1f, 1)
-    // phase 2: A[m-half 1]
+    if (T + 1 < nkt) {
+      issue_piece(std::integral_constant<int, 2>{}, T + 1);
+      issue_piece(std::integral_constant<int, 3>{}, T + 1);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    LGKM0_BAR();
+    MFMA_PAIR(0, w0f, 0, w1f, 1)
+    // ---- phase B ----
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + (4 + m) * 2048);
-    PHASE_TAIL(2)
-    MFMA_QUAD(1, w1f, 1)
-    // phase 3: no reads
-    PHASE_TAIL(3)
-    MFMA_QUAD(1, w0f, 0)
-#undef PHASE_TAIL
-#undef MFMA_QUAD
+    if (T + 2 < nkt) {
+      issue_piece(std::integral_constant<int, 0>{}, T + 2);
+      issue_piece(std::integral_constant<int, 1>{}, T + 2);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    LGKM0_BAR();
+    MFMA_PAIR(1, w1f, 1, w0f, 0)
+#undef MFMA_PAIR
   }
   if (group == 0) BAR();   // every wave must execute the same number of barriers
 
