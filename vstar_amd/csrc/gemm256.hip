@@ -1,22 +1,19 @@
 // gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
-// 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 5 quarter-tiles ahead behind COUNTED vmcnt waits, and two
+// 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 6 quarter-tiles ahead behind COUNTED vmcnt waits, and two
 // wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA cluster while its partner issues
 // ds_reads / DMA ("8-phase" structure of the CDNA4 guide, §5 "256^2 8-phase template", re-derived for this layout).
 //
 // Same math / epilogues / row maps as gemm.hip (which stays the kernel for small M, small N or odd K/64).
 //
-// Schedule.  A K-tile is consumed in 4 phases, each = L (LDS fragment reads + one DMA piece) | barrier | M (16 MFMA =
-// one 64x32 quadrant of the wave's tile over K=64) | barrier:
-//      phase 0: read A[m-half 0] (8 x b128) + W[n-half 0] (4)   -> quadrant (0,0)
-//      phase 1: read W[n-half 1] (4)                             -> quadrant (0,1)
-//      phase 2: read A[m-half 1] (8)                             -> quadrant (1,1)
-//      phase 3: no reads                                         -> quadrant (1,0)
-// The K-tile is DMA'd in 4 pieces in exactly that consumption order (a0, w0, w1, a1; 16 KiB = 2 x 1-KiB DMA per wave
-// each).  With global piece index s = 4*T + j and global phase index f = 4*T + i:
-//   piece s is issued in phase s - D (D = 5), consumed in phase 4T + {0,0,1,2}[j], and overwrites the LDS region of
-//   piece s - 8, whose last read (by the late group) retired (lgkmcnt(0)) before the barrier that ends phase s - 8 + ...
-//   -> WAR needs  s - D >= 4(T-2)+{1,1,2,3}[j]  <=>  D <= 6;   RAW: after issuing piece f + D each wave waits
-//   vmcnt(2*(D-2)) = vmcnt(6), i.e. pieces <= f + 2 have landed, before the barrier that precedes phase f + 1.
+// Schedule.  A K-tile is consumed in 2 phases, each = L (LDS fragment reads + two DMA pieces) | barrier | M (32 MFMA = two
+// 64x32 quadrants of the wave's tile over K=64) | barrier:
+//      phase A: read A[m-half 0] (8 x b128) + W[n-half 0] (4) + W[n-half 1] (4)  -> quadrants (0,0),(0,1)
+//      phase B: read A[m-half 1] (8)                                              -> quadrants (1,1),(1,0)
+// (four phases of 16 MFMA were 4 % slower: a barrier interval costs ~100 cycles of pure synchronisation.)
+// The K-tile is DMA'd in 4 pieces (a0, w0, w1, a1; 16 KiB = 2 x 1-KiB DMA per wave each), six pieces ahead: phase A(T)
+// issues pieces w1,a1 of tile T+1, phase B(T) issues a0,w0 of tile T+2; each overwrites an LDS region whose last reader
+// (of either group) retired (lgkmcnt(0)) before an earlier barrier, and each wave then waits with a COUNTED vmcnt until
+// everything the next phase reads has landed (vmcnt(8) in A, vmcnt(6) in B) before the barrier that precedes that phase.
 // Group 1 (waves 4-7) runs one barrier behind group 0, so L of one group always overlaps M of the other.
 #include "common.hpp"
 #include "kernels.hpp"
