@@ -72,7 +72,7 @@ class VSMConfig:
     owl_layers: int = 12
     owl_query_dim: int = 512
     max_batch: int = 32
-    max_text_len: int = 128
+    max_text_len: int = 192
 
     # ---- derived ----
     @property
