@@ -4,13 +4,14 @@
 // owlvit.py:121-126) and HF LlamaAttention (causal, 128-d heads, rotate-half RoPE; llava_llama.py:93-102),
 // and the SAM two-way transformer's Attention (segment_anything/modeling/transformer.py:185-242).
 //
-// attn_forward: one wave64 owns 32 query rows; v_mfma_f32_32x32x16_bf16 for both products.
+// attn_forward (attn2_kernel): one wave64 owns 32 query rows; v_mfma_f32_32x32x16_bf16 for both products; the 64-key K tile
+// and V^T tile are DMA'd into a double-buffered LDS ring shared by the block's 4 waves.
 //   S^T = K Q^T  (K tile as the A operand, Q^T as B): each lane ends up with ONE query column (lane&31) and 16 of
 //   the tile's 32 keys, so the online-softmax statistics are per-lane scalars (one shuffle with lane^32).
 //   O^T = V^T P^T: P^T is fed straight from the S^T accumulator registers (the contraction order over keys is
 //   permuted identically on the V^T side), so no cross-lane movement or LDS round trip for P.
-//   V^T comes from a [B,H,D,Spad] buffer written once per layer by attn_prepare (8-byte key-contiguous loads).
-//   K/V tiles are read straight from L2 (S <= 2305 keys x 64/128 dims per head fit the 4 MiB XCD L2).
+//   V^T comes from a [B,H,D,Spad] buffer written once per layer by attn_prepare, keys permuted so that every PV operand
+//   fragment is one 16-byte LDS read.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
@@ -50,6 +51,10 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__
 }
 
 // ---------------- V -> V^T [B,H,D,Spad] through a padded LDS tile (64 positions x D) ----------------
+// Keys are stored PERMUTED inside every aligned group of 16 (bits 2 and 3 of the position swapped): the PV MFMA's A operand
+// for half-wave h2 and k-block j needs keys 16j + 4*h2 + {0..3} and 16j + 8 + 4*h2 + {0..3} (the keys whose probabilities
+// that lane holds in its S^T accumulator registers); with the swap they are the 8 consecutive positions 16j + 8*h2 + {0..7},
+// i.e. ONE 16-byte fragment.
 template <int D>
 __global__ __launch_bounds__(256) void vt_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt, int S, int Spad,
                                                  int H) {
@@ -72,119 +77,9 @@ __global__ __launch_bounds__(256) void vt_kernel(const bf16_t* __restrict__ qkv,
     if (s0 + sv * 8 >= Spad) continue;
     bf16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (short)tile[sv * 8 + e][d];
+    for (int e = 0; e < 8; ++e)   // position p holds key (p with bits 2 and 3 swapped): see attn2_kernel's PV operand
+      o[e] = (short)tile[(sv & ~1) * 8 + ((e >> 2) << 3) + ((sv & 1) << 2) + (e & 3)][d];
     *(bf16x8*)(vt + (((int64_t)b * H + h) * D + d) * Spad + s0 + sv * 8) = o;
-  }
-}
-
-// ---------------- flash attention forward ----------------
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
-                                                   bf16_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
-  constexpr int KS = D / 16;   // MFMA k-steps over the head dim
-  constexpr int DB = D / 32;   // 32-row blocks of O^T
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
-  if (q0 >= S) return;
-  const int qi = lane & 31, h2 = lane >> 5;
-  const int query = q0 + qi;
-  const int qrow = query < S ? query : S - 1;
-  const int64_t ld = 3 * (int64_t)H * D;
-  const bf16_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
-  const bf16_t* Kb = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D + h2 * 8;
-  const bf16_t* Vb = vt + (((int64_t)b * H + h) * D + qi) * Spad + 4 * h2;
-
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
-
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m = -1e30f, l = 0.f;
-
-  const int kend = CAUSAL ? min(S, q0 + 32) : S;
-  for (int kt0 = 0; kt0 < kend; kt0 += 32) {
-    // ---- S^T tile = K[kt0..kt0+31] . Q^T ----
-    int krow = kt0 + qi;
-    krow = krow < S ? krow : S - 1;
-    const bf16_t* Kp = Kb + (int64_t)krow * ld;
-    bf16x8 kf[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(Kp + ks * 16);
-    // V^T fragments for this key tile (issued early; consumed after the softmax)
-    bf16x8 vf[2][DB];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const bf16_t* vp = Vb + (int64_t)db * 32 * Spad + kt0 + 16 * j;
-        const bf16x4 lo = *(const bf16x4*)(vp);
-        const bf16x4 hi = *(const bf16x4*)(vp + 8);
-        vf[j][db] = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], sacc, 0, 0, 0);
-
-    // ---- online softmax: this lane = query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2 ----
-    float p[16];
-    float mx = -1e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-      float sv = sacc[r] * scale_log2e;
-      const bool masked = (key >= S) || (CAUSAL && key > query);
-      sv = masked ? -1e30f : sv;
-      p[r] = sv;
-      mx = fmaxf(mx, sv);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f(m - m_new);
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      p[r] = exp2f(p[r] - m_new);
-      rs += p[r];
-    }
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = m_new;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-
-    // ---- O^T += V^T . P^T : k-slot (h2, i) of k-block j <-> key kt0 + 16j + 8(i>>2) + 4 h2 + (i&3) ----
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      bf16x8 pb;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(p[8 * j + i]);
-#pragma unroll
-      for (int db = 0; db < DB; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j][db], pb, oacc[db], 0, 0, 0);
-    }
-  }
-
-  if (query < S) {
-    const float inv = 1.0f / l;
-    bf16_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(oacc[db][g * 4 + e] * inv);
-        *(bf16x4*)(op + db * 32 + g * 8) = o;
-      }
   }
 }
 
@@ -339,200 +234,13 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
           bf16x8 pb;
 #pragma unroll
           for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(p[8 * j + i]);
-          const int u0 = st * 8 + 4 * j + h2;                   // 8-byte key unit of the first group; second = u0 + 2
+          const int vc = st * 4 + 2 * j + h2;                   // 16-byte chunk holding this lane's 8 (permuted) keys
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
             const int d = db * 32 + qi;
-            const int sw = (d >> 1) & 7;
-            const char* vrow = vb + d * 128;
-            const bf16x4 lo = *(const bf16x4*)(vrow + (((u0 >> 1) ^ sw) * 16) + (u0 & 1) * 8);
-            const bf16x4 hi = *(const bf16x4*)(vrow + ((((u0 + 2) >> 1) ^ sw) * 16) + (u0 & 1) * 8);
-            const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x8 vf = *(const bf16x8*)(vb + d * 128 + ((vc ^ ((d >> 1) & 7)) * 16));
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, oacc[db], 0, 0, 0);
           }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  }
-
-  if (active && query < S) {
-    const float inv = 1.0f / l;
-    bf16_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
-#pragma unroll
-    for (int db = 0; db < DB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(oacc[db][g * 4 + e] * inv);
-        *(bf16x4*)(op + db * 32 + g * 8) = o;
-      }
-  }
-}
-
-// ---------------- flash attention forward, v3: as v2, but each wave consumes the whole 64-key tile at once ----------------
-// Two independent S^T accumulators (keys 0-31 / 32-63) give the MFMA pipe two chains, the K-fragment reads are issued as
-// one batch, and the online-softmax bookkeeping (row max, shuffle, rescale test, row sum) runs once per 64 keys.
-// Same per-wave math as attn_kernel, but the 64-key K tile [64][D] and V^T tile [D][64] are DMA'd once per block
-// (global_load_lds, whole 128/256-byte lines) into a double-buffered LDS ring and shared by the block's 4 waves, instead of
-// every wave issuing fragment-shaped global loads (32 cache lines per instruction).  XOR chunk swizzles (applied on the
-// DMA source address and on the read address) keep the ds_read_b128 K-fragment reads conflict-free and the ds_read_b64
-// V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
-template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
-                                                    bf16_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
-  constexpr int KS = D / 16, DB = D / 32;
-  constexpr int KBYTES = 64 * D * 2;               // K tile = V^T tile bytes
-  constexpr int KCH = D / 8;                        // 16-B chunks per K row
-  constexpr int KROWS_PER_INST = 64 / KCH;          // K rows covered by one wave-wide DMA instruction
-  constexpr int K_INST = 64 / KROWS_PER_INST / 4;   // K DMA instructions per wave per tile (4 waves)
-  constexpr int V_INST = D / 8 / 4;                 // V^T: D rows x 8 chunks, 8 rows per instruction
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0b = blockIdx.x * 128;
-  const int q0 = q0b + wave * 32;
-  const bool active = q0 < S;
-  const int qi = lane & 31, h2 = lane >> 5;
-  const int query = q0 + qi;
-  const int qrow = query < S ? query : S - 1;
-  const int64_t ld = 3 * (int64_t)H * D;
-  const bf16_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
-  const bf16_t* Vg = vt + ((int64_t)b * H + h) * D * (int64_t)Spad;
-
-  // per-lane DMA sources
-  const bf16_t* ksrc[K_INST];
-  int krow_l[K_INST];
-#pragma unroll
-  for (int i = 0; i < K_INST; ++i) {
-    const int row = (i * 4 + wave) * KROWS_PER_INST + lane / KCH;       // key row inside the tile
-    const int ch = lane % KCH;
-    const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
-    krow_l[i] = row;
-    ksrc[i] = Kg + (ch ^ sw) * 8;
-  }
-  const bf16_t* vsrc[V_INST];
-#pragma unroll
-  for (int i = 0; i < V_INST; ++i) {
-    const int d = (i * 4 + wave) * 8 + (lane >> 3);
-    const int ch = lane & 7;
-    vsrc[i] = Vg + (int64_t)d * Spad + (ch ^ ((d >> 1) & 7)) * 8;
-  }
-  auto stage = [&](int t) {
-    char* base = smem + (t & 1) * 2 * KBYTES;
-    const int kt0 = t * 64;
-#pragma unroll
-    for (int i = 0; i < K_INST; ++i) {
-      int kr = kt0 + krow_l[i];
-      kr = kr < S ? kr : S - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[i] + (int64_t)kr * ld), (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < V_INST; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + kt0), (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-  };
-
-  const bf16_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
-  bf16x8 qf[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
-  f32x16 oacc[DB];
-#pragma unroll
-  for (int db = 0; db < DB; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m = -1e30f, l = 0.f;
-
-  const int kend = CAUSAL ? min(S, q0b + 128) : S;
-  const int nkt = (kend + 63) / 64;
-  const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
-
-  stage(0);
-  for (int t = 0; t < nkt; ++t) {
-    if (t + 1 < nkt) {
-      stage(t + 1);
-      if (K_INST + V_INST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    const char* kb = smem + (t & 1) * 2 * KBYTES;
-    const char* vb = kb + KBYTES;
-    const int kt0 = t * 64;
-    if (active && !(CAUSAL && kt0 > q0 + 31)) {            // wave-uniform: tile entirely above this wave's diagonal
-      // ---- S^T = K . Q^T for both 32-key halves ----
-      f32x16 s0, s1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-      const char* krow0 = kb + qi * (D * 2);
-      const char* krow1 = krow0 + 32 * (D * 2);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int off = ((ks * 2 + h2) ^ kswz) * 16;
-        const bf16x8 kf0 = *(const bf16x8*)(krow0 + off);
-        const bf16x8 kf1 = *(const bf16x8*)(krow1 + off);
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf[ks], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf[ks], s1, 0, 0, 0);
-      }
-      // ---- online softmax over 64 keys (this lane: query `query`; s0[r] = key kt0 + (r&3) + 8*(r>>2) + 4*h2, s1: +32) ----
-      constexpr float RESCALE_THR = 6.0f;
-      const bool need_mask = (kt0 + 64 > S) || (CAUSAL && kt0 + 63 > q0);
-      if (need_mask) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-          if ((key >= S) || (CAUSAL && key > query)) s0[r] = -1e30f;
-          if ((key + 32 >= S) || (CAUSAL && key + 32 > query)) s1[r] = -1e30f;
-        }
-      }
-      float mx = -1e30f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;
-      if (__any(mx > m + RESCALE_THR)) {
-        const float m_new = fmaxf(m, mx);
-        const float alpha = exp2f(m - m_new);
-        l *= alpha;
-        m = m_new;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      }
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = exp2f(fmaf(s0[r], scale_log2e, -m));
-        s1[r] = exp2f(fmaf(s1[r], scale_log2e, -m));
-        rs += s0[r] + s1[r];
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      l += rs;
-      // ---- O^T += V^T . P^T over the four 16-key k-blocks ----
-#pragma unroll
-      for (int kbk = 0; kbk < 4; ++kbk) {
-        bf16x8 pb;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(kbk < 2 ? s0[8 * (kbk & 1) + i] : s1[8 * (kbk & 1) + i]);
-        const int u0 = (kbk >> 1) * 8 + 4 * (kbk & 1) + h2;        // 8-byte key unit of the first group; second = u0 + 2
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int d = db * 32 + qi;
-          const int sw = (d >> 1) & 7;
-          const char* vrow = vb + d * 128;
-          const bf16x4 lo = *(const bf16x4*)(vrow + (((u0 >> 1) ^ sw) * 16) + (u0 & 1) * 8);
-          const bf16x4 hi = *(const bf16x4*)(vrow + ((((u0 + 2) >> 1) ^ sw) * 16) + (u0 & 1) * 8);
-          const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, oacc[db], 0, 0, 0);
         }
       }
     }
@@ -710,12 +418,12 @@ hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, i
   return hipGetLastError();
 }
 
-template <int D, bool CAUSAL, bool V3>
+template <int D, bool CAUSAL>
 static hipError_t launch_attn2(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, float sl,
                                hipStream_t s) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
-  auto kern = V3 ? attn3_kernel<D, CAUSAL> : attn2_kernel<D, CAUSAL>;
+  auto kern = attn2_kernel<D, CAUSAL>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -730,28 +438,10 @@ hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B,
                         float scale, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
-  static const int ver = [] { const char* e = getenv("VSTAR_ATTN"); return e ? atoi(e) : 2; }();
-  if (ver == 3) {
-    if (D == 64) return causal ? launch_attn2<64, true, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                               : launch_attn2<64, false, true>(qkv, vt, out, B, S, Spad, H, sl, s);
-    return causal ? launch_attn2<128, true, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                  : launch_attn2<128, false, true>(qkv, vt, out, B, S, Spad, H, sl, s);
-  }
-  if (ver == 2) {
-    if (D == 64) return causal ? launch_attn2<64, true, false>(qkv, vt, out, B, S, Spad, H, sl, s)
-                               : launch_attn2<64, false, false>(qkv, vt, out, B, S, Spad, H, sl, s);
-    return causal ? launch_attn2<128, true, false>(qkv, vt, out, B, S, Spad, H, sl, s)
-                  : launch_attn2<128, false, false>(qkv, vt, out, B, S, Spad, H, sl, s);
-  }
-  dim3 grid((S + 127) / 128, H, B);
-  if (D == 64) {
-    if (causal) hipLaunchKernelGGL((attn_kernel<64, true>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
-    else hipLaunchKernelGGL((attn_kernel<64, false>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
-  } else {
-    if (causal) hipLaunchKernelGGL((attn_kernel<128, true>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
-    else hipLaunchKernelGGL((attn_kernel<128, false>), grid, dim3(256), 0, s, qkv, vt, out, S, Spad, H, sl);
-  }
-  return hipGetLastError();
+  if (D == 64) return causal ? launch_attn2<64, true>(qkv, vt, out, B, S, Spad, H, sl, s)
+                             : launch_attn2<64, false>(qkv, vt, out, B, S, Spad, H, sl, s);
+  return causal ? launch_attn2<128, true>(qkv, vt, out, B, S, Spad, H, sl, s)
+                : launch_attn2<128, false>(qkv, vt, out, B, S, Spad, H, sl, s);
 }
 
 hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Nq, int Nk, int H,
