@@ -181,7 +181,7 @@ def main():
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v5; "
                                 "includes Infinity-Cache hits); algorithmic operand+output bytes per launch ~0.3 GB",
-                "kernel": "gemm_bf16_kernel (all epilogues)", "launches_per_step": gemm_n // 2,
+                "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
                 "end_to_end_tflops_per_gpu": round(crops_per_s / world * per_crop / 1e12, 1),

@@ -16,11 +16,13 @@
 #include "kernels.hpp"
 #include <cstdlib>
 
+namespace VS_NS {
+
 namespace {
 
 // ---------------- RoPE (in place on q and k of the fused qkv buffer) ----------------
 // HF rotate-half convention with the reference's bf16 rounding points: each product and the sum are bf16.
-__global__ void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos_sin, int rows, int S, int H, int D) {
+__global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos_sin, int rows, int S, int H, int D) {
   const int half = D >> 1;
   const int vec_per_head = half >> 3;                 // 8-element vectors in the first half
   const int per_row = 2 * H * vec_per_head;           // q and k
@@ -33,21 +35,21 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__
   const int h = rem / vec_per_head;
   const int d0 = (rem - h * vec_per_head) * 8;
   const int pos = row % S;
-  bf16_t* base = qkv + (int64_t)row * (3 * H * D) + which * (H * D) + h * D;
-  const bf16x8 x1 = *(const bf16x8*)(base + d0);
-  const bf16x8 x2 = *(const bf16x8*)(base + d0 + half);
-  const bf16x8 c = *(const bf16x8*)(cos_sin + (int64_t)pos * D + d0);
-  const bf16x8 sn = *(const bf16x8*)(cos_sin + (int64_t)pos * D + half + d0);
-  bf16x8 o1, o2;
+  lp_t* base = qkv + (int64_t)row * (3 * H * D) + which * (H * D) + h * D;
+  const lpx8 x1 = *(const lpx8*)(base + d0);
+  const lpx8 x2 = *(const lpx8*)(base + d0 + half);
+  const lpx8 c = *(const lpx8*)(cos_sin + (int64_t)pos * D + d0);
+  const lpx8 sn = *(const lpx8*)(cos_sin + (int64_t)pos * D + half + d0);
+  lpx8 o1, o2;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    const float a = bf2f((bf16_t)x1[e]), b = bf2f((bf16_t)x2[e]);
-    const float cs = bf2f((bf16_t)c[e]), si = bf2f((bf16_t)sn[e]);
-    o1[e] = (short)f2bf(rbf(a * cs) + rbf(-b * si));
-    o2[e] = (short)f2bf(rbf(b * cs) + rbf(a * si));
+    const float a = lp2f((lp_t)x1[e]), b = lp2f((lp_t)x2[e]);
+    const float cs = lp2f((lp_t)c[e]), si = lp2f((lp_t)sn[e]);
+    o1[e] = (short)f2lp(rlp(a * cs) + rlp(-b * si));
+    o2[e] = (short)f2lp(rlp(b * cs) + rlp(a * si));
   }
-  *(bf16x8*)(base + d0) = o1;
-  *(bf16x8*)(base + d0 + half) = o2;
+  *(lpx8*)(base + d0) = o1;
+  *(lpx8*)(base + d0 + half) = o2;
 }
 
 // ---------------- V -> V^T [B,H,D,Spad] through a padded LDS tile (64 positions x D) ----------------
@@ -56,30 +58,30 @@ __global__ void rope_kernel(bf16_t* __restrict__ qkv, const bf16_t* __restrict__
 // that lane holds in its S^T accumulator registers); with the swap they are the 8 consecutive positions 16j + 8*h2 + {0..7},
 // i.e. ONE 16-byte fragment.
 template <int D>
-__global__ __launch_bounds__(256) void vt_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt, int S, int Spad,
+__global__ __launch_bounds__(256) void vt_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ vt, int S, int Spad,
                                                  int H) {
-  __shared__ bf16_t tile[64][D + 2];
+  __shared__ lp_t tile[64][D + 2];
   const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
   constexpr int VPR = D / 8;  // 16-B vectors per row
   for (int i = tid; i < 64 * VPR; i += 256) {
     const int r = i / VPR, cv = i - r * VPR;
     const int s = s0 + r;
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (s < S) v = *(const bf16x8*)(qkv + ((int64_t)b * S + s) * (3 * H * D) + 2 * H * D + h * D + cv * 8);
+    lpx8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < S) v = *(const lpx8*)(qkv + ((int64_t)b * S + s) * (3 * H * D) + 2 * H * D + h * D + cv * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) tile[r][cv * 8 + e] = (bf16_t)v[e];
+    for (int e = 0; e < 8; ++e) tile[r][cv * 8 + e] = (lp_t)v[e];
   }
   __syncthreads();
   // each thread writes 8 consecutive positions of one d-row: 64 positions = 8 vectors per d-row
   for (int i = tid; i < D * 8; i += 256) {
     const int d = i >> 3, sv = i & 7;
     if (s0 + sv * 8 >= Spad) continue;
-    bf16x8 o;
+    lpx8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e)   // position p holds key (p with bits 2 and 3 swapped): see attn2_kernel's PV operand
       o[e] = (short)tile[(sv & ~1) * 8 + ((e >> 2) << 3) + ((sv & 1) << 2) + (e & 3)][d];
-    *(bf16x8*)(vt + (((int64_t)b * H + h) * D + d) * Spad + s0 + sv * 8) = o;
+    *(lpx8*)(vt + (((int64_t)b * H + h) * D + d) * Spad + s0 + sv * 8) = o;
   }
 }
 
@@ -90,8 +92,8 @@ __global__ __launch_bounds__(256) void vt_kernel(const bf16_t* __restrict__ qkv,
 // DMA source address and on the read address) keep the ds_read_b128 K-fragment reads conflict-free and the ds_read_b64
 // V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
-                                                    bf16_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
+__global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, const lp_t* __restrict__ vt,
+                                                    lp_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int KBYTES = 64 * D * 2;               // K tile = V^T tile bytes
   constexpr int KCH = D / 8;                        // 16-B chunks per K row
@@ -111,11 +113,11 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   const int query = q0 + qi;
   const int qrow = query < S ? query : S - 1;
   const int64_t ld = 3 * (int64_t)H * D;
-  const bf16_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
-  const bf16_t* Vg = vt + ((int64_t)b * H + h) * D * (int64_t)Spad;
+  const lp_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
+  const lp_t* Vg = vt + ((int64_t)b * H + h) * D * (int64_t)Spad;
 
   // per-lane DMA sources
-  const bf16_t* ksrc[K_INST];
+  const lp_t* ksrc[K_INST];
   int krow_l[K_INST];
 #pragma unroll
   for (int i = 0; i < K_INST; ++i) {
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     krow_l[i] = row;
     ksrc[i] = Kg + (ch ^ sw) * 8;
   }
-  const bf16_t* vsrc[V_INST];
+  const lp_t* vsrc[V_INST];
 #pragma unroll
   for (int i = 0; i < V_INST; ++i) {
     const int d = (i * 4 + wave) * 8 + (lane >> 3);
@@ -146,10 +148,10 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + kt0), (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
   };
 
-  const bf16_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
-  bf16x8 qf[KS];
+  const lp_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
+  lpx8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(Qp + ks * 16);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const lpx8*)(Qp + ks * 16);
   f32x16 oacc[DB];
 #pragma unroll
   for (int db = 0; db < DB; ++db)
@@ -188,8 +190,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
         const char* krow = kb + (st * 32 + qi) * (D * 2);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(krow + (((ks * 2 + h2) ^ kswz) * 16));
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+          const lpx8 kf = *(const lpx8*)(krow + (((ks * 2 + h2) ^ kswz) * 16));
+          sacc = mfma_32x32x16(kf, qf[ks], sacc);
         }
         // ---- online softmax (this lane: query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2) ----
         // The running reference max m is only raised when some row's tile max exceeds it by more than RESCALE_THR
@@ -231,15 +233,15 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
         // ---- O^T += V^T . P^T ----
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          bf16x8 pb;
+          lpx8 pb;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pb[i] = (short)f2bf(p[8 * j + i]);
+          for (int i = 0; i < 8; ++i) pb[i] = (short)f2lp(p[8 * j + i]);
           const int vc = st * 4 + 2 * j + h2;                   // 16-byte chunk holding this lane's 8 (permuted) keys
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
             const int d = db * 32 + qi;
-            const bf16x8 vf = *(const bf16x8*)(vb + d * 128 + ((vc ^ ((d >> 1) & 7)) * 16));
-            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, oacc[db], 0, 0, 0);
+            const lpx8 vf = *(const lpx8*)(vb + d * 128 + ((vc ^ ((d >> 1) & 7)) * 16));
+            oacc[db] = mfma_32x32x16(vf, pb, oacc[db]);
           }
         }
       }
@@ -251,23 +253,23 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 
   if (active && query < S) {
     const float inv = 1.0f / l;
-    bf16_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
+    lp_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        bf16x4 o;
+        lpx4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (short)f2bf(oacc[db][g * 4 + e] * inv);
-        *(bf16x4*)(op + db * 32 + g * 8) = o;
+        for (int e = 0; e < 4; ++e) o[e] = (short)f2lp(oacc[db][g * 4 + e] * inv);
+        *(lpx4*)(op + db * 32 + g * 8) = o;
       }
   }
 }
 
 // ---------------- small generic attention (SAM head): one wave per (b, head, query) ----------------
 template <int D>
-__global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                         const bf16_t* __restrict__ v, bf16_t* __restrict__ out, int B,
+__global__ __launch_bounds__(256) void small_attn_kernel(const lp_t* __restrict__ q, const lp_t* __restrict__ k,
+                                                         const lp_t* __restrict__ v, lp_t* __restrict__ out, int B,
                                                          int Nq, int Nk, int H, float scale) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -277,9 +279,9 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restric
   const int b = (int)(wid / ((int64_t)Nq * H));
   const int C = H * D;
   float qv[D];
-  const bf16_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
+  const lp_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
 #pragma unroll
-  for (int d = 0; d < D; ++d) qv[d] = bf2f(qp[d]);
+  for (int d = 0; d < D; ++d) qv[d] = lp2f(qp[d]);
   // pass 1: scores for this lane's keys (kept for up to 40 keys per lane = 2560 keys)
   constexpr int MAXK = 40;
   float sc[MAXK];
@@ -289,11 +291,11 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restric
     const int key = i * 64 + lane;
     float s = -1e30f;
     if (key < Nk) {
-      const bf16_t* kp = k + ((int64_t)b * Nk + key) * C + h * D;
+      const lp_t* kp = k + ((int64_t)b * Nk + key) * C + h * D;
       float a = 0.f;
 #pragma unroll
-      for (int d = 0; d < D; ++d) a += qv[d] * bf2f(kp[d]);
-      s = rbf(rbf(a) * scale);     // reference: bf16 matmul, then bf16 divide by sqrt(d)
+      for (int d = 0; d < D; ++d) a += qv[d] * lp2f(kp[d]);
+      s = rlp(rlp(a) * scale);     // reference: bf16 matmul, then bf16 divide by sqrt(d)
     }
     sc[i] = s;
     mx = fmaxf(mx, s);
@@ -318,25 +320,25 @@ __global__ __launch_bounds__(256) void small_attn_kernel(const bf16_t* __restric
   for (int i = 0; i < MAXK; ++i) {
     const int key = i * 64 + lane;
     if (key < Nk) {
-      const float pr = rbf(sc[i] * inv);   // softmax output is bf16 in the reference
-      const bf16_t* vp = v + ((int64_t)b * Nk + key) * C + h * D;
+      const float pr = rlp(sc[i] * inv);   // softmax output is bf16 in the reference
+      const lp_t* vp = v + ((int64_t)b * Nk + key) * C + h * D;
 #pragma unroll
-      for (int d = 0; d < D; ++d) o[d] += pr * bf2f(vp[d]);
+      for (int d = 0; d < D; ++d) o[d] += pr * lp2f(vp[d]);
     }
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) o[d] = wave_sum(o[d]);
   if (lane == 0) {
-    bf16_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
+    lp_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
 #pragma unroll
-    for (int d = 0; d < D; ++d) op[d] = f2bf(o[d]);
+    for (int d = 0; d < D; ++d) op[d] = f2lp(o[d]);
   }
 }
 
 // few-keys variant (image -> token cross attention of the SAM head: 2304 queries x 6 keys): one THREAD per (b, head, query)
 template <int D, int MAXK>
-__global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
-                                                                 const bf16_t* __restrict__ v, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const lp_t* __restrict__ q, const lp_t* __restrict__ k,
+                                                                 const lp_t* __restrict__ v, lp_t* __restrict__ out,
                                                                  int B, int Nq, int Nk, int H, float scale) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * H * Nq) return;
@@ -344,13 +346,13 @@ __global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const bf16_t* _
   const int qi = (int)((idx / H) % Nq);
   const int b = (int)(idx / ((int64_t)H * Nq));
   const int C = H * D;
-  const bf16_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
+  const lp_t* qp = q + ((int64_t)b * Nq + qi) * C + h * D;
   float qv[D];
 #pragma unroll
   for (int d0 = 0; d0 < D; d0 += 8) {
-    const bf16x8 t = *(const bf16x8*)(qp + d0);
+    const lpx8 t = *(const lpx8*)(qp + d0);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qv[d0 + e] = bf2f((bf16_t)t[e]);
+    for (int e = 0; e < 8; ++e) qv[d0 + e] = lp2f((lp_t)t[e]);
   }
   float sc[MAXK];
   float mx = -1e30f;
@@ -358,15 +360,15 @@ __global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const bf16_t* _
   for (int j = 0; j < MAXK; ++j) {
     sc[j] = -1e30f;
     if (j < Nk) {
-      const bf16_t* kp = k + ((int64_t)b * Nk + j) * C + h * D;
+      const lp_t* kp = k + ((int64_t)b * Nk + j) * C + h * D;
       float a = 0.f;
 #pragma unroll
       for (int d0 = 0; d0 < D; d0 += 8) {
-        const bf16x8 t = *(const bf16x8*)(kp + d0);
+        const lpx8 t = *(const lpx8*)(kp + d0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a += qv[d0 + e] * bf2f((bf16_t)t[e]);
+        for (int e = 0; e < 8; ++e) a += qv[d0 + e] * lp2f((lp_t)t[e]);
       }
-      sc[j] = rbf(rbf(a) * scale);
+      sc[j] = rlp(rlp(a) * scale);
       mx = fmaxf(mx, sc[j]);
     }
   }
@@ -383,29 +385,29 @@ __global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const bf16_t* _
 #pragma unroll
   for (int j = 0; j < MAXK; ++j) {
     if (j < Nk) {
-      const float pr = rbf(sc[j] * inv);
-      const bf16_t* vp = v + ((int64_t)b * Nk + j) * C + h * D;
+      const float pr = rlp(sc[j] * inv);
+      const lp_t* vp = v + ((int64_t)b * Nk + j) * C + h * D;
 #pragma unroll
       for (int d0 = 0; d0 < D; d0 += 8) {
-        const bf16x8 t = *(const bf16x8*)(vp + d0);
+        const lpx8 t = *(const lpx8*)(vp + d0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[d0 + e] += pr * bf2f((bf16_t)t[e]);
+        for (int e = 0; e < 8; ++e) o[d0 + e] += pr * lp2f((lp_t)t[e]);
       }
     }
   }
-  bf16_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
+  lp_t* op = out + ((int64_t)b * Nq + qi) * C + h * D;
 #pragma unroll
   for (int d0 = 0; d0 < D; d0 += 8) {
-    bf16x8 t;
+    lpx8 t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(o[d0 + e]);
-    *(bf16x8*)(op + d0) = t;
+    for (int e = 0; e < 8; ++e) t[e] = (short)f2lp(o[d0 + e]);
+    *(lpx8*)(op + d0) = t;
   }
 }
 
 }  // namespace
 
-hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, int S, int Spad, int H, int D, hipStream_t s) {
+hipError_t attn_prepare(lp_t* qkv, lp_t* vt, const lp_t* cos_sin, int B, int S, int Spad, int H, int D, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   if (Spad % 64 != 0 || Spad < S) return hipErrorInvalidValue;
   if (cos_sin) {
@@ -419,7 +421,7 @@ hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin, int B, i
 }
 
 template <int D, bool CAUSAL>
-static hipError_t launch_attn2(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, float sl,
+static hipError_t launch_attn2(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, float sl,
                                hipStream_t s) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
@@ -434,7 +436,7 @@ static hipError_t launch_attn2(const bf16_t* qkv, const bf16_t* vt, bf16_t* out,
   return hipGetLastError();
 }
 
-hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, int D, int causal,
+hipError_t attn_forward(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, int D, int causal,
                         float scale, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
@@ -444,7 +446,7 @@ hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B,
                 : launch_attn2<128, false>(qkv, vt, out, B, S, Spad, H, sl, s);
 }
 
-hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Nq, int Nk, int H,
+hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,
                            int D, hipStream_t s) {
   if (Nk > 40 * 64) return hipErrorInvalidValue;
   const int64_t waves = (int64_t)B * H * Nq;
@@ -462,3 +464,5 @@ hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
+
+}  // namespace VS_NS

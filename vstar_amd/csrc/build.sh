@@ -7,12 +7,24 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-value -mllvm -amdgpu-mfma-vgpr-form"
 mkdir -p build
 pids=()
+HDRS="common.hpp kernels.hpp gemm_epilogue.hpp engine_base.hpp ../../include/vstar_hip.h ../../include/vstar_vqa.h"
+stale() {  # stale <object> <source>
+  [ ! -f "$1" ] && return 0
+  [ "$2" -nt "$1" ] && return 0
+  for h in $HDRS; do [ -f "$h" ] && [ "$h" -nt "$1" ] && return 0; done
+  return 1
+}
+# bf16 instantiation: every kernel file + the VSM engine
 for f in gemm gemm256 norm attention elementwise heads preprocess engine; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.hpp -nt build/$f.o ] || [ kernels.hpp -nt build/$f.o ] || [ gemm_epilogue.hpp -nt build/$f.o ] || [ ../../include/vstar_hip.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
-    pids+=($!)
-  fi
+  if stale build/$f.o $f.hip; then $HIPCC $FLAGS -c $f.hip -o build/$f.o & pids+=($!); fi
 done
-for p in "${pids[@]}"; do wait $p; done
+# fp16 instantiation (-DVSTAR_LP_F16): the dtype-generic kernel files + the VQA-LLM engine
+for f in gemm gemm256 norm attention elementwise decode vqa_engine; do
+  [ -f $f.hip ] || continue
+  if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
+done
+fail=0
+for p in "${pids[@]}"; do wait $p || fail=1; done
+[ $fail -eq 0 ] || { echo "build failed"; exit 1; }
 $HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
 echo "built $(realpath $OUT)"

@@ -1,36 +1,70 @@
-// common.hpp — shared device/host helpers for the gfx950 kernels (wave64, bf16 storage, fp32 math).
+// common.hpp — shared device/host helpers for the gfx950 kernels (wave64, 16-bit storage, fp32 math).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bf16 bits
-typedef __attribute__((ext_vector_type(8))) short bf16x8;
-typedef __attribute__((ext_vector_type(4))) short bf16x4;
+// Every kernel file is dtype-generic over its 16-bit storage element `lp_t`: the translation unit is compiled once for
+// bf16 (default; the VSM path, torch_dtype=bfloat16 at visual_search.py:145) and once with -DVSTAR_LP_F16 for IEEE fp16 (the
+// VQA-LLM path, torch_dtype=float16 at LLaVA/llava/model/builder.py:43).  The storage type selects the conversion
+// instructions, the MFMA opcode and the namespace the host launchers live in; everything else (DMA, LDS layouts,
+// schedules) is identical because both are 2-byte elements.
+#ifdef VSTAR_LP_F16
+#define VS_NS vs_f16
+#define VS_DTYPE_NAME "f16"
+#else
+#define VS_NS vs_bf16
+#define VS_DTYPE_NAME "bf16"
+#endif
+
+typedef uint16_t lp_t;  // raw bits of one low-precision element
+typedef __attribute__((ext_vector_type(8))) short lpx8;
+typedef __attribute__((ext_vector_type(4))) short lpx4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define WAVE 64
 
-__device__ __host__ __forceinline__ float bf2f(bf16_t v) {
+namespace VS_NS {
+
+#ifdef VSTAR_LP_F16
+__device__ __host__ __forceinline__ float lp2f(lp_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even like torch's float -> half (v_cvt_f16_f32 on the device)
+__device__ __host__ __forceinline__ lp_t f2lp(float f) { return __builtin_bit_cast(unsigned short, (_Float16)f); }
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma_x8;
+__device__ __forceinline__ f32x4 mfma_16x16x32(lpx8 a, lpx8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_x8, a), __builtin_bit_cast(mfma_x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(lpx8 a, lpx8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(mfma_x8, a), __builtin_bit_cast(mfma_x8, b), c, 0, 0, 0);
+}
+#else
+__device__ __host__ __forceinline__ float lp2f(lp_t v) {
   union { uint32_t u; float f; } x;
   x.u = ((uint32_t)v) << 16;
   return x.f;
 }
 // round-to-nearest-even, NaN preserved (matches torch's float -> bfloat16).  Device code uses the gfx950 hardware
 // conversion (v_cvt_pk_bf16_f32); the bit-twiddling form is the host path (weight packing).
-__device__ __host__ __forceinline__ bf16_t f2bf(float f) {
+__device__ __host__ __forceinline__ lp_t f2lp(float f) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const __bf16 b = (__bf16)f;
   return __builtin_bit_cast(unsigned short, b);
 #endif
   union { uint32_t u; float f; } x;
   x.f = f;
-  if ((x.u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((x.u >> 16) | 0x40);
+  if ((x.u & 0x7fffffffu) > 0x7f800000u) return (lp_t)((x.u >> 16) | 0x40);
   uint32_t lsb = (x.u >> 16) & 1u;
   x.u += 0x7fffu + lsb;
-  return (bf16_t)(x.u >> 16);
+  return (lp_t)(x.u >> 16);
 }
-__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }  // round through bf16
+__device__ __forceinline__ f32x4 mfma_16x16x32(lpx8 a, lpx8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_32x32x16(lpx8 a, lpx8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+#endif
+__device__ __forceinline__ float rlp(float f) { return lp2f(f2lp(f)); }  // round through the storage type
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -45,11 +79,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // activations, with the reference's bf16 rounding points (Appendix C of SURVEY.md)
 __device__ __forceinline__ float act_quick_gelu_bf16(float t) {  // t already bf16-rounded
-  float u = rbf(1.702f * t);
-  float s = rbf(1.0f / (1.0f + __expf(-u)));
+  float u = rlp(1.702f * t);
+  float s = rlp(1.0f / (1.0f + __expf(-u)));
   return t * s;
 }
 __device__ __forceinline__ float act_gelu_erf(float t) { return 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); }
 __device__ __forceinline__ float act_silu_bf16(float g) {  // g already bf16-rounded; torch silu on bf16 rounds once
-  return rbf(g / (1.0f + __expf(-g)));
+  return rlp(g / (1.0f + __expf(-g)));
 }
+
+}  // namespace VS_NS
+using namespace VS_NS;

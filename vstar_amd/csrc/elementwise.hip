@@ -2,11 +2,13 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+namespace VS_NS {
+
 namespace {
 
 // Conv2d(3, C, kernel=ps, stride=ps, bias=False) as a GEMM: A[b*P + py*G + px][c*ps*ps + ky*ps + kx]
 // (HF CLIPVisionEmbeddings.patch_embedding / OwlViTVisionEmbeddings.patch_embedding; clip_encoder.py:53-57, owlvit.py:121-126)
-__global__ void im2col_patch_kernel(const bf16_t* __restrict__ pix, bf16_t* __restrict__ A, int B, int I, int ps, int Kpad) {
+__global__ void im2col_patch_kernel(const lp_t* __restrict__ pix, lp_t* __restrict__ A, int B, int I, int ps, int Kpad) {
   const int G = I / ps, P = G * G;
   const int K = 3 * ps * ps;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -14,7 +16,7 @@ __global__ void im2col_patch_kernel(const bf16_t* __restrict__ pix, bf16_t* __re
   if (idx >= total) return;
   const int k = (int)(idx % Kpad);
   const int64_t row = idx / Kpad;
-  bf16_t v = 0;
+  lp_t v = 0;
   if (k < K) {
     const int p = (int)(row % P), b = (int)(row / P);
     const int c = k / (ps * ps), rem = k - c * ps * ps;
@@ -26,8 +28,8 @@ __global__ void im2col_patch_kernel(const bf16_t* __restrict__ pix, bf16_t* __re
 }
 
 // embeddings = cat([class_embedding, patch_embeds]) + position_embedding   (bf16 add)
-__global__ void vit_assemble_kernel(const bf16_t* __restrict__ patch, const bf16_t* __restrict__ cls,
-                                    const bf16_t* __restrict__ pos, bf16_t* __restrict__ tokens, int B, int P, int C) {
+__global__ void vit_assemble_kernel(const lp_t* __restrict__ patch, const lp_t* __restrict__ cls,
+                                    const lp_t* __restrict__ pos, lp_t* __restrict__ tokens, int B, int P, int C) {
   const int cv = C >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * (P + 1) * cv;
@@ -35,19 +37,19 @@ __global__ void vit_assemble_kernel(const bf16_t* __restrict__ patch, const bf16
   const int v = (int)(idx % cv);
   const int64_t row = idx / cv;
   const int t = (int)(row % (P + 1)), b = (int)(row / (P + 1));
-  const bf16x8 a = (t == 0) ? *(const bf16x8*)(cls + v * 8)
-                            : *(const bf16x8*)(patch + ((int64_t)b * P + (t - 1)) * C + v * 8);
-  const bf16x8 pe = *(const bf16x8*)(pos + (int64_t)t * C + v * 8);
-  bf16x8 o;
+  const lpx8 a = (t == 0) ? *(const lpx8*)(cls + v * 8)
+                            : *(const lpx8*)(patch + ((int64_t)b * P + (t - 1)) * C + v * 8);
+  const lpx8 pe = *(const lpx8*)(pos + (int64_t)t * C + v * 8);
+  lpx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)a[e]) + bf2f((bf16_t)pe[e]));
-  *(bf16x8*)(tokens + row * C + v * 8) = o;
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2lp(lp2f((lp_t)a[e]) + lp2f((lp_t)pe[e]));
+  *(lpx8*)(tokens + row * C + v * 8) = o;
 }
 
 // prepare_inputs_labels_for_multimodal, mm_use_im_start_end branch (llava_arch.py:185-208,235-247):
 // spliced position s < img_col -> ids[s]; s >= img_col+P -> ids[s-P+1]; the P image rows are left to the projector GEMM.
 __global__ void llm_embed_text_kernel(const int32_t* __restrict__ ids, int L, int img_col, int P,
-                                      const bf16_t* __restrict__ table, int vocab, bf16_t* __restrict__ x, int B, int C) {
+                                      const lp_t* __restrict__ table, int vocab, lp_t* __restrict__ x, int B, int C) {
   const int cv = C >> 3;
   const int T = L - 1;  // text tokens per row
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,26 +63,26 @@ __global__ void llm_embed_text_kernel(const int32_t* __restrict__ ids, int L, in
   int id = ids[(int64_t)b * L + col];
   id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
   const int S = T + P;
-  *(bf16x8*)(x + ((int64_t)b * S + s) * C + v * 8) = *(const bf16x8*)(table + (int64_t)id * C + v * 8);
+  *(lpx8*)(x + ((int64_t)b * S + s) * C + v * 8) = *(const lpx8*)(table + (int64_t)id * C + v * 8);
 }
 
-__global__ void add_bcast_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, bf16_t* __restrict__ out,
+__global__ void add_bcast_kernel(const lp_t* __restrict__ a, const lp_t* __restrict__ b, lp_t* __restrict__ out,
                                  int64_t rows, int cols, int64_t b_rows) {
   const int cv = cols >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cv) return;
   const int v = (int)(idx % cv);
   const int64_t r = idx / cv;
-  const bf16x8 x = *(const bf16x8*)(a + r * cols + v * 8);
-  const bf16x8 y = *(const bf16x8*)(b + (r % b_rows) * cols + v * 8);
-  bf16x8 o;
+  const lpx8 x = *(const lpx8*)(a + r * cols + v * 8);
+  const lpx8 y = *(const lpx8*)(b + (r % b_rows) * cols + v * 8);
+  lpx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)x[e]) + bf2f((bf16_t)y[e]));
-  *(bf16x8*)(out + r * cols + v * 8) = o;
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2lp(lp2f((lp_t)x[e]) + lp2f((lp_t)y[e]));
+  *(lpx8*)(out + r * cols + v * 8) = o;
 }
 
 // image_embeds[:, 1:, :] * image_embeds[:, :1, :]   (owlvit.py:131-137)
-__global__ void owl_cls_mul_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B, int N, int C) {
+__global__ void owl_cls_mul_kernel(const lp_t* __restrict__ x, lp_t* __restrict__ y, int B, int N, int C) {
   const int cv = C >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)B * (N - 1) * cv;
@@ -88,22 +90,22 @@ __global__ void owl_cls_mul_kernel(const bf16_t* __restrict__ x, bf16_t* __restr
   const int v = (int)(idx % cv);
   const int64_t r = idx / cv;
   const int p = (int)(r % (N - 1)), b = (int)(r / (N - 1));
-  const bf16x8 t = *(const bf16x8*)(x + ((int64_t)b * N + 1 + p) * C + v * 8);
-  const bf16x8 c = *(const bf16x8*)(x + ((int64_t)b * N) * C + v * 8);
-  bf16x8 o;
+  const lpx8 t = *(const lpx8*)(x + ((int64_t)b * N + 1 + p) * C + v * 8);
+  const lpx8 c = *(const lpx8*)(x + ((int64_t)b * N) * C + v * 8);
+  lpx8 o;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)t[e]) * bf2f((bf16_t)c[e]));
-  *(bf16x8*)(y + r * C + v * 8) = o;
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2lp(lp2f((lp_t)t[e]) * lp2f((lp_t)c[e]));
+  *(lpx8*)(y + r * C + v * 8) = o;
 }
 
-__global__ void gather_rows_kernel(const bf16_t* __restrict__ x, const int32_t* __restrict__ idx_, bf16_t* __restrict__ y,
+__global__ void gather_rows_kernel(const lp_t* __restrict__ x, const int32_t* __restrict__ idx_, lp_t* __restrict__ y,
                                    int rows, int cols) {
   const int cv = cols >> 3;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)rows * cv) return;
   const int v = (int)(idx % cv);
   const int r = (int)(idx / cv);
-  *(bf16x8*)(y + (int64_t)r * cols + v * 8) = *(const bf16x8*)(x + (int64_t)idx_[r] * cols + v * 8);
+  *(lpx8*)(y + (int64_t)r * cols + v * 8) = *(const lpx8*)(x + (int64_t)idx_[r] * cols + v * 8);
 }
 
 // one block per row; first maximal index wins (torch.argmax tie rule on CPU/GPU is "first occurrence")
@@ -138,37 +140,37 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-hipError_t im2col_patch(const bf16_t* pix, bf16_t* A, int B, int I, int ps, int Kpad, hipStream_t s) {
+hipError_t im2col_patch(const lp_t* pix, lp_t* A, int B, int I, int ps, int Kpad, hipStream_t s) {
   const int G = I / ps;
   const int64_t total = (int64_t)B * G * G * Kpad;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3(nblk(total)), dim3(256), 0, s, pix, A, B, I, ps, Kpad);
   return hipGetLastError();
 }
-hipError_t vit_assemble_tokens(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* tokens, int B, int P,
+hipError_t vit_assemble_tokens(const lp_t* patch, const lp_t* cls, const lp_t* pos, lp_t* tokens, int B, int P,
                                int C, hipStream_t s) {
   if (C % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(vit_assemble_kernel, dim3(nblk((int64_t)B * (P + 1) * (C / 8))), dim3(256), 0, s, patch, cls, pos,
                      tokens, B, P, C);
   return hipGetLastError();
 }
-hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const bf16_t* table, int vocab, bf16_t* x, int B,
+hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const lp_t* table, int vocab, lp_t* x, int B,
                           int C, hipStream_t s) {
   if (C % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(llm_embed_text_kernel, dim3(nblk((int64_t)B * (L - 1) * (C / 8))), dim3(256), 0, s, ids, L, img_col,
                      P, table, vocab, x, B, C);
   return hipGetLastError();
 }
-hipError_t add_bcast(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s) {
+hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s) {
   if (cols % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(add_bcast_kernel, dim3(nblk(rows * (cols / 8))), dim3(256), 0, s, a, b, out, rows, cols, b_rows);
   return hipGetLastError();
 }
-hipError_t owl_cls_mul(const bf16_t* x, bf16_t* y, int B, int N, int C, hipStream_t s) {
+hipError_t owl_cls_mul(const lp_t* x, lp_t* y, int B, int N, int C, hipStream_t s) {
   if (C % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(owl_cls_mul_kernel, dim3(nblk((int64_t)B * (N - 1) * (C / 8))), dim3(256), 0, s, x, y, B, N, C);
   return hipGetLastError();
 }
-hipError_t gather_rows(const bf16_t* x, const int32_t* idx, bf16_t* y, int rows, int cols, hipStream_t s) {
+hipError_t gather_rows(const lp_t* x, const int32_t* idx, lp_t* y, int rows, int cols, hipStream_t s) {
   if (cols % 8) return hipErrorInvalidValue;
   if (rows <= 0) return hipSuccess;
   hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((int64_t)rows * (cols / 8))), dim3(256), 0, s, x, idx, y, rows, cols);
@@ -179,3 +181,5 @@ hipError_t argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out,
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, s, x, cols, ld, out, out_stride);
   return hipGetLastError();
 }
+
+}  // namespace VS_NS

@@ -2,97 +2,49 @@
 // the VSM scoring path.  Mirrors VSMForCausalLM.model_forward(inference=True) / .inference
 // (VisualSearch/model/VSM.py:201-364, 438-553) with the generate() loop collapsed into one teacher-forced prefill
 // (SURVEY.md §7 "hard parts"; the lm_head argmax at the verify positions lets the caller prove the collapse is exact).
-#include <hip/hip_runtime.h>
-#include <cmath>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
-#include "common.hpp"
-#include "kernels.hpp"
+#include "engine_base.hpp"
 
 namespace {
-
-thread_local std::string g_tls_error;
-
-struct HostTensor {
-  std::vector<bf16_t> data;
-  std::vector<int64_t> shape;
-  int64_t numel() const { int64_t n = 1; for (auto d : shape) n *= d; return n; }
-};
-
-struct Lin { bf16_t* W = nullptr; bf16_t* b = nullptr; int N = 0, K = 0; };
-struct VitBlock { bf16_t *ln1_g, *ln1_b, *ln2_g, *ln2_b; Lin qkv, out, fc1, fc2; };
-struct VitTower {
-  int image = 0, patch = 0, grid = 0, P = 0, N = 0, hidden = 0, heads = 0, mlp = 0, nblocks = 0, kpad = 0;
-  Lin patch_lin; bf16_t *cls = nullptr, *pos = nullptr, *pre_g = nullptr, *pre_b = nullptr;
-  std::vector<VitBlock> blocks;
-  // activations
-  bf16_t *im2col = nullptr, *patch_out = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp_buf = nullptr,
-         *vt = nullptr;
-  int Spad = 0;
-};
-struct LlmBlock { bf16_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; };
 struct SamAttn { Lin q, k, v, out; int internal; };
-struct SamLayer { SamAttn self_attn, t2i, i2t; bf16_t *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *n4g, *n4b; Lin lin1, lin2; };
-
-#define HIPCHK(expr)                                                                         \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess) {                                                                  \
-      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
-      return VSTAR_ERR_HIP;                                                                  \
-    }                                                                                        \
-  } while (0)
-
+struct SamLayer { SamAttn self_attn, t2i, i2t; lp_t *n1g, *n1b, *n2g, *n2b, *n3g, *n3b, *n4g, *n4b; Lin lin1, lin2; };
 }  // namespace
 
-struct vstar_engine {
+struct vstar_engine : EngineBase {
   vstar_config cfg{};
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::string error;
-  bool finalized = false;
-  std::map<std::string, HostTensor> staged;
-  std::vector<void*> allocs;
-
   // packed weights
   VitTower clip, owl;
   Lin projector;
-  bf16_t* embed = nullptr;
+  lp_t* embed = nullptr;
   std::vector<LlmBlock> llm;
-  bf16_t* final_norm = nullptr;
+  lp_t* final_norm = nullptr;
   Lin lm_head;
-  bf16_t* rope = nullptr;   // [Smax, 128] cos|sin bf16
+  lp_t* rope = nullptr;   // [Smax, 128] cos|sin bf16
   Lin det0, det1, seg0, seg1;
-  bf16_t *owl_post_g = nullptr, *owl_post_b = nullptr, *owl_ln_g = nullptr, *owl_ln_b = nullptr;
+  lp_t *owl_post_g = nullptr, *owl_post_b = nullptr, *owl_ln_g = nullptr, *owl_ln_b = nullptr;
   Lin cls_fused, box0, box1, box2;
   Lin vis_proj;
-  bf16_t *no_mask = nullptr, *dense_pe = nullptr, *iou_token = nullptr, *mask_tokens = nullptr;
+  lp_t *no_mask = nullptr, *dense_pe = nullptr, *iou_token = nullptr, *mask_tokens = nullptr;
   SamLayer sam_layers[2];
-  SamAttn sam_final; bf16_t *sam_nfg = nullptr, *sam_nfb = nullptr;
-  Lin conv1, conv2; bf16_t *ln2d_g = nullptr, *ln2d_b = nullptr;
+  SamAttn sam_final; lp_t *sam_nfg = nullptr, *sam_nfb = nullptr;
+  Lin conv1, conv2; lp_t *ln2d_g = nullptr, *ln2d_b = nullptr;
   Lin hyp0, hyp1, hyp2;
 
   // LLM activations
   int Smax = 0, llm_spad = 0;
-  bf16_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr, *lvt = nullptr;
-  bf16_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
-  bf16_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
+  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr, *lvt = nullptr;
+  lp_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
+  lp_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
   float* vlogits = nullptr;    // [B*V, vocab]
-  bf16_t *fc_tmp = nullptr, *emb_det = nullptr, *emb_seg = nullptr;
+  lp_t *fc_tmp = nullptr, *emb_det = nullptr, *emb_seg = nullptr;
   int32_t *d_ids = nullptr, *d_rowidx = nullptr, *d_argmax = nullptr;
-  bf16_t *d_clip_pix = nullptr, *d_owl_pix = nullptr;
+  lp_t *d_clip_pix = nullptr, *d_owl_pix = nullptr;
   // OWL / SAM activations
-  bf16_t *owl_feats_pre = nullptr, *owl_feats = nullptr, *box_t0 = nullptr, *box_t1 = nullptr;
+  lp_t *owl_feats_pre = nullptr, *owl_feats = nullptr, *box_t0 = nullptr, *box_t1 = nullptr;
   float *cls_emb = nullptr, *box_raw = nullptr;
-  bf16_t *s_src = nullptr, *s_keys = nullptr, *s_kpe = nullptr, *s_ia = nullptr, *s_ib = nullptr, *s_ic = nullptr;
-  bf16_t *s_tok0 = nullptr, *s_q = nullptr, *s_qpe = nullptr, *s_ta = nullptr, *s_tb = nullptr, *s_tc = nullptr, *s_td = nullptr,
+  lp_t *s_src = nullptr, *s_keys = nullptr, *s_kpe = nullptr, *s_ia = nullptr, *s_ib = nullptr, *s_ic = nullptr;
+  lp_t *s_tok0 = nullptr, *s_q = nullptr, *s_qpe = nullptr, *s_ta = nullptr, *s_tb = nullptr, *s_tc = nullptr, *s_td = nullptr,
          *s_mlp = nullptr;
-  bf16_t *s_col1 = nullptr, *s_c1 = nullptr, *s_c1n = nullptr, *s_col2 = nullptr, *s_c2 = nullptr, *s_hyp_in = nullptr,
+  lp_t *s_col1 = nullptr, *s_c1 = nullptr, *s_c1n = nullptr, *s_col2 = nullptr, *s_c2 = nullptr, *s_hyp_in = nullptr,
          *s_hyp_a = nullptr, *s_hyp_b = nullptr, *s_hyper = nullptr;
   int32_t* d_tokidx = nullptr;
   vstar_result* d_results = nullptr;
@@ -103,250 +55,20 @@ struct vstar_engine {
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
   int32_t* d_tables = nullptr; size_t tables_cap = 0;
   PreJob* d_jobs = nullptr;
-  bf16_t* d_lut = nullptr;
+  lp_t* d_lut = nullptr;
   std::vector<int32_t> h_tables;
   std::vector<PreJob> h_jobs;
   struct AxisTab { int off_b, off_c, ks; };
   int preprocess(int B, const int32_t* boxes);
   std::vector<int32_t> h_rowidx;
 
-  // profiling
-  bool profile = false;
-  std::vector<hipEvent_t> ev;
-  size_t ev_used = 0;
-  double prof_ms = 0, prof_flops = 0;
-  int64_t prof_launches = 0;
-  double pending_flops = 0;
-
-  void set_error(const std::string& m) { error = m; g_tls_error = m; }
-
-  template <typename T> int dalloc(T** p, size_t count) {
-    void* q = nullptr;
-    size_t bytes = count * sizeof(T);
-    if (bytes == 0) bytes = 16;
-    hipError_t e = hipMalloc(&q, bytes);
-    if (e != hipSuccess) { set_error("hipMalloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e)); return VSTAR_ERR_NOMEM; }
-    allocs.push_back(q);
-    *p = (T*)q;
-    return 0;
-  }
-  const HostTensor* find(const std::string& k) {
-    auto it = staged.find(k);
-    return it == staged.end() ? nullptr : &it->second;
-  }
-  int need(const std::string& k, const HostTensor** out) {
-    *out = find(k);
-    if (!*out) { set_error("missing checkpoint tensor: " + k); return VSTAR_ERR_MISSING; }
-    return 0;
-  }
-  int upload_vec(const std::string& k, bf16_t** dev, int64_t expect = -1) {
-    const HostTensor* t;
-    int rc = need(k, &t);
-    if (rc) return rc;
-    if (expect >= 0 && t->numel() != expect) { set_error("bad size for " + k); return VSTAR_ERR_INVALID; }
-    rc = dalloc(dev, (size_t)t->numel());
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(*dev, t->data.data(), t->numel() * 2, hipMemcpyHostToDevice));
-    return 0;
-  }
-  // Packs rows of several [n_i, K] matrices (optionally with biases) into one padded [Npad, Kpad] device matrix.
-  // perm: optional row permutation of the concatenated matrix (packed row r <- concat row perm[r]).
-  int make_lin(const std::vector<std::string>& wkeys, const std::vector<std::string>& bkeys, Lin* out, int K_expect = -1,
-               const std::vector<int>* perm = nullptr, bool conv3x3 = false, bool conv_patch = false) {
-    std::vector<const HostTensor*> ws;
-    int N = 0, K = -1;
-    for (auto& k : wkeys) {
-      const HostTensor* t;
-      int rc = need(k, &t);
-      if (rc) return rc;
-      int n = (int)t->shape[0];
-      int kk = (int)(t->numel() / n);
-      if (K < 0) K = kk;
-      if (kk != K) { set_error("K mismatch in " + k); return VSTAR_ERR_INVALID; }
-      ws.push_back(t);
-      N += n;
-    }
-    if (K_expect >= 0 && K != K_expect) { set_error("unexpected K for " + wkeys[0]); return VSTAR_ERR_INVALID; }
-    const int Kpad = (K + 63) / 64 * 64, Npad = (N + 255) / 256 * 256;
-    std::vector<bf16_t> host((size_t)Npad * Kpad, 0);
-    int r0 = 0;
-    for (auto* t : ws) {
-      const int n = (int)t->shape[0];
-      for (int r = 0; r < n; ++r) {
-        bf16_t* dst = &host[(size_t)(r0 + r) * Kpad];
-        const bf16_t* src = &t->data[(size_t)r * K];
-        if (conv3x3) {   // [O][C][3][3] -> [O][(ky*3+kx)*C + c]
-          const int C = K / 9;
-          for (int c = 0; c < C; ++c)
-            for (int tap = 0; tap < 9; ++tap) dst[tap * C + c] = src[c * 9 + tap];
-        } else {
-          (void)conv_patch;  // [O][C][ky][kx] flattens to c*ps*ps + ky*ps + kx, which is what im2col_patch emits
-          memcpy(dst, src, (size_t)K * 2);
-        }
-      }
-      r0 += n;
-    }
-    if (perm) {
-      std::vector<bf16_t> tmp((size_t)Npad * Kpad, 0);
-      for (int r = 0; r < N; ++r) memcpy(&tmp[(size_t)r * Kpad], &host[(size_t)(*perm)[r] * Kpad], (size_t)Kpad * 2);
-      host.swap(tmp);
-    }
-    int rc = dalloc(&out->W, host.size());
-    if (rc) return rc;
-    HIPCHK(hipMemcpy(out->W, host.data(), host.size() * 2, hipMemcpyHostToDevice));
-    out->N = N;
-    out->K = Kpad;
-    out->b = nullptr;
-    if (!bkeys.empty()) {
-      std::vector<bf16_t> hb((size_t)Npad, 0);
-      int o = 0;
-      for (auto& k : bkeys) {
-        const HostTensor* t;
-        rc = need(k, &t);
-        if (rc) return rc;
-        memcpy(&hb[o], t->data.data(), (size_t)t->numel() * 2);
-        o += (int)t->numel();
-      }
-      if (o != N) { set_error("bias size mismatch for " + wkeys[0]); return VSTAR_ERR_INVALID; }
-      if (perm) {
-        std::vector<bf16_t> tb((size_t)Npad, 0);
-        for (int r = 0; r < N; ++r) tb[r] = hb[(*perm)[r]];
-        hb.swap(tb);
-      }
-      rc = dalloc(&out->b, hb.size());
-      if (rc) return rc;
-      HIPCHK(hipMemcpy(out->b, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
-    }
-    return 0;
-  }
-
-  // ---- GEMM launch with optional event profiling ----
-  int gemm(const GemmParams& p, int epi, bool f32) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (profile) {
-      if (ev_used + 2 > ev.size()) {
-        for (int i = 0; i < 256; ++i) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
-      }
-      e0 = ev[ev_used++]; e1 = ev[ev_used++];
-      hipEventRecord(e0, stream);
-    }
-    hipError_t e = gemm_bf16(p, epi, f32, stream);
-    if (e != hipSuccess) { set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return VSTAR_ERR_HIP; }
-    if (profile) {
-      hipEventRecord(e1, stream);
-      pending_flops += 2.0 * p.M * (double)p.N * p.K;
-      prof_launches++;
-    }
-    return 0;
-  }
-  int lin(const bf16_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
-          const bf16_t* res = nullptr, int64_t ldr = 0, bool f32 = false) {
-    GemmParams p{};
-    p.A = A; p.lda = lda; p.a_group = 0;
-    p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr;
-    p.C = C; p.ldc = ldc; p.c_group = 0;
-    p.M = M; p.N = L.N; p.K = L.K;
-    return gemm(p, epi, f32);
-  }
-  void collect_profile() {
-    if (!profile) return;
-    for (size_t i = 0; i + 1 < ev_used; i += 2) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) prof_ms += ms;
-    }
-    prof_flops += pending_flops;
-    pending_flops = 0;
-    ev_used = 0;
-  }
-
-  int build_tower(VitTower& t, const std::string& pre, const std::string& preln_name, int image, int patch, int hidden,
-                  int heads, int mlp, int nblocks, int maxB);
-  int run_tower(VitTower& t, const bf16_t* pix, int B);
   int finalize();
-  int score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, const int32_t* ids, int L, const int32_t* loc_pos,
+  int score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* ids, int L, const int32_t* loc_pos,
             const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
-  int sam_attn(const SamAttn& a, const bf16_t* q_in, int nq, const bf16_t* k_in, const bf16_t* v_in, int nk, int B,
-               bf16_t* pq, bf16_t* pk, bf16_t* pv, bf16_t* att, bf16_t* out, const bf16_t* res);
+  int sam_attn(const SamAttn& a, const lp_t* q_in, int nq, const lp_t* k_in, const lp_t* v_in, int nk, int B,
+               lp_t* pq, lp_t* pk, lp_t* pv, lp_t* att, lp_t* out, const lp_t* res);
   int make_sam_attn(const std::string& pre, SamAttn* a);
 };
-
-#undef HIPCHK
-#define HIPCHK(expr)                                                                         \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess) {                                                                  \
-      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
-      return VSTAR_ERR_HIP;                                                                  \
-    }                                                                                        \
-  } while (0)
-#define RC(expr) do { int _rc = (expr); if (_rc) return _rc; } while (0)
-#define KCHK(expr)                                                                           \
-  do {                                                                                       \
-    hipError_t _e = (expr);                                                                  \
-    if (_e != hipSuccess) {                                                                  \
-      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
-      return VSTAR_ERR_HIP;                                                                  \
-    }                                                                                        \
-  } while (0)
-
-int vstar_engine::build_tower(VitTower& t, const std::string& pre, const std::string& preln_name, int image, int patch,
-                              int hidden, int heads, int mlp, int nblocks, int maxB) {
-  t.image = image; t.patch = patch; t.grid = image / patch; t.P = t.grid * t.grid; t.N = t.P + 1;
-  t.hidden = hidden; t.heads = heads; t.mlp = mlp; t.nblocks = nblocks;
-  if (hidden != heads * 64) { set_error("ViT head dim must be 64"); return VSTAR_ERR_INVALID; }
-  RC(make_lin({pre + "embeddings.patch_embedding.weight"}, {}, &t.patch_lin, 3 * patch * patch));
-  t.kpad = t.patch_lin.K;
-  RC(upload_vec(pre + "embeddings.class_embedding", &t.cls, hidden));
-  RC(upload_vec(pre + "embeddings.position_embedding.weight", &t.pos, (int64_t)t.N * hidden));
-  RC(upload_vec(pre + preln_name + ".weight", &t.pre_g, hidden));
-  RC(upload_vec(pre + preln_name + ".bias", &t.pre_b, hidden));
-  t.blocks.resize(nblocks);
-  for (int i = 0; i < nblocks; ++i) {
-    const std::string lp = pre + "encoder.layers." + std::to_string(i) + ".";
-    VitBlock& b = t.blocks[i];
-    RC(upload_vec(lp + "layer_norm1.weight", &b.ln1_g, hidden));
-    RC(upload_vec(lp + "layer_norm1.bias", &b.ln1_b, hidden));
-    RC(upload_vec(lp + "layer_norm2.weight", &b.ln2_g, hidden));
-    RC(upload_vec(lp + "layer_norm2.bias", &b.ln2_b, hidden));
-    RC(make_lin({lp + "self_attn.q_proj.weight", lp + "self_attn.k_proj.weight", lp + "self_attn.v_proj.weight"},
-                {lp + "self_attn.q_proj.bias", lp + "self_attn.k_proj.bias", lp + "self_attn.v_proj.bias"}, &b.qkv, hidden));
-    RC(make_lin({lp + "self_attn.out_proj.weight"}, {lp + "self_attn.out_proj.bias"}, &b.out, hidden));
-    RC(make_lin({lp + "mlp.fc1.weight"}, {lp + "mlp.fc1.bias"}, &b.fc1, hidden));
-    RC(make_lin({lp + "mlp.fc2.weight"}, {lp + "mlp.fc2.bias"}, &b.fc2, mlp));
-  }
-  const size_t rows = (size_t)maxB * t.N;
-  t.Spad = (t.N + 63) / 64 * 64;
-  RC(dalloc(&t.im2col, (size_t)maxB * t.P * t.kpad));
-  RC(dalloc(&t.patch_out, (size_t)maxB * t.P * hidden));
-  RC(dalloc(&t.x, rows * hidden));
-  RC(dalloc(&t.h, rows * hidden));
-  RC(dalloc(&t.qkv, rows * 3 * hidden));
-  RC(dalloc(&t.att, rows * hidden));
-  RC(dalloc(&t.mlp_buf, rows * mlp));
-  RC(dalloc(&t.vt, (size_t)maxB * hidden * t.Spad));
-  return 0;
-}
-
-// HF CLIPVisionTransformer / OwlViTVisionTransformer forward up to the last executed block (pre-LN blocks, quick-GELU)
-int vstar_engine::run_tower(VitTower& t, const bf16_t* pix, int B) {
-  const int C = t.hidden, rows = B * t.N;
-  KCHK(im2col_patch(pix, t.im2col, B, t.image, t.patch, t.kpad, stream));
-  RC(lin(t.im2col, t.kpad, t.patch_lin, t.patch_out, C, B * t.P));
-  KCHK(vit_assemble_tokens(t.patch_out, t.cls, t.pos, t.h, B, t.P, C, stream));
-  KCHK(layernorm_bf16(t.h, t.pre_g, t.pre_b, t.x, rows, C, 1e-5f, nullptr, 0, stream));
-  for (int i = 0; i < t.nblocks; ++i) {
-    VitBlock& b = t.blocks[i];
-    KCHK(layernorm_bf16(t.x, b.ln1_g, b.ln1_b, t.h, rows, C, 1e-5f, nullptr, 0, stream));
-    RC(lin(t.h, C, b.qkv, t.qkv, 3 * C, rows));
-    KCHK(attn_prepare(t.qkv, t.vt, nullptr, B, t.N, t.Spad, t.heads, 64, stream));
-    KCHK(attn_forward(t.qkv, t.vt, t.att, B, t.N, t.Spad, t.heads, 64, 0, 0.125f, stream));
-    RC(lin(t.att, C, b.out, t.x, C, rows, VSTAR_EPI_NONE, t.x, C));
-    KCHK(layernorm_bf16(t.x, b.ln2_g, b.ln2_b, t.h, rows, C, 1e-5f, nullptr, 0, stream));
-    RC(lin(t.h, C, b.fc1, t.mlp_buf, t.mlp, rows, VSTAR_EPI_QUICK_GELU));
-    RC(lin(t.mlp_buf, t.mlp, b.fc2, t.x, C, rows, VSTAR_EPI_NONE, t.x, C));
-  }
-  return 0;
-}
 
 int vstar_engine::make_sam_attn(const std::string& pre, SamAttn* a) {
   RC(make_lin({pre + "q_proj.weight"}, {pre + "q_proj.bias"}, &a->q, 256));
@@ -394,13 +116,13 @@ int vstar_engine::finalize() {
   Smax = c.max_text_len - 1 + clip.P;
   llm_spad = (Smax + 63) / 64 * 64;
   {  // rotate-half RoPE table, HF LlamaRotaryEmbedding: inv_freq = theta^(-2i/d), fp32, cast to bf16 before use
-    std::vector<bf16_t> tab((size_t)Smax * 128);
+    std::vector<lp_t> tab((size_t)Smax * 128);
     for (int s = 0; s < Smax; ++s)
       for (int i = 0; i < 64; ++i) {
         const float inv = 1.0f / powf(c.llm_rope_theta, (float)(2 * i) / 128.0f);
         const float f = (float)s * inv;
-        tab[(size_t)s * 128 + i] = f2bf(cosf(f));
-        tab[(size_t)s * 128 + 64 + i] = f2bf(sinf(f));
+        tab[(size_t)s * 128 + i] = f2lp(cosf(f));
+        tab[(size_t)s * 128 + 64 + i] = f2lp(sinf(f));
       }
     RC(dalloc(&rope, tab.size()));
     HIPCHK(hipMemcpy(rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
@@ -515,7 +237,7 @@ int vstar_engine::finalize() {
   RC(dalloc(&d_jobs, (size_t)maxB * 2));
   RC(dalloc(&d_lut, (size_t)3 * 256));
   {
-    bf16_t lut[3 * 256];
+    lp_t lut[3 * 256];
     clip_norm_lut(lut);
     HIPCHK(hipMemcpy(d_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
   }
@@ -591,8 +313,8 @@ int vstar_engine::preprocess(int B, const int32_t* boxes) {
 }
 
 // segment_anything Attention.forward (transformer.py:220-242): proj -> heads -> softmax(qk/sqrt(c)) v -> out_proj (+res)
-int vstar_engine::sam_attn(const SamAttn& a, const bf16_t* q_in, int nq, const bf16_t* k_in, const bf16_t* v_in, int nk,
-                           int B, bf16_t* pq, bf16_t* pk, bf16_t* pv, bf16_t* att, bf16_t* out, const bf16_t* res) {
+int vstar_engine::sam_attn(const SamAttn& a, const lp_t* q_in, int nq, const lp_t* k_in, const lp_t* v_in, int nk,
+                           int B, lp_t* pq, lp_t* pk, lp_t* pv, lp_t* att, lp_t* out, const lp_t* res) {
   const int I = a.internal;
   RC(lin(q_in, 256, a.q, pq, I, B * nq));
   RC(lin(k_in, 256, a.k, pk, I, B * nk));
@@ -603,7 +325,7 @@ int vstar_engine::sam_attn(const SamAttn& a, const bf16_t* q_in, int nq, const b
 }
 
 namespace {
-__global__ void sam_tokens_kernel(const bf16_t* iou, const bf16_t* mask_tokens, const bf16_t* seg, bf16_t* out, int B) {
+__global__ void sam_tokens_kernel(const lp_t* iou, const lp_t* mask_tokens, const lp_t* seg, lp_t* out, int B) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * 6 * 256) return;
   const int c = (int)(idx % 256), t = (int)((idx / 256) % 6), b = (int)(idx / (6 * 256));
@@ -611,7 +333,7 @@ __global__ void sam_tokens_kernel(const bf16_t* iou, const bf16_t* mask_tokens, 
 }
 }  // namespace
 
-int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, const int32_t* ids, int L,
+int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* ids, int L,
                         const int32_t* loc_pos, const int32_t* verify_pos, int n_verify, unsigned flags,
                         vstar_result* out) {
   if (!finalized) { set_error("vstar_finalize_weights has not been called"); return VSTAR_ERR_STATE; }
@@ -648,7 +370,7 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
   }
   HIPCHK(hipMemcpyAsync(d_ids, ids, (size_t)B * L * 4, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
-  const bf16_t *cpix = clip_pix, *opix = owl_pix;
+  const lp_t *cpix = clip_pix, *opix = owl_pix;
   if (internal_pix) {
     cpix = d_clip_pix;   // filled by vstar_preprocess_crops on this stream
     opix = d_owl_pix;
@@ -683,7 +405,7 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
   const int nsel = B * (1 + n_verify);
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
-    KCHK(rmsnorm_bf16(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+    KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
     KCHK(attn_prepare(lqkv, lvt, rope, B, S, Spad, c.llm_heads, 128, stream));
     KCHK(attn_forward(lqkv, lvt, latt, B, S, Spad, c.llm_heads, 128, 1, att_scale, stream));
@@ -693,18 +415,18 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
       KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
       KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
       RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
-      KCHK(rmsnorm_bf16(sel_x, b.post_norm, sel_h, nsel, H, c.llm_rms_eps, nullptr, stream));
+      KCHK(rmsnorm_lp(sel_x, b.post_norm, sel_h, nsel, H, c.llm_rms_eps, nullptr, stream));
       RC(lin(sel_h, H, b.gate_up, sel_act, c.llm_mlp, nsel, VSTAR_EPI_SILU_MUL));
       RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
       break;
     }
     RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-    KCHK(rmsnorm_bf16(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+    KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
     RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
   }
   // ---- a6/a7: final norm on the needed rows only, lm_head argmax at the verify rows, [LOC]-1 gather ----
-  KCHK(rmsnorm_bf16(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));
+  KCHK(rmsnorm_lp(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));
   if (n_verify > 0) {
     RC(lin(hsel + (size_t)B * H, H, lm_head, vlogits, c.llm_vocab, B * n_verify, VSTAR_EPI_NONE, nullptr, 0, true));
     KCHK(argmax_rows(vlogits, B * n_verify, c.llm_vocab, c.llm_vocab, d_argmax, 1, stream));
@@ -721,9 +443,9 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
     float* res_f = (float*)d_results;
     // ---- a9: OWL-ViT tower + get_visual_embs (owlvit.py:121-148) ----
     RC(run_tower(owl, opix, B));
-    KCHK(layernorm_bf16(owl.x, owl_post_g, owl_post_b, owl.h, B * owl.N, OH, 1e-5f, nullptr, 0, stream));
+    KCHK(layernorm_lp(owl.x, owl_post_g, owl_post_b, owl.h, B * owl.N, OH, 1e-5f, nullptr, 0, stream));
     KCHK(owl_cls_mul(owl.h, owl_feats_pre, B, owl.N, OH, stream));
-    KCHK(layernorm_bf16(owl_feats_pre, owl_ln_g, owl_ln_b, owl_feats, prow, OH, 1e-5f, nullptr, 0, stream));
+    KCHK(layernorm_lp(owl_feats_pre, owl_ln_g, owl_ln_b, owl_feats, prow, OH, 1e-5f, nullptr, 0, stream));
     // ---- a10: class + box heads (owlvit.py:150-170) ----
     const int cld = cls_fused.N + 2;
     RC(lin(owl_feats, OH, cls_fused, cls_emb, cld, prow, VSTAR_EPI_NONE, nullptr, 0, true));
@@ -750,25 +472,25 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
         KCHK(add_bcast(s_q, s_tok0, s_mlp, trow, 256, trow, stream));           // q = queries + query_pe
         RC(sam_attn(Ly.self_attn, s_mlp, T, s_mlp, s_q, T, B, s_ta, s_tb, s_tc, s_td, s_qpe, s_q));
       }
-      KCHK(layernorm_bf16(s_qpe, Ly.n1g, Ly.n1b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+      KCHK(layernorm_lp(s_qpe, Ly.n1g, Ly.n1b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
       // (2) tokens -> image cross attention
       KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));             // q = queries + query_pe
       KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));          // k = keys + key_pe
       RC(sam_attn(Ly.t2i, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
-      KCHK(layernorm_bf16(s_tb, Ly.n2g, Ly.n2b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+      KCHK(layernorm_lp(s_tb, Ly.n2g, Ly.n2b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
       // (3) MLP on tokens
       RC(lin(s_q, 256, Ly.lin1, s_mlp, Ly.lin1.N, trow, VSTAR_EPI_RELU));
       RC(lin(s_mlp, Ly.lin1.N, Ly.lin2, s_tb, 256, trow, VSTAR_EPI_NONE, s_q, 256));
-      KCHK(layernorm_bf16(s_tb, Ly.n3g, Ly.n3b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+      KCHK(layernorm_lp(s_tb, Ly.n3g, Ly.n3b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
       // (4) image -> tokens cross attention (q = keys + key_pe, k = queries + query_pe, v = queries)
       KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
       RC(sam_attn(Ly.i2t, s_kpe, NP, s_qpe, s_q, T, B, s_ia, s_ta, s_tb, s_ib, s_ic, s_keys));
-      KCHK(layernorm_bf16(s_ic, Ly.n4g, Ly.n4b, s_keys, prow, 256, 1e-5f, nullptr, 0, stream));
+      KCHK(layernorm_lp(s_ic, Ly.n4g, Ly.n4b, s_keys, prow, 256, 1e-5f, nullptr, 0, stream));
     }
     KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
     KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));
     RC(sam_attn(sam_final, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
-    KCHK(layernorm_bf16(s_tb, sam_nfg, sam_nfb, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+    KCHK(layernorm_lp(s_tb, sam_nfg, sam_nfb, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
     // hypernetwork MLP 0 on mask token 0 (= token row 1)
     KCHK(gather_rows(s_q, d_tokidx, s_hyp_in, B, 256, stream));
     RC(lin(s_hyp_in, 256, hyp0, s_hyp_a, 256, B, VSTAR_EPI_RELU));
@@ -777,7 +499,7 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
     // output_upscaling: Upsample(256->64) LN2d GELU Upsample(64->32) GELU (mask_decoder.py:78-84)
     KCHK(upsample2x_im2col3x3(s_keys, s_col1, B, 48, 48, 256, stream));
     RC(lin(s_col1, 2304, conv1, s_c1, 64, B * 96 * 96));
-    KCHK(layernorm_bf16(s_c1, ln2d_g, ln2d_b, s_c1n, B * 96 * 96, 64, 1e-6f, nullptr, 1, stream));
+    KCHK(layernorm_lp(s_c1, ln2d_g, ln2d_b, s_c1n, B * 96 * 96, 64, 1e-6f, nullptr, 1, stream));
     KCHK(upsample2x_im2col3x3(s_c1n, s_col2, B, 96, 96, 64, stream));
     RC(lin(s_col2, 576, conv2, s_c2, 32, B * 192 * 192, VSTAR_EPI_GELU));
     KCHK(hyper_mask(s_hyper, s_c2, res_f + offsetof(vstar_result, lowres_mask) / 4, rstride, B, 192 * 192, 32, stream));
@@ -805,20 +527,20 @@ int vstar_engine::score(int B, const bf16_t* clip_pix, const bf16_t* owl_pix, co
 extern "C" {
 
 int vstar_create(const vstar_config* cfg, int device, vstar_handle** out) {
-  if (!cfg || !out) { g_tls_error = "null argument"; return VSTAR_ERR_INVALID; }
-  if (cfg->abi_version != VSTAR_ABI_VERSION) { g_tls_error = "ABI version mismatch"; return VSTAR_ERR_INVALID; }
-  if (cfg->max_batch <= 0 || cfg->max_text_len < 2) { g_tls_error = "bad limits"; return VSTAR_ERR_INVALID; }
+  if (!cfg || !out) { tls_error() = "null argument"; return VSTAR_ERR_INVALID; }
+  if (cfg->abi_version != VSTAR_ABI_VERSION) { tls_error() = "ABI version mismatch"; return VSTAR_ERR_INVALID; }
+  if (cfg->max_batch <= 0 || cfg->max_text_len < 2) { tls_error() = "bad limits"; return VSTAR_ERR_INVALID; }
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || device < 0 || device >= n) {
-    g_tls_error = "no such HIP device (libvstar_hip has no CPU fallback)";
+    tls_error() = "no such HIP device (libvstar_hip has no CPU fallback)";
     return VSTAR_ERR_HIP;
   }
   vstar_engine* h = new vstar_engine();
   h->cfg = *cfg;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
-    g_tls_error = "hipStreamCreate failed";
+    tls_error() = "hipStreamCreate failed";
     delete h;
     return VSTAR_ERR_HIP;
   }
@@ -830,64 +552,37 @@ void vstar_destroy(vstar_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
-  for (void* p : h->allocs) hipFree(p);
+  h->release_base();
   if (h->d_stats) hipFree(h->d_stats);
   if (h->d_image) hipFree(h->d_image);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
-  for (auto e : h->ev) hipEventDestroy(e);
   hipStreamDestroy(h->stream);
   delete h;
 }
 
-const char* vstar_last_error(const vstar_handle* h) { return h ? h->error.c_str() : g_tls_error.c_str(); }
+const char* vstar_last_error(const vstar_handle* h) { return h ? h->error.c_str() : tls_error().c_str(); }
 
 int vstar_load_tensor(vstar_handle* h, const char* key, const void* host_ptr, int dtype, int ndim, const int64_t* shape) {
-  if (!h || !key || !host_ptr || ndim < 0 || ndim > 8 || (ndim && !shape)) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
+  if (!h || !key || !host_ptr || ndim < 0 || ndim > 8 || (ndim && !shape)) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   if (h->finalized) { h->set_error("weights already finalized"); return VSTAR_ERR_STATE; }
-  HostTensor t;
-  t.shape.assign(shape, shape + ndim);
-  const int64_t n = t.numel();
-  t.data.resize((size_t)n);
-  if (dtype == VSTAR_BF16) {
-    memcpy(t.data.data(), host_ptr, (size_t)n * 2);
-  } else if (dtype == VSTAR_F32) {
-    const float* s = (const float*)host_ptr;
-    for (int64_t i = 0; i < n; ++i) t.data[i] = f2bf(s[i]);
-  } else if (dtype == VSTAR_F16) {
-    const uint16_t* s = (const uint16_t*)host_ptr;
-    for (int64_t i = 0; i < n; ++i) {
-      const uint16_t hb = s[i];
-      const uint32_t sign = (hb & 0x8000u) << 16;
-      uint32_t exp = (hb >> 10) & 0x1f, man = hb & 0x3ff;
-      uint32_t bits;
-      if (exp == 0) {
-        if (man == 0) bits = sign;
-        else { int sh = 0; while (!(man & 0x400)) { man <<= 1; sh++; } man &= 0x3ff; bits = sign | ((127 - 15 - sh + 1) << 23) | (man << 13); }
-      } else if (exp == 31) bits = sign | 0x7f800000u | (man << 13);
-      else bits = sign | ((exp - 15 + 127) << 23) | (man << 13);
-      float f; memcpy(&f, &bits, 4);
-      t.data[i] = f2bf(f);
-    }
-  } else { h->set_error("unknown dtype"); return VSTAR_ERR_INVALID; }
-  h->staged[key] = std::move(t);
-  return VSTAR_OK;
+  return h->stage_tensor(key, host_ptr, dtype, ndim, shape);
 }
 
 int vstar_finalize_weights(vstar_handle* h) {
-  if (!h) { g_tls_error = "null handle"; return VSTAR_ERR_INVALID; }
+  if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->finalize();
 }
 
 int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, const uint16_t* owl_pix, const int32_t* ids,
                           int L, const int32_t* loc_pos, const int32_t* verify_pos, int n_verify, unsigned flags,
                           vstar_result* out) {
-  if (!h) { g_tls_error = "null handle"; return VSTAR_ERR_INVALID; }
+  if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->score(B, clip_pix, owl_pix, ids, L, loc_pos, verify_pos, n_verify, flags, out);
 }
 
 int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) {
-  if (!h || !rgb || height <= 0 || width <= 0) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
+  if (!h || !rgb || height <= 0 || width <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
   const size_t bytes = (size_t)height * width * 3;
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
@@ -905,14 +600,14 @@ int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) 
 }
 
 int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy) {
-  if (!h) { g_tls_error = "null handle"; return VSTAR_ERR_INVALID; }
+  if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->preprocess(B, boxes_xyxy);
 }
 
 int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_out, int n_rects, const int32_t* rects_xywh,
                         double* out) {
   if (!h || !lowres || !out || h_out <= 0 || w_out <= 0 || n_rects < 0 || n_rects > 8 || (n_rects && !rects_xywh)) {
-    g_tls_error = "bad argument";
+    tls_error() = "bad argument";
     return VSTAR_ERR_INVALID;
   }
   hipSetDevice(h->device);
@@ -931,7 +626,7 @@ int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_o
 }
 
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out) {
-  if (!h || !lowres || !out || h_out <= 0 || w_out <= 0) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
+  if (!h || !lowres || !out || h_out <= 0 || w_out <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
   float *din = nullptr, *dout = nullptr;
   const size_t nin = (size_t)VSTAR_MASK_RES * VSTAR_MASK_RES, nout = (size_t)h_out * w_out;
@@ -954,14 +649,14 @@ int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_o
 }
 
 int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t cap) {
-  if (!h || !name || !out) { g_tls_error = "bad argument"; return VSTAR_ERR_INVALID; }
+  if (!h || !name || !out) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   if (!h->finalized) { h->set_error("weights not finalized"); return VSTAR_ERR_STATE; }
   hipSetDevice(h->device);
   const bool pix = !strcmp(name, "clip_pixels") || !strcmp(name, "owl_pixels");
   if (!pix && h->last_B == 0) { h->set_error("no forward has run"); return VSTAR_ERR_STATE; }
   const int B = pix ? (int)h->h_jobs.size() / 2 : h->last_B;
   const std::string n(name);
-  const bf16_t* src = nullptr;
+  const lp_t* src = nullptr;
   int64_t cnt = 0;
   if (n == "clip_pixels") { src = h->d_clip_pix; cnt = (int64_t)B * 3 * h->cfg.clip_image_size * h->cfg.clip_image_size; }
   else if (n == "owl_pixels") { src = h->d_owl_pix; cnt = (int64_t)B * 3 * h->cfg.owl_image_size * h->cfg.owl_image_size; }
@@ -975,13 +670,13 @@ int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t 
   else if (n == "sam_keys") { src = h->s_keys; cnt = (int64_t)B * h->owl.P * 256; }
   else { h->set_error("unknown debug tensor: " + n); return VSTAR_ERR_INVALID; }
   if (cnt > cap) cnt = cap;
-  std::vector<bf16_t> tmp((size_t)cnt);
+  std::vector<lp_t> tmp((size_t)cnt);
   if (hipStreamSynchronize(h->stream) != hipSuccess ||
       hipMemcpy(tmp.data(), src, (size_t)cnt * 2, hipMemcpyDeviceToHost) != hipSuccess) {
     h->set_error("debug_read: HIP failure");
     return VSTAR_ERR_HIP;
   }
-  for (int64_t i = 0; i < cnt; ++i) out[i] = bf2f(tmp[(size_t)i]);
+  for (int64_t i = 0; i < cnt; ++i) out[i] = lp2f(tmp[(size_t)i]);
   return cnt;
 }
 
@@ -1006,7 +701,7 @@ int vstar_profile_read(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches,
 
 // ---------------- operator-level entry points ----------------
 static int op_rc(hipError_t e) {
-  if (e != hipSuccess) { g_tls_error = std::string("HIP: ") + hipGetErrorString(e); return VSTAR_ERR_HIP; }
+  if (e != hipSuccess) { tls_error() = std::string("HIP: ") + hipGetErrorString(e); return VSTAR_ERR_HIP; }
   return VSTAR_OK;
 }
 
@@ -1018,18 +713,18 @@ int vstar_op_gemm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* 
   p.M = M; p.N = N; p.K = K;
   { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   const bool nosync = (epilogue & VSTAR_EPI_NOSYNC) != 0;
-  hipError_t e = gemm_bf16(p, epilogue & 0xff, out_f32 != 0, (hipStream_t)stream);
+  hipError_t e = gemm_lp(p, epilogue & 0xff, out_f32 != 0, (hipStream_t)stream);
   if (e == hipSuccess && !nosync) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
 int vstar_op_layernorm(void* stream, const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y, int rows,
                        int cols, float eps) {
-  hipError_t e = layernorm_bf16(x, g, b, y, rows, cols, eps, nullptr, 0, (hipStream_t)stream);
+  hipError_t e = layernorm_lp(x, g, b, y, rows, cols, eps, nullptr, 0, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
 int vstar_op_rmsnorm(void* stream, const uint16_t* x, const uint16_t* g, uint16_t* y, int rows, int cols, float eps) {
-  hipError_t e = rmsnorm_bf16(x, g, y, rows, cols, eps, nullptr, (hipStream_t)stream);
+  hipError_t e = rmsnorm_lp(x, g, y, rows, cols, eps, nullptr, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
@@ -1039,19 +734,19 @@ size_t vstar_op_attention_workspace(int B, int S, int H, int D) {
 }
 int vstar_op_attention(void* stream, uint16_t* qkv, uint16_t* out, void* ws, size_t ws_bytes, int B, int S, int H, int D,
                        int causal, float rope_theta) {
-  if (ws_bytes < vstar_op_attention_workspace(B, S, H, D)) { g_tls_error = "attention workspace too small"; return VSTAR_ERR_INVALID; }
+  if (ws_bytes < vstar_op_attention_workspace(B, S, H, D)) { tls_error() = "attention workspace too small"; return VSTAR_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   const int Spad = (S + 63) / 64 * 64;
-  bf16_t* vt = (bf16_t*)ws;
-  bf16_t* cs = nullptr;
+  lp_t* vt = (lp_t*)ws;
+  lp_t* cs = nullptr;
   if (rope_theta > 0.f) {
     cs = vt + (((size_t)B * H * D * Spad + 127) / 128 * 128);
-    std::vector<bf16_t> tab((size_t)S * D);
+    std::vector<lp_t> tab((size_t)S * D);
     for (int p = 0; p < S; ++p)
       for (int i = 0; i < D / 2; ++i) {
         const float inv = 1.0f / powf(rope_theta, (float)(2 * i) / (float)D);
-        tab[(size_t)p * D + i] = f2bf(cosf((float)p * inv));
-        tab[(size_t)p * D + D / 2 + i] = f2bf(sinf((float)p * inv));
+        tab[(size_t)p * D + i] = f2lp(cosf((float)p * inv));
+        tab[(size_t)p * D + D / 2 + i] = f2lp(sinf((float)p * inv));
       }
     hipError_t e = hipMemcpy(cs, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
     if (e != hipSuccess) return op_rc(e);

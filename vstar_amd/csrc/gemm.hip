@@ -12,13 +12,15 @@
 // ds_read_b128 lane group touches 16 distinct 16-B slots (conflict-free).  global_load_lds writes
 // lane-linear, so the swizzle is applied on the per-lane SOURCE address and again on the read address.
 // MFMA operands are swapped (W fragment as "A", activation fragment as "B") so that each lane ends up
-// with 4 consecutive output COLUMNS of one row -> 8-byte bf16x4 / 16-byte f32x4 stores, and bias/residual
+// with 4 consecutive output COLUMNS of one row -> 8-byte lpx4 / 16-byte f32x4 stores, and bias/residual
 // loads of the same shape.  Workgroup ids are remapped XCD-aware (bijective) + grouped along M so that
 // blocks sharing an L2 share weight columns.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
 #include <cstdlib>
+
+namespace VS_NS {
 
 namespace {
 
@@ -35,7 +37,7 @@ __device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, in
 }
 
 template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,8 +66,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
   // ---- per-lane staging sources (4 x 1-KiB DMA pieces per operand per wave) ----
   const int st_r = lane >> 3;      // row within the 8-row piece
   const int st_c = lane & 7;       // 16-B chunk within the 128-B LDS row
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
+  const lp_t* a_src[4];
+  const lp_t* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i * 4 + wave) * 8 + st_r;          // LDS row 0..127
@@ -114,16 +116,16 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
     const char* base = smem + cur * LDS_BUF;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], wf[4];
+      lpx8 af[4], wf[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
+      for (int m = 0; m < 4; ++m) af[m] = *(const lpx8*)(base + a_rd[kk] + m * 2048);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) wf[n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
+      for (int n = 0; n < 4; ++n) wf[n] = *(const lpx8*)(base + w_rd[kk] + n * 2048);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[n], af[m], acc[m][n], 0, 0, 0);
+          acc[m][n] = mfma_16x16x32(wf[n], af[m], acc[m][n]);
     }
     __syncthreads();   // next tile landed (vmcnt(0)) + everyone done reading buf[cur]
   }
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmParams p) {
 template <int EPI, bool OUT_F32>
 hipError_t launch(const GemmParams& p, hipStream_t s) {
   static bool attr_done = false;
-  auto kern = gemm_bf16_kernel<EPI, OUT_F32>;
+  auto kern = gemm128_kernel<EPI, OUT_F32>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return e;
@@ -164,14 +166,14 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 }  // namespace
 
 bool gemm256_eligible(const GemmParams& p);
-hipError_t gemm256_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 
-hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % BK != 0 || p.K <= 0) return hipErrorInvalidValue;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  if (force != 128 && gemm256_eligible(p)) return gemm256_bf16(p, epilogue, out_f32, s);   // W is padded to 256 rows
+  if (force != 128 && gemm256_eligible(p)) return gemm256_lp(p, epilogue, out_f32, s);   // W is padded to 256 rows
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);
@@ -185,3 +187,5 @@ hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_
 #undef GEMM_CASE
   return hipErrorInvalidValue;
 }
+
+}  // namespace VS_NS

@@ -20,6 +20,8 @@
 #include "gemm_epilogue.hpp"
 #include <type_traits>
 
+namespace VS_NS {
+
 namespace {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   auto issue_piece = [&](auto jc, int T) {
     constexpr int J = decltype(jc)::value;
     char* base = smem + (T & 1) * TILE_BYTES;
-    const bf16_t* gb = ((J == 0 || J == 3) ? p.A : p.W) + T * BK;
+    const lp_t* gb = ((J == 0 || J == 3) ? p.A : p.W) + T * BK;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_global_load_lds((gptr_t)(gb + src_off[J][u]), (lptr_t)(base + lds_off[J][u]), 16, 0, 0);
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // DMA: phase A(T) issues pieces 4T+6, 4T+7 (w1, a1 of tile T+1), phase B(T) issues 4T+8, 4T+9 (a0, w0 of tile T+2) —
   // each overwrites a region whose last reader retired at least one phase (= one barrier on both groups) earlier — and
   // waits until everything the NEXT phase reads has landed: vmcnt(8) in A (4 pieces may stay in flight), vmcnt(6) in B.
-  bf16x8 af[8], w0f[4], w1f[4];
+  lpx8 af[8], w0f[4], w1f[4];
   const int nkt = p.K / BK;
   for (int T = 0; T < nkt; ++T) {
     const char* base = smem + (T & 1) * TILE_BYTES;
@@ -158,10 +160,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
       _Pragma("unroll") for (int m = 0; m < 4; ++m)                                      \
         _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                  \
-          acc[(mh) * 4 + m][(nha) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
-              WFA[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nha) * 2 + n], 0, 0, 0); \
-          acc[(mh) * 4 + m][(nhb) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
-              WFB[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n], 0, 0, 0); \
+          acc[(mh) * 4 + m][(nha) * 2 + n] = mfma_16x16x32(    \
+              WFA[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nha) * 2 + n]);          \
+          acc[(mh) * 4 + m][(nhb) * 2 + n] = mfma_16x16x32(    \
+              WFB[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n]);          \
         }                                                                                \
     __builtin_amdgcn_s_setprio(0);                                                       \
     BAR();                                                                               \
@@ -171,13 +173,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        w0f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + n * 2048);
-        w1f[kk * 2 + n] = *(const bf16x8*)(base + w_rd[kk] + (2 + n) * 2048);
+        w0f[kk * 2 + n] = *(const lpx8*)(base + w_rd[kk] + n * 2048);
+        w1f[kk * 2 + n] = *(const lpx8*)(base + w_rd[kk] + (2 + n) * 2048);
       }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + m * 2048);
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const lpx8*)(base + a_rd[kk] + m * 2048);
     if (T + 1 < nkt) {
       issue_piece(std::integral_constant<int, 2>{}, T + 1);
       issue_piece(std::integral_constant<int, 3>{}, T + 1);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const bf16x8*)(base + a_rd[kk] + (4 + m) * 2048);
+      for (int m = 0; m < 4; ++m) af[kk * 4 + m] = *(const lpx8*)(base + a_rd[kk] + (4 + m) * 2048);
     if (T + 2 < nkt) {
       issue_piece(std::integral_constant<int, 0>{}, T + 2);
       issue_piece(std::integral_constant<int, 1>{}, T + 2);
@@ -244,9 +246,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       int bc = colbase + f * 16 + fq * 4;
       bc = bc + 4 <= n_out ? bc : (n_out - 4 > 0 ? n_out - 4 : 0);
       if (EPI != VSTAR_EPI_SILU_MUL && p.bias) {
-        const bf16x4 b = *(const bf16x4*)(p.bias + bc);
+        const lpx4 b = *(const lpx4*)(p.bias + bc);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bias_v[f][e] = bf2f((bf16_t)b[e]);
+        for (int e = 0; e < 4; ++e) bias_v[f][e] = lp2f((lp_t)b[e]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias_v[f][e] = 0.f;
@@ -259,23 +261,23 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-          bf16x4 v;
+          lpx4 v;
           if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = (short)f2bf(act_silu_bf16(rbf(acc[mh * 4 + m][2 * f][e])) * rbf(acc[mh * 4 + m][2 * f + 1][e]));
+              v[e] = (short)f2lp(act_silu_bf16(rlp(acc[mh * 4 + m][2 * f][e])) * rlp(acc[mh * 4 + m][2 * f + 1][e]));
           } else {   // stage 1 = bf16(acc + bias); the activation is applied after the transpose
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (short)f2bf(acc[mh * 4 + m][f][e] + bias_v[f][e]);
+            for (int e = 0; e < 4; ++e) v[e] = (short)f2lp(acc[mh * 4 + m][f][e] + bias_v[f][e]);
           }
-          *(bf16x4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
+          *(lpx4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
       for (int it = 0; it < 64 / RPI; ++it) {
         const int rl = it * RPI + rl0;
-        const bf16x8 v = *(const bf16x8*)(slab + rl * RSTRIDE + ch * 16);
+        const lpx8 v = *(const lpx8*)(slab + rl * RSTRIDE + ch * 16);
         const int row = m0 + wr * 128 + mh * 64 + rl;
         if (row < p.M && !(p.debug_flags & 1)) {
           const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
@@ -324,7 +326,7 @@ bool gemm256_eligible(const GemmParams& p) {
   return true;
 }
 
-hipError_t gemm256_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);
@@ -338,3 +340,5 @@ hipError_t gemm256_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStre
 #undef GEMM_CASE
   return hipErrorInvalidValue;
 }
+
+}  // namespace VS_NS

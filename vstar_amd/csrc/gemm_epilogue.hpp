@@ -1,8 +1,10 @@
 // gemm_epilogue.hpp — shared GEMM epilogue: one 16x16 accumulator fragment slice (4 consecutive output columns of
-// one row) -> bias, activation with the reference's bf16 rounding points, residual, bf16x4 / f32x4 store.
+// one row) -> bias, activation with the reference's bf16 rounding points, residual, lpx4 / f32x4 store.
 #pragma once
 #include "common.hpp"
 #include "kernels.hpp"
+
+namespace VS_NS {
 
 __device__ __forceinline__ int64_t gemm_map_row(int r, int group, int64_t gstride, int64_t off) {
   if (group <= 0) return (int64_t)r;
@@ -18,24 +20,24 @@ __device__ __forceinline__ void gemm_epilogue_values(const GemmParams& p, int co
   const bool full = (col + 3 < n_out);
   if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = act_silu_bf16(rbf(a[e])) * rbf(u[e]);
+    for (int e = 0; e < 4; ++e) o[e] = act_silu_bf16(rlp(a[e])) * rlp(u[e]);
     return;
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) o[e] = a[e];
   if (p.bias) {
     if (full) {
-      const bf16x4 b = *(const bf16x4*)(p.bias + col);
+      const lpx4 b = *(const lpx4*)(p.bias + col);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)b[e]);
+      for (int e = 0; e < 4; ++e) o[e] += lp2f((lp_t)b[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(p.bias[col + e]);
+      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += lp2f(p.bias[col + e]);
     }
   }
   if (!OUT_F32) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);       // nn.Linear output is bf16 in the reference
+    for (int e = 0; e < 4; ++e) o[e] = rlp(o[e]);       // nn.Linear output is bf16 in the reference
   }
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
@@ -58,18 +60,18 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
   float o[4];
   gemm_epilogue_values<EPI, OUT_F32>(p, col, n_out, a, u, o);
   if (p.res) {
-    const bf16_t* rp = p.res + crow * p.ldr + col;
+    const lp_t* rp = p.res + crow * p.ldr + col;
     if (!OUT_F32) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rbf(o[e]);     // activation output rounded before the add
+      for (int e = 0; e < 4; ++e) o[e] = rlp(o[e]);     // activation output rounded before the add
     }
     if (full) {
-      const bf16x4 rv = *(const bf16x4*)rp;
+      const lpx4 rv = *(const lpx4*)rp;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] += bf2f((bf16_t)rv[e]);
+      for (int e = 0; e < 4; ++e) o[e] += lp2f((lp_t)rv[e]);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += bf2f(rp[e]);
+      for (int e = 0; e < 4; ++e) if (col + e < n_out) o[e] += lp2f(rp[e]);
     }
   }
   if (OUT_F32) {
@@ -81,13 +83,13 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
       for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = o[e];
     }
   } else {
-    bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
+    lp_t* c = (lp_t*)p.C + crow * p.ldc + col;
     if (full && ((((uintptr_t)c) & 7) == 0)) {
-      bf16x4 v = {(short)f2bf(o[0]), (short)f2bf(o[1]), (short)f2bf(o[2]), (short)f2bf(o[3])};
-      *(bf16x4*)c = v;
+      lpx4 v = {(short)f2lp(o[0]), (short)f2lp(o[1]), (short)f2lp(o[2]), (short)f2lp(o[3])};
+      *(lpx4*)c = v;
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2bf(o[e]);
+      for (int e = 0; e < 4; ++e) if (col + e < n_out) c[e] = f2lp(o[e]);
     }
   }
 }
@@ -97,35 +99,37 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 // instead of 32-byte fragments.  The transcendental activations live here (static 8-element bodies) so that the
 // accumulator-indexed stage-1 loops stay small enough to unroll (a runtime-indexed acc[] would go to scratch).
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, bf16x8 v) {
+__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8 v) {
   if (col >= n_out) return;
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(act_quick_gelu_bf16(bf2f((bf16_t)v[e])));
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(act_quick_gelu_bf16(lp2f((lp_t)v[e])));
   } else if (EPI == VSTAR_EPI_GELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(act_gelu_erf(bf2f((bf16_t)v[e])));
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(act_gelu_erf(lp2f((lp_t)v[e])));
   } else if (EPI == VSTAR_EPI_RELU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(fmaxf(bf2f((bf16_t)v[e]), 0.f));
+    for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(fmaxf(lp2f((lp_t)v[e]), 0.f));
   }
-  bf16_t* c = (bf16_t*)p.C + crow * p.ldc + col;
+  lp_t* c = (lp_t*)p.C + crow * p.ldc + col;
   const bool full = (col + 7 < n_out) && ((((uintptr_t)c) & 15) == 0);
   if (p.res) {
-    const bf16_t* rp = p.res + crow * p.ldr + col;
+    const lp_t* rp = p.res + crow * p.ldr + col;
     if (full && ((((uintptr_t)rp) & 15) == 0)) {
-      const bf16x8 rv = *(const bf16x8*)rp;
+      const lpx8 rv = *(const lpx8*)rp;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f((bf16_t)rv[e]));
+      for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(lp2f((lp_t)v[e]) + lp2f((lp_t)rv[e]));
     } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) if (col + e < n_out) v[e] = (short)f2bf(bf2f((bf16_t)v[e]) + bf2f(rp[e]));
+      for (int e = 0; e < 8; ++e) if (col + e < n_out) v[e] = (short)f2lp(lp2f((lp_t)v[e]) + lp2f(rp[e]));
     }
   }
   if (full) {
-    *(bf16x8*)c = v;
+    *(lpx8*)c = v;
   } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (bf16_t)v[e];
+    for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (lp_t)v[e];
   }
 }
+
+}  // namespace VS_NS

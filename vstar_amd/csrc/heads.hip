@@ -2,6 +2,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+namespace VS_NS {
+
 namespace {
 
 // HF OwlViTClassPredictionHead.forward with ONE query per crop (owlvit.py:102-119,150-170):
@@ -9,32 +11,32 @@ namespace {
 // emb row layout (fp32, from one fused GEMM): [0,Q) dense0 | Q shift | Q+1 scale.  bf16 rounding points as in the
 // bf16 reference.  One wave per image token.
 __global__ __launch_bounds__(256) void owl_class_kernel(const float* __restrict__ emb, int ld, int Q,
-                                                        const bf16_t* __restrict__ query, float* __restrict__ out,
+                                                        const lp_t* __restrict__ query, float* __restrict__ out,
                                                         int out_stride_crop, int B, int rows_per_crop) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)B * rows_per_crop) return;
   const int b = (int)(row / rows_per_crop), p = (int)(row % rows_per_crop);
   const float* er = emb + row * ld;
-  const bf16_t* qr = query + (int64_t)b * Q;
+  const lp_t* qr = query + (int64_t)b * Q;
   float ee = 0.f, qq = 0.f;
   for (int d = lane; d < Q; d += 64) {
-    const float e = rbf(er[d]), q = bf2f(qr[d]);
+    const float e = rlp(er[d]), q = lp2f(qr[d]);
     ee += e * e;
     qq += q * q;
   }
   ee = wave_sum(ee);
   qq = wave_sum(qq);
-  const float en = rbf(rbf(sqrtf(ee)) + 1e-6f), qn = rbf(rbf(sqrtf(qq)) + 1e-6f);
+  const float en = rlp(rlp(sqrtf(ee)) + 1e-6f), qn = rlp(rlp(sqrtf(qq)) + 1e-6f);
   float dot = 0.f;
-  for (int d = lane; d < Q; d += 64) dot += rbf(rbf(er[d]) / en) * rbf(bf2f(qr[d]) / qn);
-  dot = rbf(wave_sum(dot));
+  for (int d = lane; d < Q; d += 64) dot += rlp(rlp(er[d]) / en) * rlp(lp2f(qr[d]) / qn);
+  dot = rlp(wave_sum(dot));
   if (lane == 0) {
-    const float shift = rbf(er[Q]);
-    const float sc = rbf(er[Q + 1]);
+    const float shift = rlp(er[Q]);
+    const float sc = rlp(er[Q + 1]);
     const float elu = sc > 0.f ? sc : (__expf(sc) - 1.0f);
-    const float scale = rbf(rbf(elu) + 1.0f);
-    out[(int64_t)b * out_stride_crop + p] = rbf(rbf(dot + shift) * scale);
+    const float scale = rlp(rlp(elu) + 1.0f);
+    out[(int64_t)b * out_stride_crop + p] = rlp(rlp(dot + shift) * scale);
   }
 }
 
@@ -53,13 +55,13 @@ __global__ void owl_box_kernel(const float* __restrict__ raw, int ld, float* __r
   else coord = 1.0f / (float)grid;
   coord = fminf(fmaxf(coord, 0.f), 1.f);
   const float bias = logf(coord + 1e-4f) - log1pf(-coord + 1e-4f);
-  const float v = rbf(rbf(raw[row * ld + c]) + bias);
-  out[(int64_t)b * out_stride_crop + p * 4 + c] = rbf(1.0f / (1.0f + __expf(-v)));
+  const float v = rlp(rlp(raw[row * ld + c]) + bias);
+  out[(int64_t)b * out_stride_crop + p * 4 + c] = rlp(1.0f / (1.0f + __expf(-v)));
 }
 
 // mask_decoder.Upsample: F.interpolate(x.float(), scale_factor=2, "bilinear").to(bf16) then Conv2d 3x3 pad 1
 // (mask_decoder.py:15-27).  Emits the conv's im2col matrix directly: A[(b,Y,X)][(ky*3+kx)*C + c].
-__global__ void up2x_im2col_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ A, int B, int h, int w, int C) {
+__global__ void up2x_im2col_kernel(const lp_t* __restrict__ src, lp_t* __restrict__ A, int B, int h, int w, int C) {
   const int cv = C >> 3;
   const int H2 = 2 * h, W2 = 2 * w;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,45 +75,45 @@ __global__ void up2x_im2col_kernel(const bf16_t* __restrict__ src, bf16_t* __res
   const int Y = (int)((r / W2) % H2);
   const int b = (int)(r / ((int64_t)W2 * H2));
   const int yy = Y + tap / 3 - 1, xx = X + tap % 3 - 1;
-  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  lpx8 o = {0, 0, 0, 0, 0, 0, 0, 0};
   if (yy >= 0 && yy < H2 && xx >= 0 && xx < W2) {
     const float sy = fmaxf(0.5f * (yy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (xx + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)sy, x0 = (int)sx;
     const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
     const float ly = sy - y0, lx = sx - x0;
-    const bf16_t* base = src + (int64_t)b * h * w * C + v * 8;
-    const bf16x8 v00 = *(const bf16x8*)(base + ((int64_t)y0 * w + x0) * C);
-    const bf16x8 v01 = *(const bf16x8*)(base + ((int64_t)y0 * w + x1) * C);
-    const bf16x8 v10 = *(const bf16x8*)(base + ((int64_t)y1 * w + x0) * C);
-    const bf16x8 v11 = *(const bf16x8*)(base + ((int64_t)y1 * w + x1) * C);
+    const lp_t* base = src + (int64_t)b * h * w * C + v * 8;
+    const lpx8 v00 = *(const lpx8*)(base + ((int64_t)y0 * w + x0) * C);
+    const lpx8 v01 = *(const lpx8*)(base + ((int64_t)y0 * w + x1) * C);
+    const lpx8 v10 = *(const lpx8*)(base + ((int64_t)y1 * w + x0) * C);
+    const lpx8 v11 = *(const lpx8*)(base + ((int64_t)y1 * w + x1) * C);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float t = (1.f - ly) * ((1.f - lx) * bf2f((bf16_t)v00[e]) + lx * bf2f((bf16_t)v01[e])) +
-                      ly * ((1.f - lx) * bf2f((bf16_t)v10[e]) + lx * bf2f((bf16_t)v11[e]));
-      o[e] = (short)f2bf(t);
+      const float t = (1.f - ly) * ((1.f - lx) * lp2f((lp_t)v00[e]) + lx * lp2f((lp_t)v01[e])) +
+                      ly * ((1.f - lx) * lp2f((lp_t)v10[e]) + lx * lp2f((lp_t)v11[e]));
+      o[e] = (short)f2lp(t);
     }
   }
-  *(bf16x8*)(A + idx * 8) = o;
+  *(lpx8*)(A + idx * 8) = o;
 }
 
 // masks = hyper_in @ upscaled_embedding.view(b, c, h*w)  (mask_decoder.py:176-181), mask token 0 only
 template <int C>
-__global__ void hyper_mask_kernel(const bf16_t* __restrict__ hyper, const bf16_t* __restrict__ up, float* __restrict__ out,
+__global__ void hyper_mask_kernel(const lp_t* __restrict__ hyper, const lp_t* __restrict__ up, float* __restrict__ out,
                                   int out_stride_crop, int B, int npix) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * npix) return;
   const int b = (int)(idx / npix), pix = (int)(idx % npix);
-  const bf16_t* u = up + idx * C;
-  const bf16_t* hy = hyper + (int64_t)b * C;
+  const lp_t* u = up + idx * C;
+  const lp_t* hy = hyper + (int64_t)b * C;
   float a = 0.f;
 #pragma unroll
   for (int v = 0; v < C / 8; ++v) {
-    const bf16x8 x = *(const bf16x8*)(u + v * 8);
-    const bf16x8 w = *(const bf16x8*)(hy + v * 8);
+    const lpx8 x = *(const lpx8*)(u + v * 8);
+    const lpx8 w = *(const lpx8*)(hy + v * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) a += bf2f((bf16_t)x[e]) * bf2f((bf16_t)w[e]);
+    for (int e = 0; e < 8; ++e) a += lp2f((lp_t)x[e]) * lp2f((lp_t)w[e]);
   }
-  out[(int64_t)b * out_stride_crop + pix] = rbf(a);
+  out[(int64_t)b * out_stride_crop + pix] = rlp(a);
 }
 
 // F.interpolate(low_res.float(), (h, w), "bilinear", align_corners=False) + clamp(min=0)  (VSM.py:534-537, visual_search.py:223-224)
@@ -205,7 +207,7 @@ hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout,
   return hipGetLastError();
 }
 
-hipError_t owl_class_logits(const float* emb, int ld, int Q, const bf16_t* query, float* out, int out_stride_crop, int B,
+hipError_t owl_class_logits(const float* emb, int ld, int Q, const lp_t* query, float* out, int out_stride_crop, int B,
                             int rows_per_crop, hipStream_t s) {
   const int64_t rows = (int64_t)B * rows_per_crop;
   hipLaunchKernelGGL(owl_class_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, emb, ld, Q, query, out,
@@ -217,13 +219,13 @@ hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_c
                      out_stride_crop, B, grid);
   return hipGetLastError();
 }
-hipError_t upsample2x_im2col3x3(const bf16_t* src, bf16_t* A, int B, int h, int w, int C, hipStream_t s) {
+hipError_t upsample2x_im2col3x3(const lp_t* src, lp_t* A, int B, int h, int w, int C, hipStream_t s) {
   if (C % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(up2x_im2col_kernel, dim3(nblk((int64_t)B * 4 * h * w * 9 * (C / 8))), dim3(256), 0, s, src, A, B, h,
                      w, C);
   return hipGetLastError();
 }
-hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out_stride_crop, int B, int npix, int C,
+hipError_t hyper_mask(const lp_t* hyper, const lp_t* up, float* out, int out_stride_crop, int B, int npix, int C,
                       hipStream_t s) {
   if (C != 32) return hipErrorInvalidValue;
   hipLaunchKernelGGL(hyper_mask_kernel<32>, dim3(nblk((int64_t)B * npix)), dim3(256), 0, s, hyper, up, out,
@@ -235,3 +237,5 @@ hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, 
                      wout, (float)hin / (float)hout, (float)win / (float)wout);
   return hipGetLastError();
 }
+
+}  // namespace VS_NS

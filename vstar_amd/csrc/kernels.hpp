@@ -2,69 +2,71 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "../../include/vstar_hip.h"
+#include "common.hpp"
 
-typedef uint16_t bf16_t;
+namespace VS_NS {
 
 // Row maps let a GEMM read/write a strided sub-sequence without a gather pass:
 //   mapped(r) = (r / group) * gstride + off + r % group      (group <= 0: identity)
 struct GemmParams {
-  const bf16_t* A; int64_t lda; int a_group; int64_t a_gstride; int64_t a_off;
-  const bf16_t* W;          // [ceil(N/128)*128, K], K % 64 == 0
-  const bf16_t* bias;       // [N] or null
-  const bf16_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
+  const lp_t* A; int64_t lda; int a_group; int64_t a_gstride; int64_t a_off;
+  const lp_t* W;          // [ceil(N/128)*128, K], K % 64 == 0
+  const lp_t* bias;       // [N] or null
+  const lp_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
   void* C; int64_t ldc; int c_group; int64_t c_gstride; int64_t c_off;
   int M, N, K;
   int debug_flags;   // diagnostics only: bit0 = skip the epilogue's global stores, bit1 = skip the whole epilogue
 };
-hipError_t gemm_bf16(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 
 // ---- norms (norm.hip) ----
 // y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
-hipError_t layernorm_bf16(const bf16_t* x, const bf16_t* gamma, const bf16_t* beta, bf16_t* y, int rows, int cols,
+hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t* y, int rows, int cols,
                           float eps, const int32_t* row_index, int act, hipStream_t s);
-hipError_t rmsnorm_bf16(const bf16_t* x, const bf16_t* gamma, bf16_t* y, int rows, int cols, float eps,
+hipError_t rmsnorm_lp(const lp_t* x, const lp_t* gamma, lp_t* y, int rows, int cols, float eps,
                         const int32_t* row_index, hipStream_t s);
 
 // ---- attention (attention.hip) ----
 // qkv: [B*S, 3*H*D] (q | k | v).  rope_and_vt: in-place rotate-half RoPE on q,k (if cs != null) and V^T -> vt[B,H,D,Spad]
-hipError_t attn_prepare(bf16_t* qkv, bf16_t* vt, const bf16_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), bf16, or null*/,
+hipError_t attn_prepare(lp_t* qkv, lp_t* vt, const lp_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), bf16, or null*/,
                         int B, int S, int Spad, int H, int D, hipStream_t s);
-hipError_t attn_forward(const bf16_t* qkv, const bf16_t* vt, bf16_t* out, int B, int S, int Spad, int H, int D,
+hipError_t attn_forward(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, int D,
                         int causal, float scale, hipStream_t s);
 // generic small attention for the SAM head: q[B,Nq,H*D] k[B,Nk,H*D] v[B,Nk,H*D] -> out[B,Nq,H*D]; D <= 32, fp32 math
-hipError_t small_attention(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* out, int B, int Nq, int Nk, int H,
+hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,
                            int D, hipStream_t s);
 
 // ---- elementwise / layout (elementwise.hip) ----
 // pix [B,3,I,I] -> A [B*P, Kpad], k = c*ps*ps + ky*ps + kx, zero padded to Kpad
-hipError_t im2col_patch(const bf16_t* pix, bf16_t* A, int B, int I, int ps, int Kpad, hipStream_t s);
+hipError_t im2col_patch(const lp_t* pix, lp_t* A, int B, int I, int ps, int Kpad, hipStream_t s);
 // tokens[b,0]=cls+pos[0]; tokens[b,1+p]=patch[b,p]+pos[1+p]   (bf16 add)
-hipError_t vit_assemble_tokens(const bf16_t* patch, const bf16_t* cls, const bf16_t* pos, bf16_t* tokens, int B, int P,
+hipError_t vit_assemble_tokens(const lp_t* patch, const lp_t* cls, const lp_t* pos, lp_t* tokens, int B, int P,
                                int C, hipStream_t s);
 // LLaMA input embeddings for the text positions of the spliced sequence (image rows are written by the projector GEMM)
-hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const bf16_t* table, int vocab, bf16_t* x, int B,
+hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const lp_t* table, int vocab, lp_t* x, int B,
                           int C, hipStream_t s);
 // out[r, :] = a[r, :] + b[(r % b_rows), :]   (bf16 add; b broadcast over groups of b_rows)
-hipError_t add_bcast(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s);
+hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s);
 // OWL-ViT: y[b,p,:] = x[b,1+p,:] * x[b,0,:]  (x = post_layernorm output, [B,N,C]) -> [B,N-1,C]
-hipError_t owl_cls_mul(const bf16_t* x, bf16_t* y, int B, int N, int C, hipStream_t s);
+hipError_t owl_cls_mul(const lp_t* x, lp_t* y, int B, int N, int C, hipStream_t s);
 // gather rows: y[r,:] = x[idx[r],:]
-hipError_t gather_rows(const bf16_t* x, const int32_t* idx, bf16_t* y, int rows, int cols, hipStream_t s);
+hipError_t gather_rows(const lp_t* x, const int32_t* idx, lp_t* y, int rows, int cols, hipStream_t s);
 // argmax over fp32 logits rows
 hipError_t argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out, int out_stride, hipStream_t s);
 
 // ---- heads (heads.hip) ----
 // class head: emb [R, ldc] fp32 = dense0(512) | shift | scale ; query [B, Q] bf16; rows_per_crop = 2304
-hipError_t owl_class_logits(const float* emb, int ld, int Q, const bf16_t* query, float* out, int out_stride_crop,
+hipError_t owl_class_logits(const float* emb, int ld, int Q, const lp_t* query, float* out, int out_stride_crop,
                             int B, int rows_per_crop, hipStream_t s);
 // box head final: raw [R, 4] fp32 (dense2 out incl. bias) + grid bias -> sigmoid -> out[b*stride + p*4 ..]
 hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s);
 // SAM upscaling: bilinear x2 (align_corners=False, fp32 -> bf16) fused with 3x3 im2col (zero pad):
 // src [B, h, w, C] channels-last -> A [B*(2h)*(2w), 9*C], k = (ky*3+kx)*C + c
-hipError_t upsample2x_im2col3x3(const bf16_t* src, bf16_t* A, int B, int h, int w, int C, hipStream_t s);
+hipError_t upsample2x_im2col3x3(const lp_t* src, lp_t* A, int B, int h, int w, int C, hipStream_t s);
 // masks[b, pix] = sum_c hyper[b,c] * up[b,pix,c]  (bf16 in, fp32 accumulate, bf16-rounded like the reference matmul) -> fp32
-hipError_t hyper_mask(const bf16_t* hyper, const bf16_t* up, float* out, int out_stride_crop, int B, int npix, int C,
+hipError_t hyper_mask(const lp_t* hyper, const lp_t* up, float* out, int out_stride_crop, int B, int npix, int C,
                       hipStream_t s);
 // bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0)
 hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s);
@@ -74,7 +76,6 @@ hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout,
                       unsigned* mm_scratch, hipStream_t s);
 
 // ---- GPU-side crop preprocessing (preprocess.hip) ----
-#include <vector>
 struct PreJob {            // one (crop, target) pair; jobs are stored as [crop][0 = CLIP, 1 = OWL-ViT]
   int x0, y0, cw, ch;      // crop box inside the resident image
   int in_w, in_h;          // resampled extent (CLIP: the padded square side; OWL: cw, ch)
@@ -86,6 +87,9 @@ struct PreJob {            // one (crop, target) pair; jobs are stored as [crop]
   int64_t out_off;         // element offset into the bf16 pixel buffer [3][out][out]
 };
 void pil_bicubic_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize);
-void clip_norm_lut(bf16_t* lut);
+void clip_norm_lut(lp_t* lut);
 hipError_t preprocess_launch(const uint8_t* img, int W, const PreJob* jobs, const int32_t* tables, uint8_t* temp,
-                             const bf16_t* lut, bf16_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s);
+                             const lp_t* lut, lp_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s);
+
+}  // namespace VS_NS
+using namespace VS_NS;

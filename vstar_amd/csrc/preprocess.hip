@@ -11,6 +11,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 
+namespace VS_NS {
+
 namespace {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
 
 // vertical pass + normalisation LUT: out[c][yo][xo] bf16
 __global__ __launch_bounds__(256) void resize_v_kernel(const PreJob* __restrict__ jobs, const int32_t* __restrict__ tables,
-                                                       const uint8_t* __restrict__ temp, const bf16_t* __restrict__ lut,
-                                                       bf16_t* __restrict__ out, int which) {
+                                                       const uint8_t* __restrict__ temp, const lp_t* __restrict__ lut,
+                                                       lp_t* __restrict__ out, int which) {
   const PreJob j = jobs[blockIdx.z * 2 + which];
   const int xo = blockIdx.x * blockDim.x + threadIdx.x;
   const int yo = blockIdx.y;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void resize_v_kernel(const PreJob* __restrict_
     s0 += p[0] * kk; s1 += p[1] * kk; s2 += p[2] * kk;
   }
   const int64_t plane = (int64_t)j.out * j.out;
-  bf16_t* o = out + j.out_off + (int64_t)yo * j.out + xo;
+  lp_t* o = out + j.out_off + (int64_t)yo * j.out + xo;
   o[0] = lut[clip8(s0)];
   o[plane] = lut[256 + clip8(s1)];
   o[2 * plane] = lut[512 + clip8(s2)];
@@ -120,21 +122,23 @@ void pil_bicubic_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds,
 }
 
 // bf16((float(u8 * (1/255) in double) - mean) / std) per channel: HF rescale (double multiply, float32 cast) + normalize
-void clip_norm_lut(bf16_t* lut /*[3*256]*/) {
+void clip_norm_lut(lp_t* lut /*[3*256]*/) {
   const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
   const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
   for (int c = 0; c < 3; ++c)
     for (int v = 0; v < 256; ++v) {
       const float r = (float)((double)v * 0.00392156862745098);
-      lut[c * 256 + v] = f2bf((r - mean[c]) / stdv[c]);
+      lut[c * 256 + v] = f2lp((r - mean[c]) / stdv[c]);
     }
 }
 
 hipError_t preprocess_launch(const uint8_t* img, int W, const PreJob* jobs, const int32_t* tables, uint8_t* temp,
-                             const bf16_t* lut, bf16_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s) {
+                             const lp_t* lut, lp_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s) {
   dim3 gh((out_size + 255) / 256, max_in_h, B);
   hipLaunchKernelGGL(resize_h_kernel, gh, dim3(256), 0, s, img, W, jobs, tables, temp, which);
   dim3 gv((out_size + 255) / 256, out_size, B);
   hipLaunchKernelGGL(resize_v_kernel, gv, dim3(256), 0, s, jobs, tables, temp, lut, out, which);
   return hipGetLastError();
 }
+
+}  // namespace VS_NS
