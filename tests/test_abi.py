@@ -11,8 +11,8 @@ from vstar_amd.config import CVstarConfig, VSMConfig
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "vstar_hip.h")).read()
+def _declared(header="vstar_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(vstar_[a-z_0-9]+)\s*\(", src)))
 
@@ -24,6 +24,26 @@ def test_header_symbols_match_binding_list():
 def test_library_exports_every_declared_symbol(lib):
     for name in _declared():
         assert hasattr(lib, name), name
+
+
+def test_vqa_header_symbols_match_binding_list(lib):
+    names = _declared("vstar_vqa.h")
+    assert names == sorted(_lib.EXPORTS_VQA)
+    for name in names:
+        assert hasattr(lib, name), name
+
+
+def test_vqa_config_layout_and_loud_failure(lib):
+    from vstar_amd.config import CVqaConfig, VQAConfig
+    assert ctypes.sizeof(CVqaConfig) == 4 * (25 + 8)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    c = VQAConfig.tiny().to_c()
+    assert lib.vstar_vqa_create(ctypes.byref(c), 0, ctypes.byref(h)) != 0
+    c.abi_version = 7
+    assert lib.vstar_vqa_create(ctypes.byref(c), 0, ctypes.byref(h)) == -1
 
 
 def test_result_record_layout():

@@ -1,0 +1,204 @@
+"""VQA-LLM engine on the MI355X, through the C-ABI of include/vstar_vqa.h.
+
+(1) against the golden vectors produced by the REFERENCE's own LlavaSearchLlamaForCausalLM (tests/golden/vqa_*.npz):
+    long/short image and object features, the question's last-row logits, every option continuation's logits scored
+    against the forked question cache, the CrossEntropy option losses and the argmin, and the greedy decode.
+(2) internal consistency that holds at any size: forked-prefix option scoring == re-prefilling question+option;
+    KV-cached decode == cache-less re-prefill; batched decode == one sequence at a time; the weight-streaming GEMM ==
+    the MFMA tile GEMM == torch on the same fp16 operands.
+
+Tolerance: the reference computes in fp16 end to end and so does the engine (fp16 storage, fp32 accumulate, HF's rounding
+points).  Gate: rel_L2(engine, golden fp32) <= max(5e-3, 3 x rel_L2(fp16 reference algorithm on torch-CPU, golden)); the
+noise floor is measured in the test with the oracle on an fp16 state dict and printed.  Tokens are compared while the
+reference's own top-2 logit margin exceeds 0.05 (below that fp16 rounding may legitimately flip the arg-max).
+"""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqa_oracle as O
+from tests.test_vqa_oracle import load_case
+from vstar_amd import _lib
+from vstar_amd.config import VQAConfig
+from vstar_amd.vqa_engine import Seq, VqaEngine
+from vstar_amd.weights import random_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "vqa_*.npz")))
+
+
+def rel_l2(got, ref):
+    got = np.asarray(got, dtype=np.float64).reshape(-1)
+    ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+_ENGINES = {}
+
+
+def engine_for(cfg, wseed):
+    key = (cfg.projector_type, wseed)
+    if key not in _ENGINES:
+        eng = VqaEngine(cfg, 0)
+        eng.load_state_dict(random_state_dict(cfg, seed=wseed, dtype=torch.float16))
+        _ENGINES[key] = eng
+    return _ENGINES[key]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_engine_matches_reference_golden(cuda, path):
+    z, cfg, pix, ids, opts, n_obj, il, ol = load_case(path)
+    wseed = int(z["weight_seed"])
+    eng = engine_for(cfg, wseed)
+    # ---- fp16 noise floor of the reference algorithm itself (torch CPU, fp16 state dict) ----
+    sd16 = random_state_dict(cfg, wseed, torch.float16)
+    n_long, n_short = O.encode_images(sd16, cfg, pix.half())
+    emb16 = O.splice(sd16, ids, n_long[:1], n_short[:1], n_long[1:], n_short[1:], il, ol)
+    q16, past16 = O.llama_forward(sd16, cfg, emb16)
+    noise = {"image_long": rel_l2(n_long[0].float(), z["image_long"]), "image_short": rel_l2(n_short[0].float(), z["image_short"]),
+             "q_logits_last": rel_l2(q16[-1].float(), z["q_logits_last"])}
+    # ---- engine ----
+    eng.encode_images(pix, 0)
+    got = {}
+    long0, short0 = eng.features(0)
+    got["image_long"], got["image_short"] = long0, short0
+    report = {}
+    for k in ("image_long", "image_short"):
+        report[k] = rel_l2(got[k], z[k])
+    for j in range(n_obj):
+        lj, sj = eng.features(1 + j)
+        report[f"obj{j}_long"] = rel_l2(lj, z["obj_long"][j])
+        report[f"obj{j}_short"] = rel_l2(sj, z["obj_short"][j])
+        noise[f"obj{j}_long"], noise[f"obj{j}_short"] = noise["image_long"], noise["image_short"]
+    rows = eng.expand_ids(ids, [0], list(range(1, 1 + n_obj)), il, ol)
+    S = len(rows)
+    want = [(0, r) for r in range(0, S, 16)] + [(0, -1)]
+    q_logits, q_arg = eng.forward([Seq(rows, kv_slot=0)], want)
+    report["q_logits_last"] = rel_l2(q_logits[-1], z["q_logits_last"])
+    report["q_logits_rows"] = rel_l2(q_logits[:-1], z["q_logits_rows"])
+    noise["q_logits_rows"] = rel_l2(q16[::16].float(), z["q_logits_rows"])
+    # ---- options: forked prefix (slot 0) -> slots 1.. ; logits of every option row ----
+    seqs = [Seq(o, kv_slot=1 + j, past_len=S, prefix_slot=0) for j, o in enumerate(opts)]
+    o_logits, _ = eng.forward(seqs, [(j, t) for j, o in enumerate(opts) for t in range(len(o))])
+    report["opt_logits"] = rel_l2(o_logits, z["opt_logits"])
+    o16 = torch.cat([O.llama_forward(sd16, cfg, sd16["model.embed_tokens.weight"][torch.tensor(o)], past16)[0] for o in opts], 0)
+    noise["opt_logits"] = rel_l2(o16.float(), z["opt_logits"])
+    losses, k = [], 0
+    for o in opts:
+        lg = torch.cat([torch.from_numpy(q_logits[-1:]), torch.from_numpy(o_logits[k:k + len(o) - 1])], 0)
+        k += len(o)
+        losses.append(float(torch.nn.functional.cross_entropy(lg.float(), torch.tensor(o))))
+    print(os.path.basename(path), {k: "%.2e (noise %.2e)" % (v, noise[k]) for k, v in report.items()})
+    print("  losses", [round(x, 4) for x in losses], "reference", z["losses"].round(4).tolist())
+    for k, v in report.items():
+        assert v <= max(5e-3, 3 * noise[k]), (k, v, noise[k])
+    np.testing.assert_allclose(losses, z["losses"], atol=0.02)
+    ref_sorted = np.sort(z["losses"])
+    if ref_sorted[1] - ref_sorted[0] > 0.05:
+        assert int(np.argmin(losses)) == int(np.argmin(z["losses"]))
+    # ---- greedy decode with the KV cache ----
+    cur, pos, gen = int(q_arg[-1]), S, []
+    for step in range(len(z["gen"])):
+        gen.append(cur)
+        _, nxt = eng.forward([Seq([cur], kv_slot=0, past_len=pos)], [(0, 0)], logits=False)
+        cur, pos = int(nxt[0]), pos + 1
+    n_cmp = 0
+    for g, r, m in zip(gen, z["gen"], z["gen_margin"]):
+        if m < 0.05:
+            break
+        assert g == int(r)
+        n_cmp += 1
+    print("  greedy tokens compared:", n_cmp, "of", len(gen), gen, z["gen"].tolist())
+    assert n_cmp >= 1
+
+
+def test_fork_equals_reprefill_and_cache_equals_no_cache(cuda):
+    cfg = VQAConfig.tiny()
+    eng = engine_for(cfg, 0)
+    g = torch.Generator().manual_seed(11)
+    eng.encode_images(torch.randn(1, 3, 224, 224, generator=g), 0)
+    q = [1] + torch.randint(3, 300, (9,), generator=g).tolist()
+    q[2] = -200
+    rows = eng.expand_ids(q, [0], [], None, None)          # 256 long rows + 9 text rows
+    S = len(rows)
+    opt = torch.randint(3, 300, (7,), generator=g).tolist()
+    # (a) question prefill into slot 0, option forked into slot 1
+    eng.forward([Seq(rows, kv_slot=0)], [])
+    a_logits, _ = eng.forward([Seq(opt, kv_slot=1, past_len=S, prefix_slot=0)], [(0, t) for t in range(len(opt))])
+    # (b) one prefill of question + option in slot 2 (flash-attention path)
+    b_logits, _ = eng.forward([Seq(rows + opt, kv_slot=2)], [(0, S + t) for t in range(len(opt))])
+    err = rel_l2(a_logits, b_logits)
+    print("fork vs re-prefill rel_l2 %.2e" % err)
+    assert err < 5e-3
+    # (c) token-by-token with the cache (slot 3 continues a copy of the question) == (b)
+    eng.forward([Seq(rows, kv_slot=3)], [])
+    c_rows = []
+    for t, tok in enumerate(opt):
+        lg, _ = eng.forward([Seq([tok], kv_slot=3, past_len=S + t)], [(0, 0)])
+        c_rows.append(lg[0])
+    err = rel_l2(np.stack(c_rows), b_logits)
+    print("decode-with-cache vs prefill rel_l2 %.2e" % err)
+    assert err < 5e-3
+
+
+def test_batched_ragged_decode_equals_single(cuda):
+    cfg = VQAConfig.tiny()
+    eng = engine_for(cfg, 0)
+    g = torch.Generator().manual_seed(12)
+    eng.encode_images(torch.randn(2, 3, 224, 224, generator=g), 0)
+    prompts = []
+    for i, n in enumerate((6, 11)):
+        ids = [1] + torch.randint(3, 300, (n,), generator=g).tolist()
+        ids[1] = -200
+        prompts.append(eng.expand_ids(ids, [i], [], [i == 0], None))   # sample 0 long (256 rows), sample 1 short (32 rows)
+    singles = []
+    for i, rows in enumerate(prompts):
+        lg, _ = eng.forward([Seq(rows, kv_slot=4 + i)], [(0, -1)])
+        lg2, _ = eng.forward([Seq([5 + i], kv_slot=4 + i, past_len=len(rows))], [(0, 0)])
+        singles.append((lg[0], lg2[0]))
+    lg, _ = eng.forward([Seq(r, kv_slot=i) for i, r in enumerate(prompts)], [(0, -1), (1, -1)])       # ragged prefill batch
+    lg2, _ = eng.forward([Seq([5 + i], kv_slot=i, past_len=len(r)) for i, r in enumerate(prompts)], [(0, 0), (1, 0)])
+    for i in range(2):
+        assert rel_l2(lg[i], singles[i][0]) < 2e-3, rel_l2(lg[i], singles[i][0])
+        assert rel_l2(lg2[i], singles[i][1]) < 2e-3, rel_l2(lg2[i], singles[i][1])
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1, 4096, 4096, 0), (7, 1000, 1024, 0), (16, 512, 11008, 0), (33, 768, 256, 2),
+                                         (64, 22016, 4096, 4), (48, 320, 256, 0), (5, 4096, 4096, 0)])
+def test_weight_streaming_gemm(cuda, lib, M, N, K, epi):
+    """gemm_skinny_kernel vs torch fp32 on the same fp16 operands, with bias/residual; and vs the MFMA tile kernel."""
+    g = torch.Generator().manual_seed(M * 1000 + N)
+    Npad = (N + 255) // 256 * 256
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = torch.zeros(Npad, K, dtype=torch.float16)
+    W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    W = W.cuda()
+    use_bias = epi != 4
+    bias = (torch.randn(Npad, generator=g) * 0.1).half().cuda() if use_bias else None
+    res = (torch.randn(M, n_out, generator=g) * 0.5).half().cuda() if M % 2 else None
+    outs = []
+    for kernel in (1, 2):
+        C = torch.zeros(M, n_out, dtype=torch.float16, device="cuda")
+        P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        rc = lib.vstar_vqa_op_gemm(P(A), P(W), P(bias), P(res), P(C), M, N, K, epi, kernel)
+        assert rc == 0, lib.vstar_vqa_last_error(None)
+        outs.append(C.float().cpu())
+    ref = A.float().cpu() @ W[:N].float().cpu().T
+    if use_bias:
+        ref = ref + bias[:N].float().cpu()
+    if epi == 2:
+        ref = torch.nn.functional.gelu(ref.half().float())
+    if epi == 4:   # packed rows: blocks of 16 gate rows followed by 16 up rows
+        r = ref.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r[:, :, 0].half().float()).half().float() * r[:, :, 1].half().float()).reshape(M, n_out)
+    if res is not None:
+        ref = ref.half().float() + res.float().cpu()
+    scale = float(ref.abs().max())
+    for o in outs:
+        assert float((o - ref).abs().max()) <= 2e-3 * scale + 1e-3, float((o - ref).abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * scale + 1e-3

@@ -9,7 +9,7 @@ import ctypes
 import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint, c_uint16, c_void_p
 
-from .config import CVstarConfig, MASK_RES, MAX_VERIFY, N_BOXES
+from .config import CVqaConfig, CVstarConfig, MASK_RES, MAX_VERIFY, N_BOXES
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvstar_hip.so")
 
@@ -19,6 +19,12 @@ EXPORTS = [
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats",
+]
+
+# every symbol include/vstar_vqa.h declares
+EXPORTS_VQA = [
+    "vstar_vqa_create", "vstar_vqa_destroy", "vstar_vqa_last_error", "vstar_vqa_load_tensor", "vstar_vqa_finalize_weights",
+    "vstar_vqa_encode_images", "vstar_vqa_forward", "vstar_vqa_debug_read", "vstar_vqa_last_forward_ms", "vstar_vqa_op_gemm",
 ]
 
 F32, F16, BF16 = 0, 1, 2
@@ -99,8 +105,36 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_attention.restype = c_int
     lib.vstar_op_attention_workspace.argtypes = [c_int, c_int, c_int, c_int]
     lib.vstar_op_attention_workspace.restype = c_size_t
+    # ---- VQA-LLM engine (include/vstar_vqa.h) ----
+    lib.vstar_vqa_create.argtypes = [POINTER(CVqaConfig), c_int, POINTER(H)]
+    lib.vstar_vqa_create.restype = c_int
+    lib.vstar_vqa_destroy.argtypes = [H]
+    lib.vstar_vqa_destroy.restype = None
+    lib.vstar_vqa_last_error.argtypes = [H]
+    lib.vstar_vqa_last_error.restype = c_char_p
+    lib.vstar_vqa_load_tensor.argtypes = [H, c_char_p, c_void_p, c_int, c_int, POINTER(c_int64)]
+    lib.vstar_vqa_load_tensor.restype = c_int
+    lib.vstar_vqa_finalize_weights.argtypes = [H]
+    lib.vstar_vqa_finalize_weights.restype = c_int
+    lib.vstar_vqa_encode_images.argtypes = [H, c_int, c_void_p, c_int]
+    lib.vstar_vqa_encode_images.restype = c_int
+    lib.vstar_vqa_forward.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                      c_void_p]
+    lib.vstar_vqa_forward.restype = c_int
+    lib.vstar_vqa_op_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+    lib.vstar_vqa_op_gemm.restype = c_int
+    lib.vstar_vqa_debug_read.argtypes = [H, c_char_p, c_void_p, c_int64]
+    lib.vstar_vqa_debug_read.restype = c_int64
+    lib.vstar_vqa_last_forward_ms.argtypes = [H]
+    lib.vstar_vqa_last_forward_ms.restype = c_double
     _lib = lib
     return lib
+
+
+def check_vqa(rc: int, handle=None) -> None:
+    if rc != 0:
+        msg = load().vstar_vqa_last_error(handle)
+        raise VstarError(f"libvstar_hip (vqa) error {rc}: {msg.decode() if msg else '?'}")
 
 
 def check(rc: int, handle=None) -> None:

@@ -132,3 +132,90 @@ class VSMConfig:
             out.update({"owl_tower": owl, "det_heads": heads, "sam_head": sam})
             out["full"] = core + owl + heads + sam
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# VQA-LLM: LlavaSearchLlamaForCausalLM, mirrored 1:1 by `vstar_vqa_config` in include/vstar_vqa.h
+#   LlavaSearchConfig(LlamaConfig) ...... LLaVA/llava/model/language_model/llava_search_llama.py:30-50
+#   projector builder ................... LLaVA/llava/model/multimodal_projector/builder.py:33-68 (perceiver: depth 6,
+#                                         16 heads x 96, 32 latents, 1 media embedding)
+# ------------------------------------------------------------------------------------------------------------
+VQA_ABI_VERSION = 1
+OBJECT_TOKEN_INDEX = -300  # LLaVA/llava/constants.py:10
+PAD_ROW = -(2 ** 31)
+
+
+class CVqaConfig(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("clip_image_size", ctypes.c_int32), ("clip_patch", ctypes.c_int32), ("clip_hidden", ctypes.c_int32),
+        ("clip_heads", ctypes.c_int32), ("clip_mlp", ctypes.c_int32), ("clip_layers", ctypes.c_int32),
+        ("clip_select_layer", ctypes.c_int32),
+        ("llm_hidden", ctypes.c_int32), ("llm_heads", ctypes.c_int32), ("llm_mlp", ctypes.c_int32),
+        ("llm_layers", ctypes.c_int32), ("llm_vocab", ctypes.c_int32),
+        ("llm_rms_eps", ctypes.c_float), ("llm_rope_theta", ctypes.c_float),
+        ("projector_type", ctypes.c_int32),
+        ("pcv_depth", ctypes.c_int32), ("pcv_heads", ctypes.c_int32), ("pcv_dim_head", ctypes.c_int32),
+        ("pcv_latents", ctypes.c_int32), ("pcv_ff_mult", ctypes.c_int32),
+        ("max_slots", ctypes.c_int32), ("max_ctx", ctypes.c_int32), ("max_rows", ctypes.c_int32),
+        ("max_images", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 8),
+    ]
+
+
+@dataclass
+class VQAConfig:
+    clip_image_size: int = 224
+    clip_patch: int = 14
+    clip_hidden: int = 1024
+    clip_heads: int = 16
+    clip_mlp: int = 4096
+    clip_layers: int = 24
+    clip_select_layer: int = -2
+    llm_hidden: int = 4096
+    llm_heads: int = 32
+    llm_mlp: int = 11008
+    llm_layers: int = 32
+    llm_vocab: int = 32001          # vicuna tokenizer + <im_patch> (builder.py:131-135)
+    llm_rms_eps: float = 1e-5
+    llm_rope_theta: float = 10000.0
+    projector_type: int = 0         # 0 linear, 1 mlp2x_gelu
+    pcv_depth: int = 6
+    pcv_heads: int = 16
+    pcv_dim_head: int = 96
+    pcv_latents: int = 32
+    pcv_ff_mult: int = 4
+    max_slots: int = 16
+    max_ctx: int = 2048
+    max_rows: int = 8192
+    max_images: int = 16
+
+    @property
+    def n_img_tokens(self) -> int:
+        return (self.clip_image_size // self.clip_patch) ** 2
+
+    @property
+    def feat_rows(self) -> int:
+        """Rows of one feature-table slot: P long rows then pcv_latents short rows."""
+        return self.n_img_tokens + self.pcv_latents
+
+    def to_c(self) -> CVqaConfig:
+        c = CVqaConfig()
+        c.abi_version = VQA_ABI_VERSION
+        for k, v in asdict(self).items():
+            setattr(c, k, v)
+        return c
+
+    @classmethod
+    def seal_7b(cls, **kw) -> "VQAConfig":
+        """craigwu/seal_vqa_7b geometry (vicuna-7b + CLIP-L/14@224 + perceiver object projector)."""
+        return cls(**kw)
+
+    @classmethod
+    def tiny(cls, **kw) -> "VQAConfig":
+        """Small widths, real topology (head dims 64 / 128 / 96-wide perceiver heads, 224 px CLIP): golden fixtures."""
+        d = dict(clip_hidden=128, clip_heads=2, clip_mlp=256, clip_layers=3, llm_hidden=256, llm_heads=2, llm_mlp=512,
+                 llm_layers=2, llm_vocab=320, pcv_depth=2, pcv_heads=2, pcv_dim_head=96, pcv_latents=32, max_slots=8,
+                 max_ctx=512, max_rows=2048, max_images=4)
+        d.update(kw)
+        return cls(**d)

@@ -1,0 +1,419 @@
+// decode.hip — kernels of the KV-cached language-model path (VQA-LLM: LLaVA/llava/model/language_model/
+// llava_search_llama.py:56-113 driven by vstar_bench_eval.py:78-165; HF LlamaAttention 4.31 with past_key_values) and of the
+// object-feature Perceiver resampler (LLaVA/llava/model/multimodal_projector/perceiver.py:25-121).
+//
+//   gemm_skinny_kernel   out[M<=64, N] = A · W^T for decode-sized M: HBM-bound weight streaming.  One workgroup owns 16 (or
+//                        16 gate + 16 up) output columns, its 8 waves split K in an interleaved fashion so that the
+//                        workgroup as a whole reads 512 contiguous bytes of every W row per step; partial sums meet in LDS.
+//   rope_kv_append       rotate-half RoPE (HF rounding points) on q,k in place at per-row absolute positions + K/V rows
+//                        written into the per-slot cache [slot][head][ctx][128].
+//   cached_attn_kernel   one workgroup per (new row, head): scores against the cached keys (prefix slot below `past`, own
+//                        slot from there on — option scoring forks a shared question prefix without copying it), fp32
+//                        softmax, probabilities rounded to the storage type like HF, PV from the cached values.
+//   perceiver_attn       32 latents x (256 media + 32 latent) keys, 16 heads x 96 dims: one wave per (image, head, latent).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.hpp"
+#include "kernels.hpp"
+#include "gemm_epilogue.hpp"
+
+namespace VS_NS {
+
+namespace {
+
+// ------------------------------------------------ skinny GEMM ------------------------------------------------
+// Operands as in the big kernels: W fragment is the MFMA A operand (16 output columns x 32 k), the activation fragment
+// the B operand (16 rows x 32 k); lane (fr = lane%16, g = lane/16) loads 16 bytes at k = ks*32 + g*8 of W row / A row fr.
+// The accumulator lane then owns output row fr, columns 4g..4g+3 — the layout gemm_epilogue_store expects.
+constexpr int SK_WAVES = 8;
+
+template <int EPI, bool OUT_F32, int MT>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmParams p) {
+  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
+  __shared__ float red[SK_WAVES][MT][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NT;
+  const int nks = p.K >> 5;
+
+  const lp_t* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = p.W + (int64_t)(n0 + t * 16 + fr) * p.K + g * 8;
+  const lp_t* ap[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int row = m * 16 + fr;
+    row = row < p.M ? row : p.M - 1;          // rows past M repeat the last row (their results are never stored)
+    ap[m] = p.A + (int64_t)row * p.lda + g * 8;
+  }
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int UNROLL = 4;
+  int ks = wave;
+  for (; ks + (UNROLL - 1) * SK_WAVES < nks; ks += UNROLL * SK_WAVES) {
+    lpx8 wf[UNROLL][NT], af[UNROLL][MT];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int k = (ks + u * SK_WAVES) * 32;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[u][t] = __builtin_nontemporal_load((const lpx8*)(wp[t] + k));   // streamed once
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[u][m] = *(const lpx8*)(ap[m] + k);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = mfma_16x16x32(wf[u][t], af[u][m], acc[t][m]);
+  }
+  for (; ks < nks; ks += SK_WAVES) {
+    const int k = ks * 32;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const lpx8 wf = *(const lpx8*)(wp[t] + k);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[t][m] = mfma_16x16x32(wf, *(const lpx8*)(ap[m] + k), acc[t][m]);
+    }
+  }
+  // ---- cross-wave reduction (fixed order => results do not depend on scheduling); wave m finishes row tile m ----
+  f32x4 s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t) __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) *(f32x4*)red[wave][m][lane] = acc[t][m];
+    __syncthreads();
+    if (wave < MT) {
+      s[t] = *(const f32x4*)red[0][wave][lane];
+#pragma unroll
+      for (int w = 1; w < SK_WAVES; ++w) s[t] += *(const f32x4*)red[w][wave][lane];
+    }
+  }
+  if (wave >= MT) return;
+  const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  const int row = wave * 16 + fr;
+  if (row >= p.M) return;
+  if (EPI == VSTAR_EPI_SILU_MUL) gemm_epilogue_store<EPI, OUT_F32>(p, row, n0 / 2 + g * 4, n_out, s[0], s[NT - 1]);
+  else gemm_epilogue_store<EPI, OUT_F32>(p, row, n0 + g * 4, n_out, s[0], s[0]);
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch_skinny(const GemmParams& p, hipStream_t s) {
+  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
+  const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
+  const int mt = (p.M + 15) / 16;
+  switch (mt) {
+    case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 1>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 2>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 3>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 4>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------ embedding rows ------------------------------------------------
+__global__ void embed_rows_kernel(const int32_t* __restrict__ src, const lp_t* __restrict__ table, int vocab,
+                                  const lp_t* __restrict__ feats, int64_t n_feat_rows, lp_t* __restrict__ x, int R, int C) {
+  const int vec = C >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * vec) return;
+  const int r = (int)(idx / vec), v = (int)(idx - (int64_t)r * vec);
+  const int sidx = src[r];
+  lpx8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (sidx >= 0) {
+    if (sidx < vocab) o = *(const lpx8*)(table + (int64_t)sidx * C + v * 8);
+  } else if (sidx != INT32_MIN) {
+    const int64_t f = -(int64_t)sidx - 1;
+    if (f < n_feat_rows) o = *(const lpx8*)(feats + f * C + v * 8);
+  }
+  *(lpx8*)(x + (int64_t)r * C + v * 8) = o;
+}
+
+// ------------------------------------------------ RoPE + KV-cache append ------------------------------------------------
+// One thread per (row, q|k|v, head, 8-vector of the FIRST half of the head dim); handles d0 and d0 + D/2 together.
+__global__ void rope_kv_append_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos_sin, const int32_t* __restrict__ row_pos,
+                                      const int32_t* __restrict__ row_slot, lp_t* __restrict__ kc, lp_t* __restrict__ vc,
+                                      int64_t slot_stride, int ctx, int R, int H) {
+  constexpr int D = 128, HALF = 64, VPH = HALF / 8;
+  const int per_row = 3 * H * VPH;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)R * per_row) return;
+  const int row = (int)(idx / per_row);
+  int rem = (int)(idx - (int64_t)row * per_row);
+  const int which = rem / (H * VPH);
+  rem -= which * H * VPH;
+  const int h = rem / VPH, d0 = (rem - h * VPH) * 8;
+  const int pos = row_pos[row];
+  if (pos < 0) return;                                   // padding row of a ragged prefill batch
+  lp_t* base = qkv + (int64_t)row * (3 * H * D) + which * (H * D) + h * D;
+  lpx8 o1 = *(const lpx8*)(base + d0), o2 = *(const lpx8*)(base + d0 + HALF);
+  if (which < 2) {
+    const lpx8 c = *(const lpx8*)(cos_sin + (int64_t)pos * D + d0);
+    const lpx8 sn = *(const lpx8*)(cos_sin + (int64_t)pos * D + HALF + d0);
+    const lpx8 x1 = o1, x2 = o2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = lp2f((lp_t)x1[e]), b = lp2f((lp_t)x2[e]);
+      const float cs = lp2f((lp_t)c[e]), si = lp2f((lp_t)sn[e]);
+      o1[e] = (short)f2lp(rlp(a * cs) + rlp(-b * si));
+      o2[e] = (short)f2lp(rlp(b * cs) + rlp(a * si));
+    }
+    *(lpx8*)(base + d0) = o1;
+    *(lpx8*)(base + d0 + HALF) = o2;
+    if (which == 0) return;
+  }
+  lp_t* dst = (which == 1 ? kc : vc) + (int64_t)row_slot[row] * slot_stride + ((int64_t)h * ctx + pos) * D;
+  *(lpx8*)(dst + d0) = o1;
+  *(lpx8*)(dst + d0 + HALF) = o2;
+}
+
+// ------------------------------------------------ attention over the KV cache ------------------------------------------------
+__global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict__ qkv, const lp_t* __restrict__ kc,
+                                                          const lp_t* __restrict__ vc, const int32_t* __restrict__ row_seq,
+                                                          const int32_t* __restrict__ row_pos, const int32_t* __restrict__ seq_kv,
+                                                          const int32_t* __restrict__ seq_prefix,
+                                                          const int32_t* __restrict__ seq_past, lp_t* __restrict__ out, int H,
+                                                          int ctx, int64_t slot_stride, float inv_scale) {
+  constexpr int D = 128;
+  extern __shared__ float dyn[];            // [D] q | [nk] scores/probabilities
+  __shared__ float redbuf[8];
+  __shared__ float part[4][D];
+  const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+  const int pos = row_pos[r];
+  if (pos < 0) return;
+  const int seq = row_seq[r];
+  const int past = seq_past[seq], nk = pos + 1;
+  const lp_t* kown = kc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* kpre = kc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* vown = vc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* vpre = vc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
+  float* qs = dyn;
+  float* sc = dyn + D;
+  if (tid < D) qs[tid] = lp2f(qkv[(int64_t)r * (3 * H * D) + h * D + tid]);
+  __syncthreads();
+  // ---- scores: 16 lanes per key, 16 keys per pass ----
+  const int l16 = tid & 15, sub = tid >> 4;
+  float qv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qv[e] = qs[l16 * 8 + e];
+  float mx = -3.0e38f;
+  for (int j0 = 0; j0 < nk; j0 += 16) {
+    const int j = j0 + sub;
+    float a = 0.f;
+    if (j < nk) {
+      const lpx8 kv8 = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += qv[e] * lp2f((lp_t)kv8[e]);
+    }
+    a += __shfl_xor(a, 8, 64);
+    a += __shfl_xor(a, 4, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 1, 64);
+    if (j < nk) {
+      const float s = rlp(rlp(a) / inv_scale);    // HF: matmul output in the storage type, then / sqrt(head_dim)
+      if (l16 == 0) sc[j] = s;
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) redbuf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redbuf[0], redbuf[1]), fmaxf(redbuf[2], redbuf[3]));
+  float sum = 0.f;
+  for (int j = tid; j < nk; j += 256) {
+    const float e = __expf(sc[j] - mx);
+    sc[j] = e;
+    sum += e;
+  }
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) redbuf[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7]);
+  // ---- PV: thread = (key group, pair of output dims); probabilities rounded to the storage type (HF .to(query.dtype)) ----
+  const int dp = (tid & 63) * 2, grp = tid >> 6;
+  float o0 = 0.f, o1 = 0.f;
+  for (int j = grp; j < nk; j += 4) {
+    const float pr = rlp(sc[j] * inv);
+    const uint32_t v2 = *(const uint32_t*)((j < past ? vpre : vown) + (int64_t)j * D + dp);
+    o0 += pr * lp2f((lp_t)(v2 & 0xffff));
+    o1 += pr * lp2f((lp_t)(v2 >> 16));
+  }
+  part[grp][dp] = o0;
+  part[grp][dp + 1] = o1;
+  __syncthreads();
+  if (tid < D) out[(int64_t)r * (H * D) + h * D + tid] = f2lp(part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+}
+
+// ------------------------------------------------ Perceiver attention ------------------------------------------------
+// q [n*L, H*DH]; kv [n*NK, 2*H*DH] = k | v; out [n*L, H*DH].  Rounding points of the fp16 reference: q*scale, sim, sim-amax,
+// softmax output and the attn·v product are each materialised in the storage type.
+template <int DH>
+__global__ __launch_bounds__(256) void perceiver_attn_kernel(const lp_t* __restrict__ q, const lp_t* __restrict__ kv,
+                                                             lp_t* __restrict__ out, int n, int L, int NK, int H, float scale) {
+  constexpr int MAXK_PER_LANE = 8;     // up to 512 keys
+  __shared__ float qsh[4][DH];
+  __shared__ float psh[4][64 * MAXK_PER_LANE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + w;
+  if (wid >= (int64_t)n * H * L) return;
+  const int qi = (int)(wid % L), h = (int)((wid / L) % H), b = (int)(wid / ((int64_t)L * H));
+  const int C = H * DH;
+  const lp_t* qp = q + ((int64_t)b * L + qi) * C + h * DH;
+  for (int d = lane; d < DH; d += 64) qsh[w][d] = rlp(lp2f(qp[d]) * scale);
+  __builtin_amdgcn_wave_barrier();
+  float sc[MAXK_PER_LANE];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < MAXK_PER_LANE; ++i) {
+    const int key = i * 64 + lane;
+    float s = -3.0e38f;
+    if (key < NK) {
+      const lp_t* kp = kv + ((int64_t)b * NK + key) * (2 * C) + h * DH;
+      float a = 0.f;
+#pragma unroll
+      for (int d8 = 0; d8 < DH / 8; ++d8) {
+        const lpx8 k8 = *(const lpx8*)(kp + d8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a += qsh[w][d8 * 8 + e] * lp2f((lp_t)k8[e]);
+      }
+      s = rlp(a);
+    }
+    sc[i] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXK_PER_LANE; ++i) {
+    const int key = i * 64 + lane;
+    if (key < NK) {
+      const float e = __expf(rlp(sc[i] - mx));
+      sc[i] = e;
+      sum += e;
+    }
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int i = 0; i < MAXK_PER_LANE; ++i) {
+    const int key = i * 64 + lane;
+    if (key < NK) psh[w][key] = rlp(sc[i] * inv);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane * 2 < DH) {
+    const lp_t* vp = kv + (int64_t)b * NK * (2 * C) + C + h * DH + lane * 2;
+    float o0 = 0.f, o1 = 0.f;
+    for (int key = 0; key < NK; ++key) {
+      const uint32_t v2 = *(const uint32_t*)(vp + (int64_t)key * (2 * C));
+      const float pr = psh[w][key];
+      o0 += pr * lp2f((lp_t)(v2 & 0xffff));
+      o1 += pr * lp2f((lp_t)(v2 >> 16));
+    }
+    lp_t* op = out + ((int64_t)b * L + qi) * C + h * DH + lane * 2;
+    op[0] = f2lp(o0);
+    op[1] = f2lp(o1);
+  }
+}
+
+__global__ void argmax_rows_lp_kernel(const lp_t* __restrict__ x, int cols, int64_t ld, int32_t* __restrict__ out) {
+  __shared__ float bv[4];
+  __shared__ int bi[4];
+  const int row = blockIdx.x;
+  const lp_t* p = x + (int64_t)row * ld;
+  float best = -3.0e38f;
+  int idx = 0;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    const float v = lp2f(p[c]);
+    if (v > best) { best = v; idx = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = idx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+    out[row] = idx;
+  }
+}
+
+}  // namespace
+
+bool gemm_skinny_eligible(const GemmParams& p) {
+  return p.M > 0 && p.M <= 64 && p.a_group <= 0 && p.c_group <= 0 && p.K % 32 == 0 && (p.lda % 8) == 0;
+}
+
+hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+  if (!gemm_skinny_eligible(p)) return hipErrorInvalidValue;
+#define SK_CASE(E)                                                                   \
+  case E:                                                                            \
+    return out_f32 ? launch_skinny<E, true>(p, s) : launch_skinny<E, false>(p, s);
+  switch (epilogue) {
+    SK_CASE(VSTAR_EPI_NONE)
+    SK_CASE(VSTAR_EPI_QUICK_GELU)
+    SK_CASE(VSTAR_EPI_GELU)
+    SK_CASE(VSTAR_EPI_RELU)
+    SK_CASE(VSTAR_EPI_SILU_MUL)
+  }
+#undef SK_CASE
+  return hipErrorInvalidValue;
+}
+
+hipError_t embed_rows(const int32_t* src, const lp_t* table, int vocab, const lp_t* feats, int64_t n_feat_rows, lp_t* x, int R,
+                      int C, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  const int64_t n = (int64_t)R * (C / 8);
+  hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, table, vocab, feats,
+                     n_feat_rows, x, R, C);
+  return hipGetLastError();
+}
+
+hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos, const int32_t* row_slot, lp_t* kc, lp_t* vc,
+                          int64_t slot_stride, int ctx, int R, int H, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  const int64_t n = (int64_t)R * 3 * H * 8;
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_sin, row_pos, row_slot,
+                     kc, vc, slot_stride, ctx, R, H);
+  return hipGetLastError();
+}
+
+hipError_t cached_attention(const lp_t* qkv, const lp_t* kc, const lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
+                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, lp_t* out, int R, int H,
+                            int ctx, int64_t slot_stride, int max_keys, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  const size_t lds = (size_t)(128 + max_keys) * sizeof(float);
+  if (lds > 48 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cached_attn_kernel, dim3(R, H), dim3(256), lds, s, qkv, kc, vc, row_seq, row_pos, seq_kv, seq_prefix,
+                     seq_past, out, H, ctx, slot_stride, sqrtf(128.0f));
+  return hipGetLastError();
+}
+
+hipError_t perceiver_attention(const lp_t* q, const lp_t* kv, lp_t* out, int n, int L, int NK, int H, int DH, hipStream_t s) {
+  if (DH != 96 && DH != 64 && DH != 32) return hipErrorInvalidValue;
+  if (NK > 512 || n <= 0) return hipErrorInvalidValue;
+  const int64_t waves = (int64_t)n * H * L;
+  const dim3 grid((unsigned)((waves + 3) / 4));
+  const float scale = 1.0f / sqrtf((float)DH);
+  if (DH == 96) hipLaunchKernelGGL(perceiver_attn_kernel<96>, grid, dim3(256), 0, s, q, kv, out, n, L, NK, H, scale);
+  else if (DH == 64) hipLaunchKernelGGL(perceiver_attn_kernel<64>, grid, dim3(256), 0, s, q, kv, out, n, L, NK, H, scale);
+  else hipLaunchKernelGGL(perceiver_attn_kernel<32>, grid, dim3(256), 0, s, q, kv, out, n, L, NK, H, scale);
+  return hipGetLastError();
+}
+
+hipError_t argmax_rows_lp(const lp_t* x, int rows, int cols, int64_t ld, int32_t* out, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(argmax_rows_lp_kernel, dim3(rows), dim3(256), 0, s, x, cols, ld, out);
+  return hipGetLastError();
+}
+
+}  // namespace VS_NS

@@ -21,6 +21,26 @@ struct GemmParams {
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 
+// decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp
+bool gemm_skinny_eligible(const GemmParams& p);
+hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+
+// ---- KV-cached language model + Perceiver resampler (decode.hip) ----
+// x[r,:] = src[r] >= 0 ? table[src[r]] : (src[r] == INT32_MIN ? 0 : feats[-(src[r]+1)])
+hipError_t embed_rows(const int32_t* src, const lp_t* table, int vocab, const lp_t* feats, int64_t n_feat_rows, lp_t* x, int R,
+                      int C, hipStream_t s);
+// in-place RoPE on q,k of qkv [R, 3*H*128] at row_pos[r] (rows with row_pos < 0 are skipped) and K/V rows appended to the
+// cache of slot row_slot[r]: kc/vc = this layer's [slot][H][ctx][128]
+hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos, const int32_t* row_slot, lp_t* kc, lp_t* vc,
+                          int64_t slot_stride, int ctx, int R, int H, hipStream_t s);
+// causal attention of R new rows against the cache: keys [0, seq_past) come from seq_prefix's slot, the rest from seq_kv's
+hipError_t cached_attention(const lp_t* qkv, const lp_t* kc, const lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
+                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, lp_t* out, int R, int H,
+                            int ctx, int64_t slot_stride, int max_keys, hipStream_t s);
+// q [n*L, H*DH], kv [n*NK, 2*H*DH] (k | v) -> out [n*L, H*DH]
+hipError_t perceiver_attention(const lp_t* q, const lp_t* kv, lp_t* out, int n, int L, int NK, int H, int DH, hipStream_t s);
+hipError_t argmax_rows_lp(const lp_t* x, int rows, int cols, int64_t ld, int32_t* out, hipStream_t s);
+
 // ---- norms (norm.hip) ----
 // y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
 hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t* y, int rows, int cols,

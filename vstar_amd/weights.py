@@ -14,7 +14,7 @@ from typing import Dict, Iterable, Tuple
 
 import torch
 
-from .config import VSMConfig
+from .config import VSMConfig, VQAConfig
 
 CLIP_PREFIX = "clip."  # the CLIP tower is NOT part of the VSM checkpoint (merge_lora_weights_and_save_hf_model.py:145-150)
 
@@ -136,18 +136,73 @@ def state_dict_spec(cfg: VSMConfig) -> "OrderedDict[str, Tuple[int, ...]]":
 def _is_norm_weight(key: str) -> bool:
     k = key.rsplit(".", 1)[0]
     last = k.rsplit(".", 1)[-1]
+    if key.endswith(".weight") and "mm_projector_object" in key:
+        return "norm" in last or k.endswith("mm_projector_object.0") or k.endswith(".1.0")     # LayerNorm gains
     return key.endswith(".weight") and (
         "norm" in last or last == "pre_layrnorm" or k.endswith("output_upscaling.1"))
 
 
-def random_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16,
+def vqa_state_dict_spec(cfg: VQAConfig) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Every tensor the VQA-LLM engine consumes: HF keys of LlavaSearchLlamaForCausalLM (llava_search_llama.py:40-50,
+    llava_search_arch.py:14-19, builder.py:33-68, perceiver.py:25-99) plus the separately loaded CLIP tower ("clip.")."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    P, C, H = cfg.n_img_tokens, cfg.clip_hidden, cfg.llm_hidden
+    for k, v in _vit_keys(CLIP_PREFIX + "vision_model.", "pre_layrnorm", C, cfg.clip_mlp, cfg.clip_layers, cfg.clip_patch,
+                          P + 1, post=True):
+        s[k] = v
+    if cfg.projector_type == 0:
+        s["model.mm_projector.weight"] = (H, C)
+        s["model.mm_projector.bias"] = (H,)
+    else:
+        s["model.mm_projector.0.weight"] = (H, C)
+        s["model.mm_projector.0.bias"] = (H,)
+        s["model.mm_projector.2.weight"] = (H, H)
+        s["model.mm_projector.2.bias"] = (H,)
+    po = "model.mm_projector_object."
+    inner = cfg.pcv_heads * cfg.pcv_dim_head
+    s[po + "0.weight"] = (C,)
+    s[po + "0.bias"] = (C,)
+    s[po + "1.latents"] = (cfg.pcv_latents, C)
+    s[po + "1.media_pos_emb"] = (1, 1, C)
+    for i in range(cfg.pcv_depth):
+        lp = f"{po}1.layers.{i}."
+        for nm in ("norm_media", "norm_latents"):
+            s[lp + f"0.{nm}.weight"] = (C,)
+            s[lp + f"0.{nm}.bias"] = (C,)
+        s[lp + "0.to_q.weight"] = (inner, C)
+        s[lp + "0.to_kv.weight"] = (2 * inner, C)
+        s[lp + "0.to_out.weight"] = (C, inner)
+        s[lp + "1.0.weight"] = (C,)
+        s[lp + "1.0.bias"] = (C,)
+        s[lp + "1.1.weight"] = (C * cfg.pcv_ff_mult, C)
+        s[lp + "1.3.weight"] = (C, C * cfg.pcv_ff_mult)
+    s[po + "1.norm.weight"] = (C,)
+    s[po + "1.norm.bias"] = (C,)
+    s[po + "2.weight"] = (H, C)
+    s[po + "2.bias"] = (H,)
+    s["model.embed_tokens.weight"] = (cfg.llm_vocab, H)
+    for i in range(cfg.llm_layers):
+        lp = f"model.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            s[lp + f"self_attn.{nm}.weight"] = (H, H)
+        s[lp + "mlp.gate_proj.weight"] = (cfg.llm_mlp, H)
+        s[lp + "mlp.up_proj.weight"] = (cfg.llm_mlp, H)
+        s[lp + "mlp.down_proj.weight"] = (H, cfg.llm_mlp)
+        s[lp + "input_layernorm.weight"] = (H,)
+        s[lp + "post_attention_layernorm.weight"] = (H,)
+    s["model.norm.weight"] = (H,)
+    s["lm_head.weight"] = (cfg.llm_vocab, H)
+    return s
+
+
+def random_state_dict(cfg, seed: int = 0, dtype: torch.dtype = torch.bfloat16,
                       keys: Iterable[str] | None = None, share_layers: bool = False) -> Dict[str, torch.Tensor]:
     """Seeded synthetic weights: norm gains 1+N(0,0.1), biases/embeddings N(0,0.02), matrices N(0, 1/fan_in).
     Each tensor draws from its own generator seeded by (seed, index) so any subset reproduces bit-identically.
     share_layers=True (throughput benchmarks only) reuses layer 0's host tensors for every other layer of a stack:
     the engine still packs and uploads one device copy per layer, so HBM footprint and traffic are unchanged."""
     import re
-    spec = state_dict_spec(cfg)
+    spec = vqa_state_dict_spec(cfg) if isinstance(cfg, VQAConfig) else state_dict_spec(cfg)
     want = set(keys) if keys is not None else None
     out: Dict[str, torch.Tensor] = {}
     for idx, (k, shp) in enumerate(spec.items()):
@@ -166,7 +221,7 @@ def random_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = torch.
         elif k.endswith(".bias") or len(shp) == 1:
             t = 0.02 * torch.randn(shp, generator=g)
         elif "embed_tokens" in k or "position_embedding" in k or k.endswith("_token.weight") or k.endswith("_tokens.weight") \
-                or "no_mask_embed" in k:
+                or "no_mask_embed" in k or k.endswith(".latents") or k.endswith("media_pos_emb"):
             t = 0.5 * torch.randn(shp, generator=g)
         elif "gaussian_matrix" in k:
             t = torch.randn(shp, generator=g)
