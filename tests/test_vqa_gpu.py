@@ -185,7 +185,7 @@ def test_weight_streaming_gemm(cuda, lib, M, N, K, epi):
     for kernel in (1, 2):
         C = torch.zeros(M, n_out, dtype=torch.float16, device="cuda")
         P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        rc = lib.vstar_vqa_op_gemm(P(A), P(W), P(bias), P(res), P(C), M, N, K, epi, kernel)
+        rc = lib.vstar_vqa_op_gemm(P(A), P(W), P(bias), P(res), P(C), M, N, K, epi, kernel, None, 0.0)
         assert rc == 0, lib.vstar_vqa_last_error(None)
         outs.append(C.float().cpu())
     ref = A.float().cpu() @ W[:N].float().cpu().T
@@ -202,3 +202,142 @@ def test_weight_streaming_gemm(cuda, lib, M, N, K, epi):
     for o in outs:
         assert float((o - ref).abs().max()) <= 2e-3 * scale + 1e-3, float((o - ref).abs().max())
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * scale + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1, 768, 4096, 0), (9, 512, 1024, 0), (32, 2048, 4096, 4)])
+def test_weight_streaming_gemm_with_fused_rmsnorm(cuda, lib, M, N, K, epi):
+    """LlamaRMSNorm fused into the operand load == HF's two-step form (fp32 statistics, fp16 rounding points) + GEMM."""
+    g = torch.Generator().manual_seed(M + N)
+    Npad = (N + 255) // 256 * 256
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g) * 3.0).half().cuda()
+    gain = (1 + 0.1 * torch.randn(K, generator=g)).half().cuda()
+    W = torch.zeros(Npad, K, dtype=torch.float16)
+    W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    W = W.cuda()
+    C = torch.zeros(M, n_out, dtype=torch.float16, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = lib.vstar_vqa_op_gemm(P(A), P(W), None, None, P(C), M, N, K, epi, 1, P(gain), 1e-5)
+    assert rc == 0, lib.vstar_vqa_last_error(None)
+    x = A.float().cpu()
+    xn = (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5)).half()
+    y = (gain.cpu() * xn).float()                                  # fp16 * fp16 -> fp16, as LlamaRMSNorm returns
+    ref = y @ W[:N].float().cpu().T
+    if epi == 4:
+        r = ref.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r[:, :, 0].half().float()).half().float() * r[:, :, 1].half().float()).reshape(M, n_out)
+    scale = float(ref.abs().max())
+    assert float((C.float().cpu() - ref).abs().max()) <= 2e-3 * scale + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the drop-in class (vstar_amd.vqa.VQA_LLM == reference VQA_LLM, vstar_bench_eval.py:38-165) and the evaluation loop
+# ------------------------------------------------------------------------------------------------------------
+def _vqa_llm(wseed=0):
+    from vstar_amd.vqa import VQA_LLM
+    cfg = VQAConfig.tiny()
+    return VQA_LLM(cfg=cfg, engine=engine_for(cfg, wseed)), cfg
+
+
+def _oracle_sample(llm, cfg, sd, image, question, crops, images_long, objects_long, answer=None):
+    """What the reference computes for one sample, from the same host preprocessing, on the fp32 oracle."""
+    from vstar_amd import vqa
+    pix = [llm.image_processor.preprocess(image)["pixel_values"][0]] + ([c for c in crops] if crops is not None else [])
+    pix = torch.stack(pix, 0).half().float()
+    lo, sh = O.encode_images(sd, cfg, pix)
+    ids = vqa.tokenizer_image_object_token(vqa.v1_prompt("<image>\n" + question, answer), llm.tokenizer)
+    return ids, O.splice(sd, ids, lo[:1], sh[:1], lo[1:], sh[1:], images_long, objects_long)
+
+
+def test_vqa_llm_class_against_oracle(cuda):
+    from PIL import Image
+    llm, cfg = _vqa_llm(0)
+    sd = random_state_dict(cfg, 0, torch.float32)
+    rng = np.random.default_rng(5)
+    image = Image.fromarray(rng.integers(0, 256, (300, 420, 3), dtype=np.uint8))
+    crops = torch.stack([llm.get_object_crop(image, [40, 30, 50, 60], patch_scale=1.2),
+                         llm.get_object_crop(image, [200, 100, 90, 40], patch_scale=1.2)], 0)
+    question = "Additional visual information to focus on: mug <object> at location [0.1,0.1,0.2,0.3]; cup <object> at " \
+               "location [0.5,0.3,0.7,0.5].\nWhat is the colour of the mug?"
+    options = ["The colour of the mug is red.", "The colour of the mug is blue.", "green", "The mug is yellow and white."]
+    losses = llm.option_losses(image, question, options, crops, images_long=[False], objects_long=[True, True])
+    chosen = llm.multiple_choices_inference(image, question, options, crops, images_long=[False], objects_long=[True, True])
+    q_ids, emb = _oracle_sample(llm, cfg, sd, image, question, crops, [False], [True, True])
+    opt_ids = []
+    for o in options:
+        full, _ = _oracle_sample(llm, cfg, sd, image, question, crops, [False], [True, True], answer=o)
+        assert full[:len(q_ids)] == q_ids
+        opt_ids.append(full[len(q_ids):])
+    ref_losses, ref_pick = O.multiple_choice(sd, cfg, emb, opt_ids)
+    print("losses", [round(float(x), 4) for x in losses], "oracle", [round(float(x), 4) for x in ref_losses])
+    np.testing.assert_allclose([float(x) for x in losses], ref_losses.numpy(), atol=0.03)
+    srt = np.sort(ref_losses.numpy())
+    if srt[1] - srt[0] > 0.06:
+        assert chosen == ref_pick
+    # free-form greedy answer, plain image (long features), checked token by token against the oracle's arg-max
+    text = llm.free_form_inference(image, "What is in the picture?", max_new_tokens=5)
+    assert isinstance(text, str)
+    _, emb2 = _oracle_sample(llm, cfg, sd, image, "What is in the picture?", None, None, None)
+    table = sd["model.embed_tokens.weight"]
+    logits, past = O.llama_forward(sd, cfg, emb2)
+    for tok in llm.generated_ids[0]:
+        top = logits[-1].topk(2)
+        if float(top.values[0] - top.values[1]) < 0.05:
+            break
+        assert tok == int(top.indices[0])
+        logits, past = O.llama_forward(sd, cfg, table[torch.tensor([tok])], past)
+    # batched decode == one by one
+    samples = [dict(image=image, question="What is in the picture?"),
+               dict(image=image, question=question, object_crops=crops, images_long=[False], objects_long=[True, True])]
+    texts = llm.free_form_batch(samples, max_new_tokens=4)
+    batch_ids = [list(x) for x in llm.generated_ids]
+    assert texts[0] == llm.free_form_inference(image, "What is in the picture?", max_new_tokens=4)
+    assert batch_ids[0] == llm.generated_ids[0]
+
+
+def test_eval_loop_end_to_end_on_synthetic_benchmark(cuda, tmp_path):
+    """vstar_bench_eval.py:168-280 with BOTH models on the HIP engines (tiny widths): free-form answer -> (forced) missing
+    objects -> visual search -> object crops + focus prompt -> multiple choice; checks the result file's schema."""
+    import json
+    from types import SimpleNamespace
+    from PIL import Image
+    from vstar_amd import bench_eval
+    from vstar_amd.config import VSMConfig
+    from vstar_amd.vsm import VSM
+    llm, _ = _vqa_llm(0)
+    vcfg = VSMConfig.tiny(max_text_len=128)
+    vsm = VSM(SimpleNamespace(version="synthetic", vision_tower="synthetic", conv_type="llava_v1", use_mm_start_end=True,
+                              model_max_length=512), cfg=vcfg, synthetic_seed=0)
+    rng = np.random.default_rng(9)
+    for split, n in (("direct_attributes", 2), ("relative_position", 1)):
+        d = tmp_path / split
+        d.mkdir()
+        for i in range(n):
+            Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)).save(d / f"img{i}.jpg")
+            json.dump({"question": "What is the colour of the mug?", "options": ["red", "blue", "green", "black"]},
+                      open(d / f"img{i}.json", "w"))
+    calls = {"n": 0}
+    real_free_form = llm.free_form_inference
+
+    def free_form(image, question, **kw):
+        real_free_form(image, question, max_new_tokens=3)      # exercise the decode path; random weights => random text
+        calls["n"] += 1
+        return bench_eval.MISSING_MSG + " mug, table." if calls["n"] % 2 else "It is red."
+    llm.free_form_inference = free_form
+    real_search = bench_eval.search_objects
+    # random weights make the detector fire on many boxes; the tiny engine's feature table holds 8 images
+    bench_eval.search_objects = lambda *a, **k: real_search(*a, **k)[:5]
+    args = SimpleNamespace(benchmark_folder=str(tmp_path), output_path=str(tmp_path / "eval_result.json"),
+                           minimum_size_scale=4.0, minimum_size=224, vsm_model_path="synthetic")
+    try:
+        results = bench_eval.eval_model(args, llm, vsm)
+    finally:
+        bench_eval.search_objects = real_search
+    out = json.load(open(args.output_path))
+    assert set(out) == {"direct_attributes", "relative_position"}
+    rec = out["direct_attributes"][0]
+    assert set(rec) == {"question", "options", "image", "prediction_freeform", "missing_objects", "search_result",
+                        "option_chosen", "correct"}
+    searched = [r for s in out.values() for r in s if r["missing_objects"]]
+    assert searched and all(len(r["search_result"]) >= 1 and 0 <= r["option_chosen"] < 4 for r in searched)
+    assert results == out

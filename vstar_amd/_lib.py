@@ -121,7 +121,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_vqa_forward.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                       c_void_p]
     lib.vstar_vqa_forward.restype = c_int
-    lib.vstar_vqa_op_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+    lib.vstar_vqa_op_gemm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_float]
     lib.vstar_vqa_op_gemm.restype = c_int
     lib.vstar_vqa_debug_read.argtypes = [H, c_char_p, c_void_p, c_int64]
     lib.vstar_vqa_debug_read.restype = c_int64

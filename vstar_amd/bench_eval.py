@@ -1,7 +1,7 @@
 """SEAL orchestration for V*Bench (reference: vstar_bench_eval.py:168-280): VQA-LLM free-form answer -> parse the
 "missing objects" list -> visual search per object on the HIP engine -> object crops + focus prompt -> option ranking.
-The VQA-LLM itself is injected (`vqa_llm` with free_form_inference / multiple_choices_inference / get_object_crop /
-image_processor, as the reference's VQA_LLM class offers); building it on the HIP kernels is SURVEY.md §8f row 2."""
+`vqa_llm` is any object with the reference's VQA_LLM interface (free_form_inference / multiple_choices_inference /
+get_object_crop / image_processor); `vstar_amd.vqa.VQA_LLM` is that class on the HIP engine."""
 from __future__ import annotations
 
 import json
@@ -63,7 +63,7 @@ def focus_question(question, found, image, pad_left, pad_top):
     for f in found:
         x, y, w, h = f["bbox"]
         x, y = x + pad_left, y + pad_top
-        n = [x / image.width, y / image.height, (x + w) / image.width, (y + h) / image.height]
+        n = [float(np.clip(v, 0, 1)) for v in (x / image.width, y / image.height, (x + w) / image.width, (y + h) / image.height)]
         parts.append("{} <object> at location [{:.3f},{:.3f},{:.3f},{:.3f}]".format(f["name"], *n))
     return FOCUS_MSG + "; ".join(parts) + ".\n" + question
 

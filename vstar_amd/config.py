@@ -216,6 +216,6 @@ class VQAConfig:
         """Small widths, real topology (head dims 64 / 128 / 96-wide perceiver heads, 224 px CLIP): golden fixtures."""
         d = dict(clip_hidden=128, clip_heads=2, clip_mlp=256, clip_layers=3, llm_hidden=256, llm_heads=2, llm_mlp=512,
                  llm_layers=2, llm_vocab=320, pcv_depth=2, pcv_heads=2, pcv_dim_head=96, pcv_latents=32, max_slots=8,
-                 max_ctx=512, max_rows=2048, max_images=4)
+                 max_ctx=1024, max_rows=2048, max_images=8)
         d.update(kw)
         return cls(**d)

@@ -52,6 +52,41 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // ---- optional fused RMSNorm of the A rows: row statistics first (same summation order as norm_kernel<true>) ----
+  const bool fuse_norm = p.norm_w != nullptr;
+  float rstd[MT];
+  const lp_t* nwp = p.norm_w + g * 8;
+  if (fuse_norm) {
+    float* rs_sh = &red[0][0][0][0];
+    for (int row = wave; row < p.M; row += SK_WAVES) {
+      const lp_t* xr = p.A + (int64_t)row * p.lda;
+      float sum = 0.f;
+      for (int vi = lane; vi * 8 < p.K; vi += 64) {
+        const lpx8 t = *(const lpx8*)(xr + vi * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = lp2f((lp_t)t[e]);
+          sum += v * v;
+        }
+      }
+      sum = wave_sum(sum);
+      if (lane == 0) rs_sh[row] = rsqrtf(sum / (float)p.K + p.norm_eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int row = m * 16 + fr;
+      rstd[m] = rs_sh[row < p.M ? row : p.M - 1];
+    }
+    __syncthreads();           // rs_sh aliases the reduction buffer used below
+  }
+  auto normed = [&](lpx8 x, lpx8 w, float rs) {
+    lpx8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (short)f2lp(lp2f((lp_t)w[e]) * rlp(lp2f((lp_t)x[e]) * rs));
+    return y;
+  };
+
   constexpr int UNROLL = 4;
   int ks = wave;
   for (; ks + (UNROLL - 1) * SK_WAVES < nks; ks += UNROLL * SK_WAVES) {
@@ -63,6 +98,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
       for (int t = 0; t < NT; ++t) wf[u][t] = __builtin_nontemporal_load((const lpx8*)(wp[t] + k));   // streamed once
 #pragma unroll
       for (int m = 0; m < MT; ++m) af[u][m] = *(const lpx8*)(ap[m] + k);
+    }
+    if (fuse_norm) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const lpx8 nw = *(const lpx8*)(nwp + (ks + u * SK_WAVES) * 32);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[u][m] = normed(af[u][m], nw, rstd[m]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u)
@@ -77,7 +120,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
     for (int t = 0; t < NT; ++t) {
       const lpx8 wf = *(const lpx8*)(wp[t] + k);
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[t][m] = mfma_16x16x32(wf, *(const lpx8*)(ap[m] + k), acc[t][m]);
+      for (int m = 0; m < MT; ++m) {
+        lpx8 a = *(const lpx8*)(ap[m] + k);
+        if (fuse_norm) a = normed(a, *(const lpx8*)(nwp + k), rstd[m]);
+        acc[t][m] = mfma_16x16x32(wf, a, acc[t][m]);
+      }
     }
   }
   // ---- cross-wave reduction (fixed order => results do not depend on scheduling); wave m finishes row tile m ----
@@ -183,7 +230,7 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
   constexpr int D = 128;
   extern __shared__ float dyn[];            // [D] q | [nk] scores/probabilities
   __shared__ float redbuf[8];
-  __shared__ float part[4][D];
+  __shared__ float part[16][D];
   const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
   const int pos = row_pos[r];
   if (pos < 0) return;
@@ -197,28 +244,35 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
   float* sc = dyn + D;
   if (tid < D) qs[tid] = lp2f(qkv[(int64_t)r * (3 * H * D) + h * D + tid]);
   __syncthreads();
-  // ---- scores: 16 lanes per key, 16 keys per pass ----
-  const int l16 = tid & 15, sub = tid >> 4;
+  // ---- scores: 16 lanes per key, 16 key groups, 4 keys per group and pass (64 keys in flight per pass) ----
+  const int l16 = tid & 15, grp = tid >> 4;
   float qv[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) qv[e] = qs[l16 * 8 + e];
   float mx = -3.0e38f;
-  for (int j0 = 0; j0 < nk; j0 += 16) {
-    const int j = j0 + sub;
-    float a = 0.f;
-    if (j < nk) {
-      const lpx8 kv8 = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
+  for (int j0 = 0; j0 < nk; j0 += 64) {
+    lpx8 kv8[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a += qv[e] * lp2f((lp_t)kv8[e]);
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16 + grp;
+      kv8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (j < nk) kv8[u] = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
     }
-    a += __shfl_xor(a, 8, 64);
-    a += __shfl_xor(a, 4, 64);
-    a += __shfl_xor(a, 2, 64);
-    a += __shfl_xor(a, 1, 64);
-    if (j < nk) {
-      const float s = rlp(rlp(a) / inv_scale);    // HF: matmul output in the storage type, then / sqrt(head_dim)
-      if (l16 == 0) sc[j] = s;
-      mx = fmaxf(mx, s);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16 + grp;
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += qv[e] * lp2f((lp_t)kv8[u][e]);
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 4, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 1, 64);
+      if (j < nk) {
+        const float sv = rlp(rlp(a) / inv_scale);    // HF: matmul output in the storage type, then / sqrt(head_dim)
+        if (l16 == 0) sc[j] = sv;
+        mx = fmaxf(mx, sv);
+      }
     }
   }
   mx = wave_max(mx);
@@ -235,19 +289,38 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
   if ((tid & 63) == 0) redbuf[4 + (tid >> 6)] = sum;
   __syncthreads();
   const float inv = 1.0f / (redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7]);
-  // ---- PV: thread = (key group, pair of output dims); probabilities rounded to the storage type (HF .to(query.dtype)) ----
-  const int dp = (tid & 63) * 2, grp = tid >> 6;
-  float o0 = 0.f, o1 = 0.f;
-  for (int j = grp; j < nk; j += 4) {
-    const float pr = rlp(sc[j] * inv);
-    const uint32_t v2 = *(const uint32_t*)((j < past ? vpre : vown) + (int64_t)j * D + dp);
-    o0 += pr * lp2f((lp_t)(v2 & 0xffff));
-    o1 += pr * lp2f((lp_t)(v2 >> 16));
+  // ---- PV: group = keys j == grp (mod 16), lane = 8 output dims (16-byte V loads), 4 keys in flight; probabilities are
+  // rounded to the storage type (HF .to(query.dtype)) ----
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j0 = grp; j0 < nk; j0 += 64) {
+    lpx8 v8[4];
+    float pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16;
+      v8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
+      pr[u] = 0.f;
+      if (j < nk) {
+        v8[u] = *(const lpx8*)((j < past ? vpre : vown) + (int64_t)j * D + l16 * 8);
+        pr[u] = rlp(sc[j] * inv);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += pr[u] * lp2f((lp_t)v8[u][e]);
   }
-  part[grp][dp] = o0;
-  part[grp][dp + 1] = o1;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[grp][l16 * 8 + e] = o[e];
   __syncthreads();
-  if (tid < D) out[(int64_t)r * (H * D) + h * D + tid] = f2lp(part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]);
+  if (tid < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += part[g2][tid];
+    out[(int64_t)r * (H * D) + h * D + tid] = f2lp(t);
+  }
 }
 
 // ------------------------------------------------ Perceiver attention ------------------------------------------------

@@ -170,7 +170,7 @@ hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream
 
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
-  if (p.K % BK != 0 || p.K <= 0) return hipErrorInvalidValue;
+  if (p.K % BK != 0 || p.K <= 0 || p.norm_w) return hipErrorInvalidValue;   // fused RMSNorm: skinny kernel only
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (force != 128 && gemm256_eligible(p)) return gemm256_lp(p, epilogue, out_f32, s);   // W is padded to 256 rows

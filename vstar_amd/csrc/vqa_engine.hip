@@ -54,6 +54,7 @@ struct vstar_vqa_engine : EngineBase {
               const int32_t* past_len, int n_want, const int32_t* want, uint16_t* logits_out, int32_t* argmax_out);
   int lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
                const lp_t* res = nullptr, int64_t ldr = 0);
+  int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
   int llm_layers_prefill(int nseq, int S);
   int llm_layers_cached(int R, int nseq, int max_keys);
 };
@@ -69,6 +70,23 @@ int vstar_vqa_engine::lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C
     return 0;
   }
   return gemm(p, epi, false);
+}
+
+// RMSNorm + Linear: for decode-sized M the norm is fused into the weight-streaming GEMM's operand load (bit-identical to
+// the two-kernel form), otherwise norm kernel into `scratch`, then the GEMM
+int vstar_vqa_engine::lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M,
+                               int epi) {
+  const int H = cfg.llm_hidden;
+  GemmParams p{};
+  p.A = x; p.lda = H; p.W = L.W; p.bias = L.b; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
+  if (M <= 16 && L.K == H && gemm_skinny_eligible(p)) {
+    p.norm_w = norm_w; p.norm_eps = cfg.llm_rms_eps;
+    hipError_t e = gemm_skinny_lp(p, epi, false, stream);
+    if (e != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(e)); return VSTAR_ERR_HIP; }
+    return 0;
+  }
+  KCHK(rmsnorm_lp(x, norm_w, scratch, M, H, cfg.llm_rms_eps, nullptr, stream));
+  return lin_auto(scratch, H, L, C, ldc, M, epi);
 }
 
 int vstar_vqa_engine::finalize() {
@@ -296,14 +314,12 @@ int vstar_vqa_engine::llm_layers_cached(int R, int nseq, int max_keys) {
     LlmBlock& b = llm[i];
     lp_t* kc = kcache + (int64_t)i * layer_stride;
     lp_t* vc = vcache + (int64_t)i * layer_stride;
-    KCHK(rmsnorm_lp(lx, b.in_norm, lh, R, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin_auto(lh, H, b.qkv, lqkv, 3 * H, R));
+    RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE));
     KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.llm_heads, stream));
     KCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, latt, R, c.llm_heads, c.max_ctx, slot_stride,
                           max_keys, stream));
     RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
-    KCHK(rmsnorm_lp(lx, b.post_norm, lh, R, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin_auto(lh, H, b.gate_up, lact, c.llm_mlp, R, VSTAR_EPI_SILU_MUL));
+    RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.llm_mlp, R, VSTAR_EPI_SILU_MUL));
     RC(lin_auto(lact, c.llm_mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));
   }
   return 0;
@@ -378,8 +394,7 @@ int vstar_vqa_engine::forward(int nseq, const int32_t* row_off, const int32_t* s
   const size_t vpad = (size_t)(c.llm_vocab + 255) / 256 * 256;
   if (n_want) {
     KCHK(gather_rows(lx, d_want, wsel, n_want, H, stream));
-    KCHK(rmsnorm_lp(wsel, final_norm, wnorm, n_want, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin_auto(wnorm, H, lm_head, logits, (int64_t)vpad, n_want));
+    RC(lin_norm(wsel, final_norm, wnorm, lm_head, logits, (int64_t)vpad, n_want, VSTAR_EPI_NONE));
     KCHK(argmax_rows_lp(logits, n_want, c.llm_vocab, (int64_t)vpad, d_argmax, stream));
   }
   HIPCHK(hipEventRecord(ev1, stream));
@@ -460,12 +475,13 @@ int vstar_vqa_forward(vstar_vqa_handle* h, int nseq, const int32_t* row_off, con
 }
 
 int vstar_vqa_op_gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
-                      int epilogue, int kernel) {
+                      int epilogue, int kernel, const void* norm_w, float norm_eps) {
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || K % 64) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   GemmParams p{};
   const int n_out = epilogue == VSTAR_EPI_SILU_MUL ? N / 2 : N;
   p.A = (const lp_t*)A; p.lda = K; p.W = (const lp_t*)W; p.bias = (const lp_t*)bias; p.res = (const lp_t*)res; p.ldr = n_out;
   p.C = C; p.ldc = n_out; p.M = M; p.N = N; p.K = K;
+  p.norm_w = (const lp_t*)norm_w; p.norm_eps = norm_eps;
   hipError_t e;
   if (kernel == 1 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
   else e = gemm_lp(p, epilogue, false, nullptr);

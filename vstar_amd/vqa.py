@@ -133,6 +133,9 @@ class VQA_LLM:
         if object_crops is not None and len(object_crops) > 0:
             pix += [torch.as_tensor(c) for c in object_crops]
             n_obj = len(object_crops)
+        if first_slot + 1 + n_obj > self.cfg.max_images:
+            raise ValueError(f"{1 + n_obj} images/object crops exceed the engine's feature table (max_images="
+                             f"{self.cfg.max_images}); build the engine with a larger VQAConfig.max_images")
         self.engine.encode_images(torch.stack(pix, 0), first_slot)
         return [first_slot], list(range(first_slot + 1, first_slot + 1 + n_obj))
 
