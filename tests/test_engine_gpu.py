@@ -26,7 +26,7 @@ from vstar_amd.engine import VstarEngine, loc_positions
 from vstar_amd.weights import random_state_dict
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tiny*.npz")))
 
 
 def rel_l2(got, ref):
