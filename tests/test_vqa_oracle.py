@@ -109,3 +109,23 @@ def test_expand_ids_long_short_selection():
     rows = eng.expand_ids(ids, [0], [1, 2], [False], [True, False])
     assert len(rows) == 4 + L + P + L
     assert rows[2] == -(1 + P)                                            # slot 0, first short row
+
+
+def test_vqa_checkpoint_dir_roundtrip(tmp_path):
+    """HF-style directory (config.json + safetensors shard with the vision tower inside) -> engine key space."""
+    import json
+    from safetensors.torch import save_file
+    from vstar_amd.weights import load_vqa_checkpoint_dir, vqa_config_from_dir, vqa_state_dict_spec
+    cfg = VQAConfig.tiny(projector_type=1)
+    sd = random_state_dict(cfg, 3, torch.float16)
+    hf = {("model.vision_tower.vision_tower." + k[len("clip."):] if k.startswith("clip.") else k): v for k, v in sd.items()}
+    save_file(hf, str(tmp_path / "model.safetensors"))
+    json.dump({"hidden_size": cfg.llm_hidden, "num_attention_heads": cfg.llm_heads, "intermediate_size": cfg.llm_mlp,
+               "num_hidden_layers": cfg.llm_layers, "vocab_size": cfg.llm_vocab, "rms_norm_eps": 1e-5,
+               "mm_projector_type": "mlp2x_gelu", "mm_vision_select_layer": -2}, open(tmp_path / "config.json", "w"))
+    got = load_vqa_checkpoint_dir(str(tmp_path))
+    assert set(got) == set(vqa_state_dict_spec(cfg))
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    c2 = vqa_config_from_dir(str(tmp_path), clip_hidden=cfg.clip_hidden, clip_heads=cfg.clip_heads, clip_mlp=cfg.clip_mlp,
+                             clip_layers=cfg.clip_layers)
+    assert (c2.llm_hidden, c2.llm_layers, c2.projector_type, c2.llm_rms_eps) == (cfg.llm_hidden, cfg.llm_layers, 1, 1e-5)

@@ -88,7 +88,18 @@ class VQA_LLM:
                  tokenizer=None, engine: Optional[VqaEngine] = None, device: int = 0):
         """args: the reference's namespace (vqa_model_path, conv_type).  With a local checkpoint directory the weights and
         tokenizer are read from it; offline (this environment) pass `state_dict` (+ optionally `tokenizer`)."""
-        self.cfg = cfg or VQAConfig.seal_7b()
+        import os
+        from .weights import load_vqa_checkpoint_dir, vqa_config_from_dir
+        path = getattr(args, "vqa_model_path", None) if args is not None else None
+        real = engine is None and state_dict is None and path is not None and os.path.isdir(str(path))
+        if real:                      # load_pretrained_model(model_path, None, name) (builder.py:26-151), local files only
+            cfg = cfg or vqa_config_from_dir(path)
+            state_dict = load_vqa_checkpoint_dir(path, getattr(args, "vision_tower", None))
+            if tokenizer is None:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(path, use_fast=False)
+                tokenizer.add_tokens(["<im_patch>"], special_tokens=True)      # mm_use_im_patch_token default (builder.py:131-133)
+        self.cfg = cfg or (engine.cfg if engine is not None else VQAConfig.seal_7b())
         self.conv_type = getattr(args, "conv_type", "v1") if args is not None else "v1"
         if self.conv_type != "v1":
             raise ValueError("only the 'v1' conversation template of the reference evaluation is implemented")
@@ -96,10 +107,10 @@ class VQA_LLM:
         self.image_processor = _ImageProcessor(self.cfg.clip_image_size)
         self.context_len = 2048
         if engine is None:
-            engine = VqaEngine(self.cfg, device)
             if state_dict is None:
-                path = getattr(args, "vqa_model_path", None)
-                raise FileNotFoundError(f"no weights: pass state_dict= (checkpoint loading from '{path}' needs local files)")
+                raise FileNotFoundError(f"VQA-LLM checkpoint directory {path!r} not found and no state_dict given "
+                                        "(there is no hub access here; the engine has no CPU fallback)")
+            engine = VqaEngine(self.cfg, device)
             engine.load_state_dict(state_dict)
         self.engine = engine
         self.model = SimpleNamespace(config=SimpleNamespace(vocab_size=self.cfg.llm_vocab))

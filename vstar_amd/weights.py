@@ -249,26 +249,63 @@ def dense_pe(gaussian: torch.Tensor, grid: int = 48) -> torch.Tensor:
     return pe.reshape(grid * grid, 256).contiguous()
 
 
+def _read_shards(d: str) -> Dict[str, torch.Tensor]:
+    out: Dict[str, torch.Tensor] = {}
+    names = sorted(os.listdir(d))
+    st = [n for n in names if n.endswith(".safetensors")]
+    if st:
+        from safetensors.torch import load_file
+        for n in st:
+            out.update(load_file(os.path.join(d, n)))
+        return out
+    for n in names:
+        if n.endswith(".bin") and n.startswith("pytorch_model"):
+            out.update(torch.load(os.path.join(d, n), map_location="cpu", weights_only=True))
+    if not out:
+        raise FileNotFoundError(f"no weight shards in {d}")
+    return out
+
+
+def vqa_config_from_dir(vqa_dir: str, **overrides) -> VQAConfig:
+    """VQAConfig from the checkpoint's config.json (LlavaSearchConfig = LlamaConfig + mm_* fields)."""
+    import json
+    c = json.load(open(os.path.join(vqa_dir, "config.json")))
+    pt = c.get("mm_projector_type", "linear")
+    if pt not in ("linear", "mlp2x_gelu"):
+        raise ValueError(f"unsupported mm_projector_type {pt!r}")
+    kw = dict(llm_hidden=c["hidden_size"], llm_heads=c["num_attention_heads"], llm_mlp=c["intermediate_size"],
+              llm_layers=c["num_hidden_layers"], llm_vocab=c["vocab_size"], llm_rms_eps=c.get("rms_norm_eps", 1e-6),
+              llm_rope_theta=c.get("rope_theta", 10000.0), projector_type=0 if pt == "linear" else 1,
+              clip_select_layer=c.get("mm_vision_select_layer", -2))
+    kw.update(overrides)
+    return VQAConfig(**kw)
+
+
+def load_vqa_checkpoint_dir(vqa_dir: str, clip_dir: str | None = None) -> Dict[str, torch.Tensor]:
+    """HF `save_pretrained` directory of LlavaSearchLlamaForCausalLM (craigwu/seal_vqa_7b) -> engine key space.  The CLIP
+    tower is taken from the checkpoint when it carries one (`model.vision_tower.vision_tower.*`), else from `clip_dir`
+    (builder.py:137-140 loads it separately)."""
+    sd: Dict[str, torch.Tensor] = {}
+    vt = "model.vision_tower.vision_tower."
+    for k, v in _read_shards(vqa_dir).items():
+        if k.startswith(vt):
+            sd[CLIP_PREFIX + k[len(vt):]] = v
+        elif ".vision_tower." not in k:
+            sd[k] = v
+    if not any(k.startswith(CLIP_PREFIX) for k in sd):
+        if clip_dir is None:
+            raise FileNotFoundError("the checkpoint holds no CLIP tower; pass the openai/clip-vit-large-patch14 directory")
+        for k, v in _read_shards(clip_dir).items():
+            if k.startswith("vision_model."):
+                sd[CLIP_PREFIX + k] = v
+    return sd
+
+
 def load_checkpoint_dir(vsm_dir: str, clip_dir: str) -> Dict[str, torch.Tensor]:
     """Reads a HF `save_pretrained` directory of the VSM (safetensors or .bin shards) plus the CLIP tower directory and
     returns one state dict in the engine's key space (CLIP keys prefixed with `clip.`)."""
     sd: Dict[str, torch.Tensor] = {}
-
-    def _read(d: str) -> Dict[str, torch.Tensor]:
-        out: Dict[str, torch.Tensor] = {}
-        names = sorted(os.listdir(d))
-        st = [n for n in names if n.endswith(".safetensors")]
-        if st:
-            from safetensors.torch import load_file
-            for n in st:
-                out.update(load_file(os.path.join(d, n)))
-            return out
-        for n in names:
-            if n.endswith(".bin") and n.startswith("pytorch_model"):
-                out.update(torch.load(os.path.join(d, n), map_location="cpu", weights_only=True))
-        if not out:
-            raise FileNotFoundError(f"no weight shards in {d}")
-        return out
+    _read = _read_shards
 
     for k, v in _read(vsm_dir).items():
         if ".vision_tower." in k:

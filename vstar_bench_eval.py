@@ -1,10 +1,8 @@
 #!/usr/bin/env python
-"""V*Bench end-to-end entry point (reference: vstar_bench_eval.py:168-293).
-
-The visual-search stage runs on the HIP engine.  The SEAL VQA-LLM (`load_pretrained_model`, `free_form_inference`,
-`multiple_choices_inference`; LLaVA/llava/model/builder.py:26-151, vstar_bench_eval.py:38-165) is the next scope row
- and is NOT built yet: supply `--vqa-llm module:factory` returning an object with those two methods
-(e.g. the reference's own VQA_LLM on another device) or this script stops with a clear error.
+"""V*Bench end-to-end entry point (reference: vstar_bench_eval.py:168-293), both models on the HIP engines:
+the SEAL VQA-LLM (`vstar_amd.vqa.VQA_LLM`, fp16, KV-cached) and the visual-search model (`vstar_amd.vsm.VSM`, bf16).
+`--vqa-model-path` / `--vsm-model-path` are local HF checkpoint directories (there is no hub access in this environment);
+`--vqa-llm module:factory` substitutes another object with the reference's VQA_LLM interface.
 """
 from __future__ import annotations
 
@@ -23,17 +21,19 @@ def parse_args(argv):
     p.add_argument("--output-path", type=str, default="eval_result.json")
     p.add_argument("--minimum_size_scale", default=4.0, type=float)
     p.add_argument("--minimum_size", default=224, type=int)
-    p.add_argument("--vqa-llm", default=None, help="module:factory providing the VQA-LLM (not part of this engine yet)")
+    p.add_argument("--vision-tower", dest="vision_tower", default=None, help="local openai/clip-vit-large-patch14 directory")
+    p.add_argument("--vqa-llm", default=None, help="module:factory providing another VQA-LLM implementation")
     return p.parse_args(argv)
 
 
 def main(argv):
     args = parse_args(argv)
-    if not args.vqa_llm:
-        raise SystemExit("vstar_bench_eval: the SEAL VQA-LLM forward/generate is not built in this engine yet "
-                         "(SURVEY.md §8f-2). Pass --vqa-llm module:factory, or run visual_search.py for the search stage.")
-    mod, fn = args.vqa_llm.split(":")
-    vqa_llm = getattr(importlib.import_module(mod), fn)(args)
+    if args.vqa_llm:
+        mod, fn = args.vqa_llm.split(":")
+        vqa_llm = getattr(importlib.import_module(mod), fn)(args)
+    else:
+        from vstar_amd.vqa import VQA_LLM
+        vqa_llm = VQA_LLM(args)
     from vstar_amd.bench_eval import eval_model
     eval_model(args, vqa_llm)
 
