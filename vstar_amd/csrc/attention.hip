@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;       // scale > 0: max commutes with the scaling
         if (__any(mx > m + RESCALE_THR)) {                            // wave-uniform
           const float m_new = fmaxf(m, mx);
-          const float alpha = exp2f(m - m_new);
+          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
           l *= alpha;
           m = m_new;
 #pragma unroll
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          p[r] = exp2f(fmaf(sacc[r], scale_log2e, -m));               // masked: exp2(-1e30*c - m) = 0
+          p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -m));               // masked: exp2(-1e30*c - m) = 0
           rs += p[r];
         }
         rs += __shfl_xor(rs, 32, 64);
