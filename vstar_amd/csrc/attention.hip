@@ -10,8 +10,8 @@
 //   the tile's 32 keys, so the online-softmax statistics are per-lane scalars (one shuffle with lane^32).
 //   O^T = V^T P^T: P^T is fed straight from the S^T accumulator registers (the contraction order over keys is
 //   permuted identically on the V^T side), so no cross-lane movement or LDS round trip for P.
-//   V^T comes from a [B,H,D,Spad] buffer written once per layer by attn_prepare, keys permuted so that every PV operand
-//   fragment is one 16-byte LDS read.
+//   V tiles are DMA'd untransposed ([key][d], as they lie in the qkv buffer) and transposed on the way out of LDS by
+//   ds_read_b64_tr_b16 (two transpose reads per PV operand fragment): no V^T pass, no V^T buffer.
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
@@ -52,39 +52,6 @@ __global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos
   *(lpx8*)(base + d0 + half) = o2;
 }
 
-// ---------------- V -> V^T [B,H,D,Spad] through a padded LDS tile (64 positions x D) ----------------
-// Keys are stored PERMUTED inside every aligned group of 16 (bits 2 and 3 of the position swapped): the PV MFMA's A operand
-// for half-wave h2 and k-block j needs keys 16j + 4*h2 + {0..3} and 16j + 8 + 4*h2 + {0..3} (the keys whose probabilities
-// that lane holds in its S^T accumulator registers); with the swap they are the 8 consecutive positions 16j + 8*h2 + {0..7},
-// i.e. ONE 16-byte fragment.
-template <int D>
-__global__ __launch_bounds__(256) void vt_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ vt, int S, int Spad,
-                                                 int H) {
-  __shared__ lp_t tile[64][D + 2];
-  const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-  const int tid = threadIdx.x;
-  constexpr int VPR = D / 8;  // 16-B vectors per row
-  for (int i = tid; i < 64 * VPR; i += 256) {
-    const int r = i / VPR, cv = i - r * VPR;
-    const int s = s0 + r;
-    lpx8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (s < S) v = *(const lpx8*)(qkv + ((int64_t)b * S + s) * (3 * H * D) + 2 * H * D + h * D + cv * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) tile[r][cv * 8 + e] = (lp_t)v[e];
-  }
-  __syncthreads();
-  // each thread writes 8 consecutive positions of one d-row: 64 positions = 8 vectors per d-row
-  for (int i = tid; i < D * 8; i += 256) {
-    const int d = i >> 3, sv = i & 7;
-    if (s0 + sv * 8 >= Spad) continue;
-    lpx8 o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)   // position p holds key (p with bits 2 and 3 swapped): see attn2_kernel's PV operand
-      o[e] = (short)tile[(sv & ~1) * 8 + ((e >> 2) << 3) + ((sv & 1) << 2) + (e & 3)][d];
-    *(lpx8*)(vt + (((int64_t)b * H + h) * D + d) * Spad + s0 + sv * 8) = o;
-  }
-}
-
 // ---------------- flash attention forward, v2: K / V^T tiles staged through LDS ----------------
 // Same per-wave math as attn_kernel, but the 64-key K tile [64][D] and V^T tile [D][64] are DMA'd once per block
 // (global_load_lds, whole 128/256-byte lines) into a double-buffered LDS ring and shared by the block's 4 waves, instead of
@@ -92,14 +59,13 @@ __global__ __launch_bounds__(256) void vt_kernel(const lp_t* __restrict__ qkv, l
 // DMA source address and on the read address) keep the ds_read_b128 K-fragment reads conflict-free and the ds_read_b64
 // V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
 template <int D, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, const lp_t* __restrict__ vt,
-                                                    lp_t* __restrict__ out, int S, int Spad, int H, float scale_log2e) {
+__global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ out, int S, int H,
+                                                    float scale_log2e) {
   constexpr int KS = D / 16, DB = D / 32;
-  constexpr int KBYTES = 64 * D * 2;               // K tile = V^T tile bytes
+  constexpr int KBYTES = 64 * D * 2;               // K tile = V tile bytes
   constexpr int KCH = D / 8;                        // 16-B chunks per K row
   constexpr int KROWS_PER_INST = 64 / KCH;          // K rows covered by one wave-wide DMA instruction
   constexpr int K_INST = 64 / KROWS_PER_INST / 4;   // K DMA instructions per wave per tile (4 waves)
-  constexpr int V_INST = D / 8 / 4;                 // V^T: D rows x 8 chunks, 8 rows per instruction
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -114,7 +80,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const int qrow = query < S ? query : S - 1;
   const int64_t ld = 3 * (int64_t)H * D;
   const lp_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
-  const lp_t* Vg = vt + ((int64_t)b * H + h) * D * (int64_t)Spad;
+  const lp_t* Vg = qkv + (int64_t)b * S * ld + 2 * (int64_t)H * D + h * D;      // V rows of the fused qkv buffer
 
   // per-lane DMA sources
   const lp_t* ksrc[K_INST];
@@ -127,12 +93,17 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
     krow_l[i] = row;
     ksrc[i] = Kg + (ch ^ sw) * 8;
   }
-  const lp_t* vsrc[V_INST];
+  // V: the tile as it lies in the qkv buffer, [64 keys][D], DMA'd like the K tile and transposed on the way OUT of LDS by
+  // ds_read_b64_tr_b16.  Its 16-byte chunks are swizzled per QUAD of chunks (64 bytes = what one half-wave reads of a key
+  // row): quad' = quad ^ g(key), g = (key >> 1) & 1 for 128-byte rows and key & 3 for 256-byte rows, so that the 4 key rows
+  // one transpose read touches fall into different bank groups.
+  const lp_t* vsrc[K_INST];
 #pragma unroll
-  for (int i = 0; i < V_INST; ++i) {
-    const int d = (i * 4 + wave) * 8 + (lane >> 3);
-    const int ch = lane & 7;
-    vsrc[i] = Vg + (int64_t)d * Spad + (ch ^ ((d >> 1) & 7)) * 8;
+  for (int i = 0; i < K_INST; ++i) {
+    const int row = (i * 4 + wave) * KROWS_PER_INST + lane / KCH;
+    const int ch = lane % KCH;
+    const int gq = (D == 64) ? ((row >> 1) & 1) : (row & 3);
+    vsrc[i] = Vg + (ch ^ (gq << 2)) * 8;
   }
   auto stage = [&](int t) {
     char* base = smem + (t & 1) * 2 * KBYTES;
@@ -144,9 +115,20 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
       __builtin_amdgcn_global_load_lds((gptr_t)(ksrc[i] + (int64_t)kr * ld), (lptr_t)(base + (i * 4 + wave) * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < V_INST; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + kt0), (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+    for (int i = 0; i < K_INST; ++i) {
+      int kr = kt0 + krow_l[i];
+      kr = kr < S ? kr : S - 1;                      // rows past S: their probabilities are exactly 0
+      __builtin_amdgcn_global_load_lds((gptr_t)(vsrc[i] + (int64_t)kr * ld), (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, 0,
+                                       0);
+    }
   };
+  // transpose-read addressing (ds_read_b64_tr_b16: inside a 16-lane group lane t supplies the 8-byte piece
+  // V[key0 + t/4][d0 + 4*(t%4) ..+3] and receives V[key0 + 0..3][d0 + t]): lane = (MFMA row d = lane % 32, key half h2)
+  typedef __attribute__((ext_vector_type(4))) short s4_t;
+  typedef __attribute__((address_space(3))) s4_t* lds_s4_t;
+  const int t16 = lane & 15, g16 = (lane >> 4) & 1;
+  const int tr_gq = (D == 64) ? ((t16 >> 3) & 1) : (t16 >> 2);      // g(key) of this lane's key row (key0 % 4 == 0)
+  const int tr_off = ((t16 >> 2) + 4 * h2) * (D * 2) + (2 * g16 + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;
 
   const lp_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
   lpx8 qf[KS];
@@ -167,7 +149,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   for (int t = 0; t < nkt; ++t) {
     if (t + 1 < nkt) {
       stage(t + 1);
-      if (K_INST + V_INST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (2 * K_INST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -236,11 +218,14 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
           lpx8 pb;
 #pragma unroll
           for (int i = 0; i < 8; ++i) pb[i] = (short)f2lp(p[8 * j + i]);
-          const int vc = st * 4 + 2 * j + h2;                   // 16-byte chunk holding this lane's 8 (permuted) keys
 #pragma unroll
           for (int db = 0; db < DB; ++db) {
-            const int d = db * 32 + qi;
-            const lpx8 vf = *(const lpx8*)(vb + d * 128 + ((vc ^ ((d >> 1) & 7)) * 16));
+            // keys 16j + 4*h2 + {0..3} and 16j + 8 + 4*h2 + {0..3} of sub-tile st (the keys whose probabilities this lane
+            // holds in pb): two transpose reads
+            const char* a0 = vb + (st * 32 + 16 * j) * (D * 2) + tr_off + ((db ^ tr_gq) * 64);
+            const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)a0);
+            const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(a0 + 8 * (D * 2)));
+            const lpx8 vf = (lpx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             oacc[db] = mfma_32x32x16(vf, pb, oacc[db]);
           }
         }
@@ -407,22 +392,17 @@ __global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const lp_t* __r
 
 }  // namespace
 
-hipError_t attn_prepare(lp_t* qkv, lp_t* vt, const lp_t* cos_sin, int B, int S, int Spad, int H, int D, hipStream_t s) {
+hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin, int B, int S, int H, int D, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
-  if (Spad % 64 != 0 || Spad < S) return hipErrorInvalidValue;
   if (cos_sin) {
     const int64_t n = (int64_t)B * S * 2 * H * (D / 16);
     hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_sin, B * S, S, H, D);
   }
-  dim3 grid(Spad / 64, H, B);
-  if (D == 64) hipLaunchKernelGGL(vt_kernel<64>, grid, dim3(256), 0, s, qkv, vt, S, Spad, H);
-  else hipLaunchKernelGGL(vt_kernel<128>, grid, dim3(256), 0, s, qkv, vt, S, Spad, H);
   return hipGetLastError();
 }
 
 template <int D, bool CAUSAL>
-static hipError_t launch_attn2(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, float sl,
-                               hipStream_t s) {
+static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, float sl, hipStream_t s) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
   auto kern = attn2_kernel<D, CAUSAL>;
@@ -432,18 +412,15 @@ static hipError_t launch_attn2(const lp_t* qkv, const lp_t* vt, lp_t* out, int B
     attr_done = true;
   }
   dim3 grid((S + 127) / 128, H, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, vt, out, S, Spad, H, sl);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl);
   return hipGetLastError();
 }
 
-hipError_t attn_forward(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, int D, int causal,
-                        float scale, hipStream_t s) {
+hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
-  if (D == 64) return causal ? launch_attn2<64, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                             : launch_attn2<64, false>(qkv, vt, out, B, S, Spad, H, sl, s);
-  return causal ? launch_attn2<128, true>(qkv, vt, out, B, S, Spad, H, sl, s)
-                : launch_attn2<128, false>(qkv, vt, out, B, S, Spad, H, sl, s);
+  if (D == 64) return causal ? launch_attn2<64, true>(qkv, out, B, S, H, sl, s) : launch_attn2<64, false>(qkv, out, B, S, H, sl, s);
+  return causal ? launch_attn2<128, true>(qkv, out, B, S, H, sl, s) : launch_attn2<128, false>(qkv, out, B, S, H, sl, s);
 }
 
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,

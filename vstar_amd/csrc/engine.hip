@@ -30,8 +30,8 @@ struct vstar_engine : EngineBase {
   Lin hyp0, hyp1, hyp2;
 
   // LLM activations
-  int Smax = 0, llm_spad = 0;
-  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr, *lvt = nullptr;
+  int Smax = 0;
+  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
   lp_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
   lp_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
   float* vlogits = nullptr;    // [B*V, vocab]
@@ -114,7 +114,6 @@ int vstar_engine::finalize() {
   RC(upload_vec("model.norm.weight", &final_norm, H));
   RC(make_lin({"lm_head.weight"}, {}, &lm_head, H));
   Smax = c.max_text_len - 1 + clip.P;
-  llm_spad = (Smax + 63) / 64 * 64;
   {  // rotate-half RoPE table, HF LlamaRotaryEmbedding: inv_freq = theta^(-2i/d), fp32, cast to bf16 before use
     std::vector<lp_t> tab((size_t)Smax * 128);
     for (int s = 0; s < Smax; ++s)
@@ -133,7 +132,6 @@ int vstar_engine::finalize() {
   RC(dalloc(&lqkv, lrows * 3 * H));
   RC(dalloc(&latt, lrows * H));
   RC(dalloc(&lact, lrows * c.llm_mlp));
-  RC(dalloc(&lvt, (size_t)maxB * H * llm_spad));
   RC(dalloc(&hsel, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_att, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_x, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
@@ -400,15 +398,14 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   KCHK(llm_embed_text(d_ids, L, img_col, P, embed, c.llm_vocab, lx, B, H, stream));
   // ---- a5: LLaMA prefill (HF LlamaModel via llava_llama.py:93-102) ----
   const int rows = B * S;
-  const int Spad = (S + 63) / 64 * 64;
   const float att_scale = 1.0f / sqrtf(128.0f);
   const int nsel = B * (1 + n_verify);
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
     KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
-    KCHK(attn_prepare(lqkv, lvt, rope, B, S, Spad, c.llm_heads, 128, stream));
-    KCHK(attn_forward(lqkv, lvt, latt, B, S, Spad, c.llm_heads, 128, 1, att_scale, stream));
+    KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
+    KCHK(attn_forward(lqkv, latt, B, S, c.llm_heads, 128, 1, att_scale, stream));
     if (i + 1 == c.llm_layers) {
       // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
       // attention is row-wise, so o_proj / MLP run on those B*(1+V) gathered rows only (row-wise ops: bit-identical).
@@ -729,18 +726,16 @@ int vstar_op_rmsnorm(void* stream, const uint16_t* x, const uint16_t* g, uint16_
   return op_rc(e);
 }
 size_t vstar_op_attention_workspace(int B, int S, int H, int D) {
-  const size_t Spad = ((size_t)S + 63) / 64 * 64;
-  return (size_t)B * H * D * Spad * 2 + (size_t)S * D * 2 + 256;
+  (void)B; (void)H;
+  return (size_t)S * D * 2 + 256;     // the RoPE cos|sin table only: V is transposed inside the kernel (no V^T buffer)
 }
 int vstar_op_attention(void* stream, uint16_t* qkv, uint16_t* out, void* ws, size_t ws_bytes, int B, int S, int H, int D,
                        int causal, float rope_theta) {
   if (ws_bytes < vstar_op_attention_workspace(B, S, H, D)) { tls_error() = "attention workspace too small"; return VSTAR_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
-  const int Spad = (S + 63) / 64 * 64;
-  lp_t* vt = (lp_t*)ws;
   lp_t* cs = nullptr;
   if (rope_theta > 0.f) {
-    cs = vt + (((size_t)B * H * D * Spad + 127) / 128 * 128);
+    cs = (lp_t*)ws;
     std::vector<lp_t> tab((size_t)S * D);
     for (int p = 0; p < S; ++p)
       for (int i = 0; i < D / 2; ++i) {
@@ -751,8 +746,8 @@ int vstar_op_attention(void* stream, uint16_t* qkv, uint16_t* out, void* ws, siz
     hipError_t e = hipMemcpy(cs, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
     if (e != hipSuccess) return op_rc(e);
   }
-  hipError_t e = attn_prepare(qkv, vt, cs, B, S, Spad, H, D, s);
-  if (e == hipSuccess) e = attn_forward(qkv, vt, out, B, S, Spad, H, D, causal, 1.0f / sqrtf((float)D), s);
+  hipError_t e = attn_prepare(qkv, cs, B, S, H, D, s);
+  if (e == hipSuccess) e = attn_forward(qkv, out, B, S, H, D, causal, 1.0f / sqrtf((float)D), s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   return op_rc(e);
 }

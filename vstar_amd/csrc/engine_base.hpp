@@ -35,9 +35,7 @@ struct VitTower {
   Lin patch_lin; lp_t *cls = nullptr, *pos = nullptr, *pre_g = nullptr, *pre_b = nullptr;
   std::vector<VitBlock> blocks;
   // activations
-  lp_t *im2col = nullptr, *patch_out = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp_buf = nullptr,
-         *vt = nullptr;
-  int Spad = 0;
+  lp_t *im2col = nullptr, *patch_out = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp_buf = nullptr;
 };
 struct LlmBlock { lp_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; };
 
@@ -286,7 +284,6 @@ inline int EngineBase::build_tower(VitTower& t, const std::string& pre, const st
     RC(make_lin({lp + "mlp.fc2.weight"}, {lp + "mlp.fc2.bias"}, &b.fc2, mlp));
   }
   const size_t rows = (size_t)maxB * t.N;
-  t.Spad = (t.N + 63) / 64 * 64;
   RC(dalloc(&t.im2col, (size_t)maxB * t.P * t.kpad));
   RC(dalloc(&t.patch_out, (size_t)maxB * t.P * hidden));
   RC(dalloc(&t.x, rows * hidden));
@@ -294,7 +291,6 @@ inline int EngineBase::build_tower(VitTower& t, const std::string& pre, const st
   RC(dalloc(&t.qkv, rows * 3 * hidden));
   RC(dalloc(&t.att, rows * hidden));
   RC(dalloc(&t.mlp_buf, rows * mlp));
-  RC(dalloc(&t.vt, (size_t)maxB * hidden * t.Spad));
   return 0;
 }
 
@@ -309,8 +305,7 @@ inline int EngineBase::run_tower(VitTower& t, const lp_t* pix, int B) {
     VitBlock& b = t.blocks[i];
     KCHK(layernorm_lp(t.x, b.ln1_g, b.ln1_b, t.h, rows, C, 1e-5f, nullptr, 0, stream));
     RC(lin(t.h, C, b.qkv, t.qkv, 3 * C, rows));
-    KCHK(attn_prepare(t.qkv, t.vt, nullptr, B, t.N, t.Spad, t.heads, 64, stream));
-    KCHK(attn_forward(t.qkv, t.vt, t.att, B, t.N, t.Spad, t.heads, 64, 0, 0.125f, stream));
+    KCHK(attn_forward(t.qkv, t.att, B, t.N, t.heads, 64, 0, 0.125f, stream));
     RC(lin(t.att, C, b.out, t.x, C, rows, VSTAR_EPI_NONE, t.x, C));
     KCHK(layernorm_lp(t.x, b.ln2_g, b.ln2_b, t.h, rows, C, 1e-5f, nullptr, 0, stream));
     RC(lin(t.h, C, b.fc1, t.mlp_buf, t.mlp, rows, VSTAR_EPI_QUICK_GELU));

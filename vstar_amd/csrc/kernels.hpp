@@ -52,11 +52,10 @@ hipError_t rmsnorm_lp(const lp_t* x, const lp_t* gamma, lp_t* y, int rows, int c
                         const int32_t* row_index, hipStream_t s);
 
 // ---- attention (attention.hip) ----
-// qkv: [B*S, 3*H*D] (q | k | v).  rope_and_vt: in-place rotate-half RoPE on q,k (if cs != null) and V^T -> vt[B,H,D,Spad]
-hipError_t attn_prepare(lp_t* qkv, lp_t* vt, const lp_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), bf16, or null*/,
-                        int B, int S, int Spad, int H, int D, hipStream_t s);
-hipError_t attn_forward(const lp_t* qkv, const lp_t* vt, lp_t* out, int B, int S, int Spad, int H, int D,
-                        int causal, float scale, hipStream_t s);
+// qkv: [B*S, 3*H*D] (q | k | v).  attn_prepare: in-place rotate-half RoPE on q,k (no-op when cos_sin == null)
+hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), or null*/, int B, int S, int H, int D,
+                        hipStream_t s);
+hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s);
 // generic small attention for the SAM head: q[B,Nq,H*D] k[B,Nk,H*D] v[B,Nk,H*D] -> out[B,Nq,H*D]; D <= 32, fp32 math
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,
                            int D, hipStream_t s);

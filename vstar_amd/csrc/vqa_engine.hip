@@ -36,7 +36,7 @@ struct vstar_vqa_engine : EngineBase {
   lp_t *kcache = nullptr, *vcache = nullptr;   // [layers][slots][heads][ctx][128]
   int64_t slot_stride = 0, layer_stride = 0;
   // activations
-  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr, *lvt = nullptr;
+  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
   lp_t *wsel = nullptr, *wnorm = nullptr, *logits = nullptr;
   int32_t *d_src = nullptr, *d_row_pos = nullptr, *d_row_slot = nullptr, *d_row_seq = nullptr, *d_seq = nullptr, *d_want = nullptr,
           *d_argmax = nullptr, *d_latidx = nullptr, *d_patchidx = nullptr;
@@ -179,7 +179,6 @@ int vstar_vqa_engine::finalize() {
   RC(dalloc(&lqkv, R * 3 * H));
   RC(dalloc(&latt, R * H));
   RC(dalloc(&lact, R * c.llm_mlp));
-  RC(dalloc(&lvt, R * H + (size_t)64 * H * c.max_slots * 4));       // V^T of a padded prefill batch: [nseq, H*128, Spad]
   max_want = 256;
   const size_t vpad = (size_t)(c.llm_vocab + 255) / 256 * 256;
   RC(dalloc(&wsel, (size_t)max_want * H));
@@ -287,7 +286,7 @@ int vstar_vqa_engine::encode(int n, const uint16_t* pix, int first_slot) {
 
 int vstar_vqa_engine::llm_layers_prefill(int nseq, int S) {
   const vstar_vqa_config& c = cfg;
-  const int H = c.llm_hidden, rows = nseq * S, Spad = (S + 63) / 64 * 64;
+  const int H = c.llm_hidden, rows = nseq * S;
   const float att_scale = 1.0f / sqrtf(128.0f);
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
@@ -295,8 +294,7 @@ int vstar_vqa_engine::llm_layers_prefill(int nseq, int S) {
     RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
     KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kcache + (int64_t)i * layer_stride, vcache + (int64_t)i * layer_stride,
                         slot_stride, c.max_ctx, rows, c.llm_heads, stream));
-    KCHK(attn_prepare(lqkv, lvt, nullptr, nseq, S, Spad, c.llm_heads, 128, stream));
-    KCHK(attn_forward(lqkv, lvt, latt, nseq, S, Spad, c.llm_heads, 128, 1, att_scale, stream));
+    KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream));
     RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
     KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
     RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
