@@ -1,5 +1,6 @@
 // gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
-// 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 6 quarter-tiles ahead behind COUNTED vmcnt waits, and two
+// 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 6 quarter-tiles ahead behind COUNTED vmcnt waits (the first
+// K-tile of the next output tile is already in flight during the epilogue), and two
 // wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA cluster while its partner issues
 // ds_reads / DMA ("8-phase" structure of the CDNA4 guide, §5 "256^2 8-phase template", re-derived for this layout).
 //
@@ -60,48 +61,52 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // persistent: this workgroup walks tiles blockIdx.x, +gridDim.x, ... (gridDim.x = #CUs, a multiple of 8, so a
   // workgroup's tiles keep its XCD in the remap below).  The previous tile's output stores drain while the next
   // tile's first DMA pieces are in flight, and there is no per-tile workgroup launch.
-  for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
-  int t;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 8;
-  const int in_group = GROUP_M * tiles_n;
-  const int grp = t / in_group;
-  const int first_m = grp * GROUP_M;
-  const int gsz = min(tiles_m - first_m, GROUP_M);
-  const int rem = t - grp * in_group;
-  const int tm = first_m + rem % gsz;
-  const int tn = rem / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- DMA pieces: piece type j in {a0, w0, w1, a1}; each wave moves row-groups g = 2*wave + u (u = 0,1) ----
-  // A piece (m-half mh): 8-row group g -> tile rows (g>>3)*128 + mh*64 + (g&7)*8 ..+8
-  // W piece (n-half nh): 8-row group g -> tile rows (g>>2)*64  + nh*32 + (g&3)*8 ..+8
+  // The first K-tile of the NEXT output tile is DMA'd (into ring buffer 0, dead by then) BEFORE the epilogue of the
+  // current one, whose LDS slabs live in ring buffer 1 (where the last K-tile — K/64 is even — was just consumed): the
+  // pipeline fill of a tile overlaps the output stores of its predecessor.
   const int st_r = lane >> 3, st_c = lane & 7;
   uint32_t src_off[4][2];   // element offset of this lane's 16-B chunk at k0 = 0, per piece type and u
   int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
+  int m0 = 0, n0 = 0;
+  // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering; DMA source offsets of that tile ----
+  // DMA pieces: piece type j in {a0, w0, w1, a1}; each wave moves row-groups g = 2*wave + u (u = 0,1)
+  //   A piece (m-half mh): 8-row group g -> tile rows (g>>3)*128 + mh*64 + (g&7)*8 ..+8
+  //   W piece (n-half nh): 8-row group g -> tile rows (g>>2)*64  + nh*32 + (g&3)*8 ..+8
+  auto set_tile = [&](int bid) {
+    int t;
+    {
+      const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int in_group = GROUP_M * tiles_n;
+    const int grp = t / in_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int rem = t - grp * in_group;
+    m0 = (first_m + rem % gsz) * BM;
+    n0 = (rem / gsz) * BN;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int g = 2 * wave + u;
-      const bool isA = (j == 0 || j == 3);
-      const int half = (j == 0 || j == 1) ? 0 : 1;     // a0,w0 -> half 0 ; w1,a1 -> half 1
-      const int row0 = isA ? ((g >> 3) * 128 + half * 64 + (g & 7) * 8) : ((g >> 2) * 64 + half * 32 + (g & 3) * 8);
-      const int row = row0 + st_r;
-      const int cg = st_c ^ ((row >> 1) & 7);
-      lds_off[j][u] = (isA ? 0 : A_BYTES) + row0 * 128;
-      if (isA) {
-        int ar = m0 + row;
-        ar = ar < p.M ? ar : p.M - 1;
-        src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8);
-      } else {
-        src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K + cg * 8);
+      for (int u = 0; u < 2; ++u) {
+        const int g = 2 * wave + u;
+        const bool isA = (j == 0 || j == 3);
+        const int half = (j == 0 || j == 1) ? 0 : 1;     // a0,w0 -> half 0 ; w1,a1 -> half 1
+        const int row0 = isA ? ((g >> 3) * 128 + half * 64 + (g & 7) * 8) : ((g >> 2) * 64 + half * 32 + (g & 3) * 8);
+        const int row = row0 + st_r;
+        const int cg = st_c ^ ((row >> 1) & 7);
+        lds_off[j][u] = (isA ? 0 : A_BYTES) + row0 * 128;
+        if (isA) {
+          int ar = m0 + row;
+          ar = ar < p.M ? ar : p.M - 1;
+          src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8);
+        } else {
+          src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K + cg * 8);
+        }
       }
     }
-  }
+  };
   const int total_pieces = (p.K / BK) * 4;
   // piece type J is a compile-time constant at every call site, so src_off / lds_off stay in registers
   auto issue_piece = [&](auto jc, int T) {
@@ -125,22 +130,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     w_rd[kk] = A_BYTES + (wc * 64 + fr) * 128 + ch;
   }
 
+  int bid = blockIdx.x;
+  if (bid >= nwg) return;
+  set_tile(bid);
+  issue_piece(std::integral_constant<int, 0>{}, 0);
+  issue_piece(std::integral_constant<int, 1>{}, 0);
+  issue_piece(std::integral_constant<int, 2>{}, 0);
+  issue_piece(std::integral_constant<int, 3>{}, 0);
+  for (;;) {
   f32x4 acc[8][4];
 #pragma unroll
   for (int m = 0; m < 8; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // ---- prologue: pieces 0..5 in flight, pieces 0..2 (a0, w0, w1 of K-tile 0) landed, everyone past the barrier; group 1
-  // runs one barrier behind group 0 ----
-  BAR();   // every wave has finished reading its epilogue slab of the previous tile: the ring may be overwritten
-  issue_piece(std::integral_constant<int, 0>{}, 0);
-  issue_piece(std::integral_constant<int, 1>{}, 0);
-  issue_piece(std::integral_constant<int, 2>{}, 0);
-  issue_piece(std::integral_constant<int, 3>{}, 0);
+  // ---- prologue: K-tile 0 (pieces a0, w0, w1, a1) was issued before the previous tile's epilogue (or at kernel start);
+  // add a0, w0 of K-tile 1 once every wave has left its epilogue slab (ring buffer 1), then wait until a0, w0, w1 of
+  // K-tile 0 have landed.  Issue order: [4 pieces of K-tile 0][the previous epilogue's stores/loads][these 2 pieces]; vmcnt
+  // retires in order, so at most 6 outstanding leaves only the 2 new pieces (4 DMAs) + 2 older ops in flight.  Group 1 runs
+  // one barrier behind group 0.
+  BAR();
   issue_piece(std::integral_constant<int, 0>{}, 1);
   issue_piece(std::integral_constant<int, 1>{}, 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // pieces 3,4,5 may still be in flight (K >= 128: they exist)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   BAR();
   if (group == 1) BAR();
 
@@ -207,38 +219,50 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   }
   if (group == 0) BAR();   // every wave must execute the same number of barriers
 
+  // ---- next tile: its K-tile 0 goes into ring buffer 0 now; this tile's coordinates stay in em0/en0 for the epilogue ----
+  const int em0 = m0, en0 = n0;
+  bid += gridDim.x;
+  const bool has_next = bid < nwg;
+  if (has_next) {
+    set_tile(bid);
+    issue_piece(std::integral_constant<int, 0>{}, 0);
+    issue_piece(std::integral_constant<int, 1>{}, 0);
+    issue_piece(std::integral_constant<int, 2>{}, 0);
+    issue_piece(std::integral_constant<int, 3>{}, 0);
+  }
+
   // ---- epilogue ----
-  if (p.debug_flags & 2) continue;
+  if (!(p.debug_flags & 2)) {
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
   if constexpr (OUT_F32) {
     // fp32 outputs (lm_head / head taps): direct accumulator-layout stores
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      const int row = m0 + wr * 128 + m * 16 + fr;
+      const int row = em0 + wr * 128 + m * 16 + fr;
       if (row >= p.M) continue;
       const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
       if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          gemm_epilogue_store<EPI, OUT_F32>(p, crow, (n0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, (en0 + wc * 64) / 2 + j * 16 + fq * 4, n_out, acc[m][2 * j], acc[m][2 * j + 1]);
       } else {
 #pragma unroll
         for (int n = 0; n < 4; ++n)
-          gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
+          gemm_epilogue_store<EPI, OUT_F32>(p, crow, en0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
       }
     }
   } else {
-    // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab (the ring is
-    // dead: every wave is past the last barrier and every DMA has landed), then activation / residual and whole-line
-    // 16-B stores from a ROLLED loop (keeps the epilogue's code footprint small: it runs once per tile and an
+    // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab — 32 rows at a time, in
+    // ring buffer 1 (dead: every wave is past the last barrier; buffer 0 is already receiving the next tile) — then
+    // activation / residual and whole-line 16-B stores from a ROLLED loop (keeps the epilogue's code footprint small: it runs once per tile and an
     // unrolled 32-fragment epilogue with tail paths was ~10k instructions of cold i-cache).
     constexpr int WCOLS = (EPI == VSTAR_EPI_SILU_MUL) ? 32 : 64;     // output columns owned by this wave
     constexpr int NF = WCOLS / 16;                                    // 16-column fragments
     constexpr int RSTRIDE = WCOLS * 2 + 16;                           // padded LDS row (bytes)
     constexpr int CH = WCOLS / 8;                                     // 16-B chunks per row
     constexpr int RPI = 64 / CH;                                      // rows per wave-wide 16-B access
-    char* slab = smem + wave * (64 * (128 + 16));
-    const int colbase = (EPI == VSTAR_EPI_SILU_MUL) ? (n0 + wc * 64) / 2 : n0 + wc * 64;
+    char* slab = smem + TILE_BYTES + wave * (32 * (128 + 16));
+    const int colbase = (EPI == VSTAR_EPI_SILU_MUL) ? (en0 + wc * 64) / 2 : en0 + wc * 64;
     // bias for this lane's 4-column groups (clamped: columns >= n_out are computed but never stored)
     float bias_v[NF][4];
 #pragma unroll
@@ -255,30 +279,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
     }
     const int rl0 = lane / CH, ch = lane % CH;
-    auto half_pass = [&](auto mhc) {
-      constexpr int mh = decltype(mhc)::value;
+    auto quarter_pass = [&](auto qc) {
+      constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+      for (int m = 0; m < 2; ++m) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
           lpx4 v;
           if (EPI == VSTAR_EPI_SILU_MUL) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              v[e] = (short)f2lp(act_silu_bf16(rlp(acc[mh * 4 + m][2 * f][e])) * rlp(acc[mh * 4 + m][2 * f + 1][e]));
+              v[e] = (short)f2lp(act_silu_bf16(rlp(acc[qp * 2 + m][2 * f][e])) * rlp(acc[qp * 2 + m][2 * f + 1][e]));
           } else {   // stage 1 = bf16(acc + bias); the activation is applied after the transpose
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (short)f2lp(acc[mh * 4 + m][f][e] + bias_v[f][e]);
+            for (int e = 0; e < 4; ++e) v[e] = (short)f2lp(acc[qp * 2 + m][f][e] + bias_v[f][e]);
           }
           *(lpx4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll 1
-      for (int it = 0; it < 64 / RPI; ++it) {
+      for (int it = 0; it < 32 / RPI; ++it) {
         const int rl = it * RPI + rl0;
         const lpx8 v = *(const lpx8*)(slab + rl * RSTRIDE + ch * 16);
-        const int row = m0 + wr * 128 + mh * 64 + rl;
+        const int row = em0 + wr * 128 + qp * 32 + rl;
         if (row < p.M && !(p.debug_flags & 1)) {
           const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
           gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
@@ -286,9 +310,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    half_pass(std::integral_constant<int, 0>{});
-    half_pass(std::integral_constant<int, 1>{});
+    quarter_pass(std::integral_constant<int, 0>{});
+    quarter_pass(std::integral_constant<int, 1>{});
+    quarter_pass(std::integral_constant<int, 2>{});
+    quarter_pass(std::integral_constant<int, 3>{});
   }
+  }  // epilogue
+  if (!has_next) break;
   }  // persistent tile loop
 }
 
