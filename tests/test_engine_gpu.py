@@ -178,3 +178,28 @@ def test_engine_real_widths_vs_oracle(cuda):
         assert np.isfinite(v) and v < (6e-2 if k == "low_res_masks" else 3e-2), (k, v)
     assert np.abs(out["pred_boxes"] - ref["pred_boxes"].numpy()).max() < 2e-2
     eng.close()
+
+
+def test_fused_rope_epilogue_is_bit_identical_to_separate_pass(cuda, monkeypatch):
+    """The q|k RoPE fused into the 256^2 GEMM epilogue (M >= 1024 rows) == GEMM followed by rope_kernel, bit for bit."""
+    cfg = VSMConfig.tiny()
+    loc_id = cfg.llm_vocab - 1
+    sd = random_state_dict(cfg, seed=0, dtype=torch.bfloat16)
+    B, L = 4, 24                       # 4 x (256 + 23) = 1116 rows >= 1024: the 256^2 kernel takes the qkv projection
+    g = torch.Generator().manual_seed(77)
+    clip = torch.randn(B, 3, 224, 224, generator=g).bfloat16()
+    owl = torch.randn(B, 3, 768, 768, generator=g).bfloat16()
+    ids = torch.randint(3, loc_id - 3, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, 5] = -200
+    ids[:, L - 3] = loc_id
+    loc = loc_positions(ids.numpy(), loc_id, cfg.n_img_tokens)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VSTAR_FUSED_ROPE", flag)
+        eng = VstarEngine(cfg, 0)
+        eng.load_state_dict(sd)
+        outs.append(eng.score_batch(clip, owl, ids.numpy(), loc))
+        del eng
+    for k in ("pred_logits", "pred_boxes", "low_res_masks"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k

@@ -31,6 +31,7 @@ struct vstar_engine : EngineBase {
 
   // LLM activations
   int Smax = 0;
+  bool fused_rope = true;      // VSTAR_FUSED_ROPE=0 keeps RoPE as a separate pass (A/B and the bit-identity test)
   lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
   lp_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
   lp_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
@@ -403,8 +404,14 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
     KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
-    KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
+    {  // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
+      GemmParams p{};
+      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = rows; p.N = b.qkv.N; p.K = b.qkv.K;
+      const bool fused = fused_rope && gemm256_eligible(p);
+      if (fused) { p.rope_cs = rope; p.rope_S = S; p.rope_cols = 2 * H; }
+      RC(gemm(p, VSTAR_EPI_NONE, false));
+      if (!fused) KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
+    }
     KCHK(attn_forward(lqkv, latt, B, S, c.llm_heads, 128, 1, att_scale, stream));
     if (i + 1 == c.llm_layers) {
       // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
@@ -535,6 +542,7 @@ int vstar_create(const vstar_config* cfg, int device, vstar_handle** out) {
   }
   vstar_engine* h = new vstar_engine();
   h->cfg = *cfg;
+  if (const char* e = getenv("VSTAR_FUSED_ROPE")) h->fused_rope = atoi(e) != 0;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
     tls_error() = "hipStreamCreate failed";

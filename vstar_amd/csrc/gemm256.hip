@@ -279,6 +279,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
     }
     const int rl0 = lane / CH, ch = lane % CH;
+    // fused RoPE (q|k column tiles of the LLaMA qkv projection): a head = 128 columns = the two neighbouring N-waves
+    // (wc, wc^1); a lane's partner values (d +- 64) sit at the same slab position of the neighbour's slab, hence the
+    // workgroup barriers around stage 2 (every wave executes them: the condition is tile-uniform).
+    bool rope_tile = false;
+    if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
+    const char* slab_partner = smem + TILE_BYTES + (wave ^ 1) * (32 * (128 + 16));
     auto quarter_pass = [&](auto qc) {
       constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
 #pragma unroll
@@ -298,17 +304,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (EPI == VSTAR_EPI_NONE && rope_tile) BAR();
 #pragma unroll 1
       for (int it = 0; it < 32 / RPI; ++it) {
         const int rl = it * RPI + rl0;
-        const lpx8 v = *(const lpx8*)(slab + rl * RSTRIDE + ch * 16);
+        lpx8 v = *(const lpx8*)(slab + rl * RSTRIDE + ch * 16);
         const int row = em0 + wr * 128 + qp * 32 + rl;
+        if constexpr (EPI == VSTAR_EPI_NONE) {
+          if (rope_tile) {
+            const lpx8 vp = *(const lpx8*)(slab_partner + rl * RSTRIDE + ch * 16);
+            const int pos = (row < p.M ? row : p.M - 1) % p.rope_S;
+            const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + ch * 8);
+            const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + ch * 8);
+            const float sgn = (wc & 1) ? 1.0f : -1.0f;      // first half of the head: x*cos - partner*sin
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v[e] = (short)f2lp(rlp(lp2f((lp_t)v[e]) * lp2f((lp_t)c8[e])) + rlp(sgn * lp2f((lp_t)vp[e]) * lp2f((lp_t)s8[e])));
+          }
+        }
         if (row < p.M && !(p.debug_flags & 1)) {
           const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
           gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (EPI == VSTAR_EPI_NONE && rope_tile) BAR();      // the neighbour has read this slab before it is rewritten
     };
     quarter_pass(std::integral_constant<int, 0>{});
     quarter_pass(std::integral_constant<int, 1>{});

@@ -21,8 +21,13 @@ struct GemmParams {
   // gemm_skinny_lp only: when norm_w != null the rows of A are RMS-normalised on the fly (LlamaRMSNorm: fp32 statistics,
   // rlp(x * rstd), then rlp(norm_w * that)) — bit-identical to rmsnorm_lp followed by the GEMM, one launch less
   const lp_t* norm_w; float norm_eps;
+  // gemm256 only (bf16/fp16 output, VSTAR_EPI_NONE): rotate-half RoPE fused into the epilogue of the q|k columns
+  // (col < rope_cols, heads of 128): out = rlp(x*cos) + rlp(-/+ partner*sin) with position = row % rope_S and the table
+  // rope_cs [rope_S, 128] = cos(64)|sin(64) — the rounding points of rope_kernel, one pass over q,k less
+  const lp_t* rope_cs; int rope_S; int rope_cols;
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 kernel (the only one that honours rope_cs)
 
 // decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp
 bool gemm_skinny_eligible(const GemmParams& p);
