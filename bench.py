@@ -169,17 +169,17 @@ def main():
     fl = cfg.flops_per_crop(T, full=not args.skip_owl)
     per_crop = fl["core"] if args.skip_owl else fl["full"]
     # HBM-side traffic of the GEMM family per launch, from the committed rocprofv3 PMC passes of this same command
-    # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v5.json) — not re-measured live
+    # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v6.json) — not re-measured live
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_v5.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_v6.json")))
         gem = [k for k in pmc if "gemm" in k["kernel"]]
         traffic = round(sum(k["fetch_GB_corrected"] + k["write_GB"] for k in gem) * 1e9 / sum(k["launches"] for k in gem))
     except Exception:
         pass
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v5; "
+                "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v6; "
                                 "includes Infinity-Cache hits); algorithmic operand+output bytes per launch ~0.3 GB",
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
