@@ -34,7 +34,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 16 * NT;
-  const int nks = p.K >> 5;
 
   const lp_t* wp[NT];
 #pragma unroll
@@ -87,13 +86,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
     return y;
   };
 
-  constexpr int UNROLL = 4;
-  int ks = wave;
-  for (; ks + (UNROLL - 1) * SK_WAVES < nks; ks += UNROLL * SK_WAVES) {
-    lpx8 wf[UNROLL][NT], af[UNROLL][MT];
+  // K is walked in DOUBLE steps of 64 elements (two MFMA k-steps = one whole 128-byte line of every W row), interleaved
+  // over the 8 waves; UH double steps (2*UH k-steps) are in flight per wave before the first MFMA consumes them.
+  constexpr int UH = (MT == 2) ? 2 : (MT == 1 ? 1 : 2);
+  const int nd = p.K >> 6;
+  int ds = wave;
+  for (; ds + (UH - 1) * SK_WAVES < nd; ds += UH * SK_WAVES) {
+    lpx8 wf[2 * UH][NT], af[2 * UH][MT];
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int k = (ks + u * SK_WAVES) * 32;
+    for (int u = 0; u < 2 * UH; ++u) {
+      const int k = (ds + (u >> 1) * SK_WAVES) * 64 + (u & 1) * 32;
 #pragma unroll
       for (int t = 0; t < NT; ++t) wf[u][t] = __builtin_nontemporal_load((const lpx8*)(wp[t] + k));   // streamed once
 #pragma unroll
@@ -101,29 +103,32 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
     }
     if (fuse_norm) {
 #pragma unroll
-      for (int u = 0; u < UNROLL; ++u) {
-        const lpx8 nw = *(const lpx8*)(nwp + (ks + u * SK_WAVES) * 32);
+      for (int u = 0; u < 2 * UH; ++u) {
+        const lpx8 nw = *(const lpx8*)(nwp + (ds + (u >> 1) * SK_WAVES) * 64 + (u & 1) * 32);
 #pragma unroll
         for (int m = 0; m < MT; ++m) af[u][m] = normed(af[u][m], nw, rstd[m]);
       }
     }
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
+    for (int u = 0; u < 2 * UH; ++u)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[t][m] = mfma_16x16x32(wf[u][t], af[u][m], acc[t][m]);
   }
-  for (; ks < nks; ks += SK_WAVES) {
-    const int k = ks * 32;
+  for (; ds < nd; ds += SK_WAVES) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const lpx8 wf = *(const lpx8*)(wp[t] + k);
+    for (int h = 0; h < 2; ++h) {
+      const int k = ds * 64 + h * 32;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        lpx8 a = *(const lpx8*)(ap[m] + k);
-        if (fuse_norm) a = normed(a, *(const lpx8*)(nwp + k), rstd[m]);
-        acc[t][m] = mfma_16x16x32(wf, a, acc[t][m]);
+      for (int t = 0; t < NT; ++t) {
+        const lpx8 wf = *(const lpx8*)(wp[t] + k);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          lpx8 a = *(const lpx8*)(ap[m] + k);
+          if (fuse_norm) a = normed(a, *(const lpx8*)(nwp + k), rstd[m]);
+          acc[t][m] = mfma_16x16x32(wf, a, acc[t][m]);
+        }
       }
     }
   }
@@ -221,28 +226,58 @@ __global__ void rope_kv_append_kernel(lp_t* __restrict__ qkv, const lp_t* __rest
 }
 
 // ------------------------------------------------ attention over the KV cache ------------------------------------------------
-__global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict__ qkv, const lp_t* __restrict__ kc,
-                                                          const lp_t* __restrict__ vc, const int32_t* __restrict__ row_seq,
-                                                          const int32_t* __restrict__ row_pos, const int32_t* __restrict__ seq_kv,
-                                                          const int32_t* __restrict__ seq_prefix,
-                                                          const int32_t* __restrict__ seq_past, lp_t* __restrict__ out, int H,
-                                                          int ctx, int64_t slot_stride, float inv_scale) {
+// FUSED (decode steps: every sequence contributes exactly one new row): the workgroup also applies RoPE to its row's q and
+// k, appends k and v to the cache and attends to them from LDS — rope_kv_append's work without its launch.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ kc, lp_t* __restrict__ vc,
+                                                          const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_pos,
+                                                          const int32_t* __restrict__ seq_kv, const int32_t* __restrict__ seq_prefix,
+                                                          const int32_t* __restrict__ seq_past, const lp_t* __restrict__ cos_sin,
+                                                          lp_t* __restrict__ out, int H, int ctx, int64_t slot_stride,
+                                                          float inv_scale) {
   constexpr int D = 128;
   extern __shared__ float dyn[];            // [D] q | [nk] scores/probabilities
   __shared__ float redbuf[8];
   __shared__ float part[16][D];
+  __shared__ float own_k[D], own_v[D];
   const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
   const int pos = row_pos[r];
   if (pos < 0) return;
   const int seq = row_seq[r];
   const int past = seq_past[seq], nk = pos + 1;
-  const lp_t* kown = kc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const int nkc = FUSED ? pos : nk;         // keys that come from the cache
+  lp_t* kown = kc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
   const lp_t* kpre = kc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
-  const lp_t* vown = vc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  lp_t* vown = vc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
   const lp_t* vpre = vc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
   float* qs = dyn;
   float* sc = dyn + D;
-  if (tid < D) qs[tid] = lp2f(qkv[(int64_t)r * (3 * H * D) + h * D + tid]);
+  const lp_t* rowp = qkv + (int64_t)r * (3 * H * D) + h * D;
+  if (FUSED) {
+    if (tid < 128) {                         // rotate-half RoPE with HF's rounding points: tid 0-63 q pairs, 64-127 k pairs
+      const int which = tid >> 6, d = tid & 63;
+      const lp_t* base = rowp + which * (H * D);
+      const float x1 = lp2f(base[d]), x2 = lp2f(base[d + 64]);
+      const float cs = lp2f(cos_sin[(int64_t)pos * D + d]), si = lp2f(cos_sin[(int64_t)pos * D + 64 + d]);
+      const lp_t o1 = f2lp(rlp(x1 * cs) + rlp(-x2 * si)), o2 = f2lp(rlp(x2 * cs) + rlp(x1 * si));
+      if (which == 0) {
+        qs[d] = lp2f(o1);
+        qs[d + 64] = lp2f(o2);
+      } else {
+        own_k[d] = lp2f(o1);
+        own_k[d + 64] = lp2f(o2);
+        kown[(int64_t)pos * D + d] = o1;
+        kown[(int64_t)pos * D + d + 64] = o2;
+      }
+    } else {
+      const int d = tid - 128;
+      const lp_t v = rowp[2 * H * D + d];
+      own_v[d] = lp2f(v);
+      vown[(int64_t)pos * D + d] = v;
+    }
+  } else if (tid < D) {
+    qs[tid] = lp2f(rowp[tid]);
+  }
   __syncthreads();
   // ---- scores: 16 lanes per key, 16 key groups, 4 keys per group and pass (64 keys in flight per pass) ----
   const int l16 = tid & 15, grp = tid >> 4;
@@ -250,13 +285,13 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
 #pragma unroll
   for (int e = 0; e < 8; ++e) qv[e] = qs[l16 * 8 + e];
   float mx = -3.0e38f;
-  for (int j0 = 0; j0 < nk; j0 += 64) {
+  for (int j0 = 0; j0 < nkc; j0 += 64) {
     lpx8 kv8[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int j = j0 + u * 16 + grp;
       kv8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
-      if (j < nk) kv8[u] = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
+      if (j < nkc) kv8[u] = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -268,12 +303,24 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
       a += __shfl_xor(a, 4, 64);
       a += __shfl_xor(a, 2, 64);
       a += __shfl_xor(a, 1, 64);
-      if (j < nk) {
+      if (j < nkc) {
         const float sv = rlp(rlp(a) / inv_scale);    // HF: matmul output in the storage type, then / sqrt(head_dim)
         if (l16 == 0) sc[j] = sv;
         mx = fmaxf(mx, sv);
       }
     }
+  }
+  if (FUSED && grp == 0) {                     // the row's own key, from LDS
+    float a = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a += qv[e] * own_k[l16 * 8 + e];
+    a += __shfl_xor(a, 8, 64);
+    a += __shfl_xor(a, 4, 64);
+    a += __shfl_xor(a, 2, 64);
+    a += __shfl_xor(a, 1, 64);
+    const float sv = rlp(rlp(a) / inv_scale);
+    if (l16 == 0) sc[pos] = sv;
+    mx = fmaxf(mx, sv);
   }
   mx = wave_max(mx);
   if ((tid & 63) == 0) redbuf[tid >> 6] = mx;
@@ -294,7 +341,7 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
   float o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  for (int j0 = grp; j0 < nk; j0 += 64) {
+  for (int j0 = grp; j0 < nkc; j0 += 64) {
     lpx8 v8[4];
     float pr[4];
 #pragma unroll
@@ -302,7 +349,7 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
       const int j = j0 + u * 16;
       v8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
       pr[u] = 0.f;
-      if (j < nk) {
+      if (j < nkc) {
         v8[u] = *(const lpx8*)((j < past ? vpre : vown) + (int64_t)j * D + l16 * 8);
         pr[u] = rlp(sc[j] * inv);
       }
@@ -311,6 +358,11 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] += pr[u] * lp2f((lp_t)v8[u][e]);
+  }
+  if (FUSED && grp == 0) {
+    const float pr = rlp(sc[pos] * inv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] += pr * own_v[l16 * 8 + e];
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part[grp][l16 * 8 + e] = o[e];
@@ -423,7 +475,7 @@ __global__ void argmax_rows_lp_kernel(const lp_t* __restrict__ x, int cols, int6
 }  // namespace
 
 bool gemm_skinny_eligible(const GemmParams& p) {
-  return p.M > 0 && p.M <= 64 && p.a_group <= 0 && p.c_group <= 0 && p.K % 32 == 0 && (p.lda % 8) == 0;
+  return p.M > 0 && p.M <= 64 && p.a_group <= 0 && p.c_group <= 0 && p.K % 64 == 0 && (p.lda % 8) == 0;
 }
 
 hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
@@ -460,14 +512,18 @@ hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos
   return hipGetLastError();
 }
 
-hipError_t cached_attention(const lp_t* qkv, const lp_t* kc, const lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
-                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, lp_t* out, int R, int H,
-                            int ctx, int64_t slot_stride, int max_keys, hipStream_t s) {
+hipError_t cached_attention(const lp_t* qkv, lp_t* kc, lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
+                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, const lp_t* fused_cos_sin,
+                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   const size_t lds = (size_t)(128 + max_keys) * sizeof(float);
-  if (lds > 48 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(cached_attn_kernel, dim3(R, H), dim3(256), lds, s, qkv, kc, vc, row_seq, row_pos, seq_kv, seq_prefix,
-                     seq_past, out, H, ctx, slot_stride, sqrtf(128.0f));
+  if (lds > 40 * 1024) return hipErrorInvalidValue;
+  if (fused_cos_sin)
+    hipLaunchKernelGGL(cached_attn_kernel<true>, dim3(R, H), dim3(256), lds, s, qkv, kc, vc, row_seq, row_pos, seq_kv, seq_prefix,
+                       seq_past, fused_cos_sin, out, H, ctx, slot_stride, sqrtf(128.0f));
+  else
+    hipLaunchKernelGGL(cached_attn_kernel<false>, dim3(R, H), dim3(256), lds, s, qkv, kc, vc, row_seq, row_pos, seq_kv, seq_prefix,
+                       seq_past, fused_cos_sin, out, H, ctx, slot_stride, sqrtf(128.0f));
   return hipGetLastError();
 }
 

@@ -41,10 +41,12 @@ hipError_t embed_rows(const int32_t* src, const lp_t* table, int vocab, const lp
 // cache of slot row_slot[r]: kc/vc = this layer's [slot][H][ctx][128]
 hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos, const int32_t* row_slot, lp_t* kc, lp_t* vc,
                           int64_t slot_stride, int ctx, int R, int H, hipStream_t s);
-// causal attention of R new rows against the cache: keys [0, seq_past) come from seq_prefix's slot, the rest from seq_kv's
-hipError_t cached_attention(const lp_t* qkv, const lp_t* kc, const lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
-                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, lp_t* out, int R, int H,
-                            int ctx, int64_t slot_stride, int max_keys, hipStream_t s);
+// causal attention of R new rows against the cache: keys [0, seq_past) come from seq_prefix's slot, the rest from seq_kv's.
+// fused_cos_sin != null (only when every sequence has exactly ONE new row): the kernel also does rope_kv_append's work for
+// its row (RoPE on q,k, K/V appended to the cache) — qkv then holds the raw projection.
+hipError_t cached_attention(const lp_t* qkv, lp_t* kc, lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
+                            const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, const lp_t* fused_cos_sin,
+                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s);
 // q [n*L, H*DH], kv [n*NK, 2*H*DH] (k | v) -> out [n*L, H*DH]
 hipError_t perceiver_attention(const lp_t* q, const lp_t* kv, lp_t* out, int n, int L, int NK, int H, int DH, hipStream_t s);
 hipError_t argmax_rows_lp(const lp_t* x, int rows, int cols, int64_t ld, int32_t* out, hipStream_t s);

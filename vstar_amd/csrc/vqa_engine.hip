@@ -56,7 +56,7 @@ struct vstar_vqa_engine : EngineBase {
                const lp_t* res = nullptr, int64_t ldr = 0);
   int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
   int llm_layers_prefill(int nseq, int S);
-  int llm_layers_cached(int R, int nseq, int max_keys);
+  int llm_layers_cached(int R, int nseq, int max_keys, bool single_rows);
 };
 
 // GEMM dispatch for the language model: weight-streaming kernel for decode-sized M, MFMA tile kernels otherwise
@@ -303,7 +303,7 @@ int vstar_vqa_engine::llm_layers_prefill(int nseq, int S) {
   return 0;
 }
 
-int vstar_vqa_engine::llm_layers_cached(int R, int nseq, int max_keys) {
+int vstar_vqa_engine::llm_layers_cached(int R, int nseq, int max_keys, bool single_rows) {
   const vstar_vqa_config& c = cfg;
   const int H = c.llm_hidden;
   const int32_t *d_kv = d_seq, *d_prefix = d_seq + c.max_slots * 4, *d_past = d_seq + 2 * c.max_slots * 4;
@@ -313,9 +313,10 @@ int vstar_vqa_engine::llm_layers_cached(int R, int nseq, int max_keys) {
     lp_t* kc = kcache + (int64_t)i * layer_stride;
     lp_t* vc = vcache + (int64_t)i * layer_stride;
     RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE));
-    KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.llm_heads, stream));
-    KCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, latt, R, c.llm_heads, c.max_ctx, slot_stride,
-                          max_keys, stream));
+    // decode steps (one new row per sequence): RoPE + cache append happen inside the attention kernel
+    if (!single_rows) KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.llm_heads, stream));
+    KCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, single_rows ? rope : nullptr, latt, R,
+                          c.llm_heads, c.max_ctx, slot_stride, max_keys, stream));
     RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
     RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.llm_mlp, R, VSTAR_EPI_SILU_MUL));
     RC(lin_auto(lact, c.llm_mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));
@@ -387,7 +388,7 @@ int vstar_vqa_engine::forward(int nseq, const int32_t* row_off, const int32_t* s
   // ---- inputs_embeds (prepare_inputs_labels_for_multimodal, llava_search_arch.py:96-266) ----
   KCHK(embed_rows(d_src, embed, c.llm_vocab, feats, (int64_t)c.max_images * (P + L), lx, rows, H, stream));
   if (prefill) RC(llm_layers_prefill(nseq, maxT));
-  else RC(llm_layers_cached(rows, nseq, max_keys));
+  else RC(llm_layers_cached(rows, nseq, max_keys, maxT == 1));
   // ---- model.norm + lm_head on the wanted rows (llava_search_llama.py:92-93) ----
   const size_t vpad = (size_t)(c.llm_vocab + 255) / 256 * 256;
   if (n_want) {
