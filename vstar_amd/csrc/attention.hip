@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
-  const int q0b = blockIdx.x * 128;
+  // causal: the last query block has the most key tiles — launch the heavy blocks first so the tail of the grid is light
+  const int q0b = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
   const int q0 = q0b + wave * 32;
   const bool active = q0 < S;
   const int qi = lane & 31, h2 = lane >> 5;
