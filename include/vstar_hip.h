@@ -140,6 +140,16 @@ int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, cons
 int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width);
 int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy);
 
+/* Greedy free-text decode of ONE crop with a KV cache — VSMForCausalLM.inference for mode='vqa' (VSM.py:438-462 ->
+ * generate(max_new_tokens, greedy); called from VSM.inference at visual_search.py:198-219 for the contextual-cue branch,
+ * :427-443).  The reference re-runs the whole prefix for every new token (use_cache=False); here the prompt is prefilled
+ * once (CLIP tower + projector + LLaMA prefill, K/V kept in HBM) and each new token is one weight-streaming decode step,
+ * which yields the same arg-max tokens.  clip_pix: [1,3,I,I] bf16 (host, or device with VSTAR_F_DEVICE_INPUTS); ids[L]:
+ * the prompt with one -200; generation stops after max_new_tokens or at eos_id (which is stored as the last id).
+ * out_ids must hold max_new_tokens entries; *n_out receives the count. */
+int vstar_vsm_generate(vstar_handle* h, const uint16_t* clip_pix_bf16, const int32_t* ids, int L, int max_new_tokens,
+                       int eos_id, unsigned flags, int32_t* out_ids, int32_t* n_out);
+
 /* Bilinear (align_corners=False) upsample of a 192x192 low-res mask to h_out x w_out fp32, then clamp(min=0).
  * Replaces F.interpolate(...) + torch.clamp (VSM.py:534-537, visual_search.py:223-224). Host in, host out. */
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out);

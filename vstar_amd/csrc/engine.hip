@@ -2,7 +2,7 @@
 // the VSM scoring path.  Mirrors VSMForCausalLM.model_forward(inference=True) / .inference
 // (VisualSearch/model/VSM.py:201-364, 438-553) with the generate() loop collapsed into one teacher-forced prefill
 // (SURVEY.md §7 "hard parts"; the lm_head argmax at the verify positions lets the caller prove the collapse is exact).
-#include "engine_base.hpp"
+#include "llm_cached.hpp"
 
 namespace {
 struct SamAttn { Lin q, k, v, out; int internal; };
@@ -63,6 +63,10 @@ struct vstar_engine : EngineBase {
   int preprocess(int B, const int32_t* boxes);
   std::vector<int32_t> h_rowidx;
 
+  LlmCached gen;                // KV-cached runner for the free-text decode (built on first use: 0.5 GiB of cache)
+  lp_t* gen_feats = nullptr;    // [P, H] projected image features of the crop being decoded
+  int generate(const lp_t* clip_pix, const int32_t* ids, int L, int max_new, int eos_id, unsigned flags, int32_t* out_ids,
+               int32_t* n_out);
   int finalize();
   int score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* ids, int L, const int32_t* loc_pos,
             const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
@@ -527,6 +531,67 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   return 0;
 }
 
+// VSM.inference(mode='vqa'): greedy decode of one crop, KV-cached (see include/vstar_hip.h)
+int vstar_engine::generate(const lp_t* clip_pix, const int32_t* ids, int L, int max_new, int eos_id, unsigned flags,
+                           int32_t* out_ids, int32_t* n_out) {
+  if (!finalized) { set_error("weights not finalized"); return VSTAR_ERR_STATE; }
+  const vstar_config& c = cfg;
+  if (!clip_pix || !ids || !out_ids || !n_out || L < 2 || max_new < 1) { set_error("vstar_vsm_generate: bad argument"); return VSTAR_ERR_INVALID; }
+  HIPCHK(hipSetDevice(device));
+  const int H = c.llm_hidden, P = clip.P;
+  const int ctx = (P + c.max_text_len + 255) / 64 * 64;
+  if (!gen.ready) {
+    LlmCachedCfg rc;
+    rc.hidden = H; rc.heads = c.llm_heads; rc.mlp = c.llm_mlp; rc.layers = c.llm_layers; rc.vocab = c.llm_vocab;
+    rc.rms_eps = c.llm_rms_eps; rc.rope_theta = c.llm_rope_theta;
+    rc.max_slots = 1; rc.max_ctx = ctx; rc.max_rows = ctx;
+    RC(dalloc(&gen_feats, (size_t)P * H));
+    RC(gen.init(this, rc, embed, &llm, final_norm, &lm_head));
+    gen.feats = gen_feats;
+    gen.n_feat_rows = P;
+  }
+  int img = -1;
+  for (int i = 0; i < L; ++i)
+    if (ids[i] == -200) { if (img >= 0) { set_error("more than one -200 in input_ids"); return VSTAR_ERR_INVALID; } img = i; }
+  if (img < 0) { set_error("input_ids hold no image token (-200)"); return VSTAR_ERR_INVALID; }
+  if (L - 1 + P + max_new > ctx) { set_error("prompt + max_new_tokens exceed the decode context"); return VSTAR_ERR_INVALID; }
+  // ---- CLIP tower + mm_projector -> feature rows ----
+  const lp_t* cpix = clip_pix;
+  if (!(flags & VSTAR_F_DEVICE_INPUTS)) {
+    const size_t cn = (size_t)3 * c.clip_image_size * c.clip_image_size;
+    HIPCHK(hipMemcpyAsync(d_clip_pix, clip_pix, cn * 2, hipMemcpyHostToDevice, stream));
+    cpix = d_clip_pix;
+  }
+  RC(run_tower(clip, cpix, 1));
+  {
+    GemmParams p{};
+    p.A = clip.x; p.lda = c.clip_hidden; p.a_group = P; p.a_gstride = clip.N; p.a_off = 1;
+    p.W = projector.W; p.bias = projector.b; p.C = gen_feats; p.ldc = H; p.M = P; p.N = projector.N; p.K = projector.K;
+    RC(gemm(p, VSTAR_EPI_NONE, false));
+  }
+  // ---- prefill the spliced prompt, then one decode step per new token ----
+  std::vector<int32_t> rows;
+  rows.reserve((size_t)L - 1 + P);
+  for (int i = 0; i < L; ++i) {
+    if (i == img) for (int j = 0; j < P; ++j) rows.push_back(-(1 + j));
+    else rows.push_back(ids[i]);
+  }
+  int32_t row_off[2] = {0, (int32_t)rows.size()}, slot = 0, past = 0, want = (int32_t)rows.size() - 1, nxt = 0;
+  RC(gen.forward(1, row_off, rows.data(), &slot, &slot, &past, 1, &want, nullptr, &nxt));
+  int n = 0;
+  past = (int32_t)rows.size();
+  for (;;) {
+    out_ids[n++] = nxt;
+    if (nxt == eos_id || n >= max_new) break;
+    int32_t one_off[2] = {0, 1}, w0 = 0, tok = nxt;
+    RC(gen.forward(1, one_off, &tok, &slot, &slot, &past, 1, &w0, nullptr, &nxt));
+    ++past;
+  }
+  *n_out = n;
+  return 0;
+}
+
+
 // =============================================== C ABI ===============================================
 extern "C" {
 
@@ -557,6 +622,7 @@ void vstar_destroy(vstar_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  h->gen.release();
   h->release_base();
   if (h->d_stats) hipFree(h->d_stats);
   if (h->d_image) hipFree(h->d_image);
@@ -584,6 +650,12 @@ int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, cons
                           vstar_result* out) {
   if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->score(B, clip_pix, owl_pix, ids, L, loc_pos, verify_pos, n_verify, flags, out);
+}
+
+int vstar_vsm_generate(vstar_handle* h, const uint16_t* clip_pix, const int32_t* ids, int L, int max_new_tokens, int eos_id,
+                       unsigned flags, int32_t* out_ids, int32_t* n_out) {
+  if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
+  return h->generate(clip_pix, ids, L, max_new_tokens, eos_id, flags, out_ids, n_out);
 }
 
 int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) {

@@ -1,0 +1,272 @@
+// llm_cached.hpp — the KV-cached LLaMA runner shared by the two engines (dtype-generic, VS_NS): the VQA-LLM's forward
+// (LLaVA/llava/model/language_model/llava_search_llama.py:56-113) and the VSM's free-text decode for the contextual-cue
+// branch (VSMForCausalLM.inference mode='vqa', VisualSearch/model/VSM.py:438-462 / visual_search.py:427-443).
+// It owns the KV cache, the activations and the row metadata; the weights belong to the engine that built them.
+//
+// One forward call advances nseq sequences by any number of new rows each, in one of two regimes:
+//   * prefill  (every past_len == 0 and more than 64 new rows): sequences right-padded to a common length, the MFMA tile
+//     GEMMs and the flash-attention kernel; K/V rows are stored into the cache on the way.
+//   * cached   (decode steps, option continuations): flat ragged rows, weight-streaming skinny GEMMs (M <= 64), attention
+//     straight out of the KV cache with an optional shared prefix slot.
+#pragma once
+#include "engine_base.hpp"
+
+namespace VS_NS {
+
+struct LlmCachedCfg {
+  int hidden = 0, heads = 0, mlp = 0, layers = 0, vocab = 0;
+  float rms_eps = 1e-6f, rope_theta = 10000.f;
+  int max_slots = 1, max_ctx = 1024, max_rows = 1024;
+};
+
+struct LlmCached {
+  EngineBase* e = nullptr;
+  LlmCachedCfg cfg;
+  bool ready = false;
+  // weights (not owned)
+  const lp_t* embed = nullptr;
+  const std::vector<LlmBlock>* blocks = nullptr;
+  const lp_t* final_norm = nullptr;
+  const Lin* lm_head = nullptr;
+  // rows < 0 of `src` index this table (device, [n_feat_rows, hidden]); set by the owner before forward()
+  const lp_t* feats = nullptr;
+  int64_t n_feat_rows = 0;
+  // owned
+  lp_t* rope = nullptr;                          // [max_ctx, 128] cos | sin
+  lp_t *kcache = nullptr, *vcache = nullptr;     // [layers][slots][heads][ctx][128]
+  int64_t slot_stride = 0, layer_stride = 0;
+  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
+  lp_t *wsel = nullptr, *wnorm = nullptr, *logits = nullptr;
+  int32_t *d_src = nullptr, *d_row_pos = nullptr, *d_row_slot = nullptr, *d_row_seq = nullptr, *d_seq = nullptr, *d_want = nullptr,
+          *d_argmax = nullptr;
+  int max_want = 256;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double last_ms = 0;
+
+  void set_error(const std::string& m) { e->set_error(m); }
+  int init(EngineBase* owner, const LlmCachedCfg& c, const lp_t* embed_, const std::vector<LlmBlock>* blocks_,
+           const lp_t* final_norm_, const Lin* lm_head_);
+  void release() {
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
+    ev0 = ev1 = nullptr;
+  }
+  int lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
+               const lp_t* res = nullptr, int64_t ldr = 0);
+  int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
+  int llm_layers_prefill(int nseq, int S);
+  int llm_layers_cached(int R, int nseq, int max_keys, bool single_rows);
+  int forward(int nseq, const int32_t* row_off, const int32_t* src, const int32_t* kv_slot, const int32_t* prefix_slot,
+              const int32_t* past_len, int n_want, const int32_t* want, uint16_t* logits_out, int32_t* argmax_out);
+};
+
+inline int LlmCached::init(EngineBase* owner, const LlmCachedCfg& c, const lp_t* embed_, const std::vector<LlmBlock>* blocks_,
+                           const lp_t* final_norm_, const Lin* lm_head_) {
+  e = owner; cfg = c; embed = embed_; blocks = blocks_; final_norm = final_norm_; lm_head = lm_head_;
+  const int H = c.hidden;
+  if (H != c.heads * 128) { set_error("LLaMA head dim must be 128"); return VSTAR_ERR_INVALID; }
+  {  // HF LlamaRotaryEmbedding: fp32 cos/sin cast to the activation dtype before use
+    std::vector<lp_t> tab((size_t)c.max_ctx * 128);
+    for (int s = 0; s < c.max_ctx; ++s)
+      for (int i = 0; i < 64; ++i) {
+        const float inv = 1.0f / powf(c.rope_theta, (float)(2 * i) / 128.0f);
+        const float f = (float)s * inv;
+        tab[(size_t)s * 128 + i] = f2lp(cosf(f));
+        tab[(size_t)s * 128 + 64 + i] = f2lp(sinf(f));
+      }
+    RC(e->dalloc(&rope, tab.size()));
+    if (hipMemcpy(rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { set_error("rope table upload failed"); return VSTAR_ERR_HIP; }
+  }
+  slot_stride = (int64_t)c.heads * c.max_ctx * 128;
+  layer_stride = slot_stride * c.max_slots;
+  RC(e->dalloc(&kcache, (size_t)layer_stride * c.layers));
+  RC(e->dalloc(&vcache, (size_t)layer_stride * c.layers));
+  const size_t R = (size_t)c.max_rows;
+  RC(e->dalloc(&lx, R * H));
+  RC(e->dalloc(&lh, R * H));
+  RC(e->dalloc(&lqkv, R * 3 * H));
+  RC(e->dalloc(&latt, R * H));
+  RC(e->dalloc(&lact, R * c.mlp));
+  const size_t vpad = (size_t)(c.vocab + 255) / 256 * 256;
+  RC(e->dalloc(&wsel, (size_t)max_want * H));
+  RC(e->dalloc(&wnorm, (size_t)max_want * H));
+  RC(e->dalloc(&logits, (size_t)max_want * vpad));
+  RC(e->dalloc(&d_src, R));
+  RC(e->dalloc(&d_row_pos, R));
+  RC(e->dalloc(&d_row_slot, R));
+  RC(e->dalloc(&d_row_seq, R));
+  RC(e->dalloc(&d_seq, (size_t)3 * c.max_slots * 4));
+  RC(e->dalloc(&d_want, (size_t)max_want));
+  RC(e->dalloc(&d_argmax, (size_t)max_want));
+  if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { set_error("hipEventCreate failed"); return VSTAR_ERR_HIP; }
+  ready = true;
+  return 0;
+}
+
+#define LCHK(expr)                                                                           \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                          \
+      return VSTAR_ERR_HIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+// GEMM dispatch for the language model: weight-streaming kernel for decode-sized M, MFMA tile kernels otherwise
+inline int LlmCached::lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi, const lp_t* res,
+                               int64_t ldr) {
+  GemmParams p{};
+  p.A = A; p.lda = lda; p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
+  if (gemm_skinny_eligible(p)) {
+    const hipError_t he = gemm_skinny_lp(p, epi, false, e->stream);
+    if (he != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(he)); return VSTAR_ERR_HIP; }
+    return 0;
+  }
+  return e->gemm(p, epi, false);
+}
+
+// RMSNorm + Linear: for decode-sized M the norm is fused into the weight-streaming GEMM's operand load (bit-identical to
+// the two-kernel form), otherwise norm kernel into `scratch`, then the GEMM
+inline int LlmCached::lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M,
+                               int epi) {
+  const int H = cfg.hidden;
+  GemmParams p{};
+  p.A = x; p.lda = H; p.W = L.W; p.bias = L.b; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
+  if (M <= 16 && L.K == H && gemm_skinny_eligible(p)) {
+    p.norm_w = norm_w; p.norm_eps = cfg.rms_eps;
+    const hipError_t he = gemm_skinny_lp(p, epi, false, e->stream);
+    if (he != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(he)); return VSTAR_ERR_HIP; }
+    return 0;
+  }
+  LCHK(rmsnorm_lp(x, norm_w, scratch, M, H, cfg.rms_eps, nullptr, e->stream));
+  return lin_auto(scratch, H, L, C, ldc, M, epi);
+}
+
+inline int LlmCached::llm_layers_prefill(int nseq, int S) {
+  const LlmCachedCfg& c = cfg;
+  const int H = c.hidden, rows = nseq * S;
+  const float att_scale = 1.0f / sqrtf(128.0f);
+  for (int i = 0; i < c.layers; ++i) {
+    const LlmBlock& b = (*blocks)[i];
+    LCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.rms_eps, nullptr, e->stream));
+    RC(e->lin(lh, H, b.qkv, lqkv, 3 * H, rows));
+    LCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kcache + (int64_t)i * layer_stride, vcache + (int64_t)i * layer_stride,
+                        slot_stride, c.max_ctx, rows, c.heads, e->stream));
+    LCHK(attn_forward(lqkv, latt, nseq, S, c.heads, 128, 1, att_scale, e->stream));
+    RC(e->lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    LCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.rms_eps, nullptr, e->stream));
+    RC(e->lin(lh, H, b.gate_up, lact, c.mlp, rows, VSTAR_EPI_SILU_MUL));
+    RC(e->lin(lact, c.mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+  }
+  return 0;
+}
+
+inline int LlmCached::llm_layers_cached(int R, int nseq, int max_keys, bool single_rows) {
+  const LlmCachedCfg& c = cfg;
+  const int H = c.hidden;
+  const int32_t *d_kv = d_seq, *d_prefix = d_seq + c.max_slots * 4, *d_past = d_seq + 2 * c.max_slots * 4;
+  (void)nseq;
+  for (int i = 0; i < c.layers; ++i) {
+    const LlmBlock& b = (*blocks)[i];
+    lp_t* kc = kcache + (int64_t)i * layer_stride;
+    lp_t* vc = vcache + (int64_t)i * layer_stride;
+    RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE));
+    // decode steps (one new row per sequence): RoPE + cache append happen inside the attention kernel
+    if (!single_rows) LCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.heads, e->stream));
+    LCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, single_rows ? rope : nullptr, latt, R,
+                          c.heads, c.max_ctx, slot_stride, max_keys, e->stream));
+    RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
+    RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.mlp, R, VSTAR_EPI_SILU_MUL));
+    RC(lin_auto(lact, c.mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));
+  }
+  return 0;
+}
+
+inline int LlmCached::forward(int nseq, const int32_t* row_off, const int32_t* src, const int32_t* kv_slot,
+                              const int32_t* prefix_slot, const int32_t* past_len, int n_want, const int32_t* want,
+                              uint16_t* logits_out, int32_t* argmax_out) {
+  if (!ready) { e->set_error("language-model runner not initialised"); return VSTAR_ERR_STATE; }
+  const LlmCachedCfg& c = cfg;
+  if (nseq <= 0 || nseq > c.max_slots * 4 || !row_off || !src || !kv_slot || !prefix_slot || !past_len || n_want < 0 ||
+      n_want > max_want || (n_want && !want)) {
+    e->set_error("llm forward: bad argument");
+    return VSTAR_ERR_INVALID;
+  }
+  LCHK(hipSetDevice(e->device));
+  const int H = c.hidden;
+  const int R = row_off[nseq];
+  int maxT = 0, max_keys = 0;
+  bool all_fresh = true;
+  for (int i = 0; i < nseq; ++i) {
+    const int T = row_off[i + 1] - row_off[i];
+    if (T <= 0 || past_len[i] < 0 || past_len[i] + T > c.max_ctx) { e->set_error("sequence length exceeds max_ctx (or is empty)"); return VSTAR_ERR_INVALID; }
+    if (kv_slot[i] < 0 || kv_slot[i] >= c.max_slots || prefix_slot[i] < 0 || prefix_slot[i] >= c.max_slots) {
+      e->set_error("KV slot out of range");
+      return VSTAR_ERR_INVALID;
+    }
+    if (past_len[i] == 0 && prefix_slot[i] != kv_slot[i]) { e->set_error("prefix slot without a prefix"); return VSTAR_ERR_INVALID; }
+    maxT = T > maxT ? T : maxT;
+    max_keys = past_len[i] + T > max_keys ? past_len[i] + T : max_keys;
+    all_fresh = all_fresh && past_len[i] == 0;
+  }
+  for (int j = 0; j < n_want; ++j)
+    if (want[j] < 0 || want[j] >= R) { e->set_error("want row out of range"); return VSTAR_ERR_INVALID; }
+  const bool prefill = all_fresh && R > 64;
+  const int rows = prefill ? nseq * maxT : R;
+  if (rows > c.max_rows) { e->set_error("too many rows for one forward call (max_rows)"); return VSTAR_ERR_INVALID; }
+  // ---- row metadata ----
+  std::vector<int32_t> h_src((size_t)rows, INT32_MIN), h_pos((size_t)rows, -1), h_slot((size_t)rows, 0), h_seq((size_t)rows, 0);
+  std::vector<int32_t> h_want((size_t)(n_want ? n_want : 1), 0), remap((size_t)R);
+  for (int i = 0; i < nseq; ++i) {
+    const int T = row_off[i + 1] - row_off[i];
+    for (int t = 0; t < T; ++t) {
+      const int r = prefill ? i * maxT + t : row_off[i] + t;
+      h_src[r] = src[row_off[i] + t];
+      h_pos[r] = past_len[i] + t;
+      h_slot[r] = kv_slot[i];
+      h_seq[r] = i;
+      remap[row_off[i] + t] = r;
+    }
+  }
+  for (int j = 0; j < n_want; ++j) h_want[j] = remap[want[j]];
+  std::vector<int32_t> h_seqmeta((size_t)3 * c.max_slots * 4, 0);
+  for (int i = 0; i < nseq; ++i) {
+    h_seqmeta[i] = kv_slot[i];
+    h_seqmeta[(size_t)c.max_slots * 4 + i] = prefix_slot[i];
+    h_seqmeta[(size_t)2 * c.max_slots * 4 + i] = past_len[i];
+  }
+  LCHK(hipMemcpyAsync(d_src, h_src.data(), (size_t)rows * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_pos, h_pos.data(), (size_t)rows * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_slot, h_slot.data(), (size_t)rows * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_seq, h_seq.data(), (size_t)rows * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_seq, h_seqmeta.data(), h_seqmeta.size() * 4, hipMemcpyHostToDevice, e->stream));
+  if (n_want) LCHK(hipMemcpyAsync(d_want, h_want.data(), (size_t)n_want * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipStreamSynchronize(e->stream));       // the host vectors above go out of scope at return; keep it simple
+  LCHK(hipEventRecord(ev0, e->stream));
+  // ---- inputs_embeds (prepare_inputs_labels_for_multimodal, llava_search_arch.py:96-266) ----
+  LCHK(embed_rows(d_src, embed, c.vocab, feats, n_feat_rows, lx, rows, H, e->stream));
+  if (prefill) RC(llm_layers_prefill(nseq, maxT));
+  else RC(llm_layers_cached(rows, nseq, max_keys, maxT == 1));
+  // ---- model.norm + lm_head on the wanted rows (llava_search_llama.py:92-93) ----
+  const size_t vpad = (size_t)(c.vocab + 255) / 256 * 256;
+  if (n_want) {
+    LCHK(gather_rows(lx, d_want, wsel, n_want, H, e->stream));
+    RC(lin_norm(wsel, final_norm, wnorm, *lm_head, logits, (int64_t)vpad, n_want, VSTAR_EPI_NONE));
+    LCHK(argmax_rows_lp(logits, n_want, c.vocab, (int64_t)vpad, d_argmax, e->stream));
+  }
+  LCHK(hipEventRecord(ev1, e->stream));
+  if (n_want && logits_out)
+    LCHK(hipMemcpy2DAsync(logits_out, (size_t)c.vocab * 2, logits, vpad * 2, (size_t)c.vocab * 2, n_want,
+                            hipMemcpyDeviceToHost, e->stream));
+  if (n_want && argmax_out) LCHK(hipMemcpyAsync(argmax_out, d_argmax, (size_t)n_want * 4, hipMemcpyDeviceToHost, e->stream));
+  LCHK(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) last_ms = ms;
+  e->collect_profile();
+  return 0;
+}
+
+#undef LCHK
+
+}  // namespace VS_NS
+using namespace VS_NS;

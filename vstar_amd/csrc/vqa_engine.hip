@@ -3,16 +3,14 @@
 // LLaVA/llava/model/llava_search_arch.py:84-266, multimodal_projector/{builder,perceiver}.py) as used by
 // VQA_LLM.{free_form_inference,multiple_choices_inference} (vstar_bench_eval.py:78-165).
 //
-// A forward call runs in one of two regimes:
-//   * prefill  (every past_len == 0 and more than 64 new rows): sequences right-padded to a common length, the big MFMA
-//     GEMMs and the flash-attention kernel of the VSM path (fp16 instantiation); K/V rows are stored into the cache on the way.
-//   * cached   (decode steps, option continuations): flat ragged rows, weight-streaming skinny GEMMs (M <= 64), attention
-//     straight out of the KV cache with an optional shared prefix slot.
+// The KV-cached language-model forward itself is llm_cached.hpp (shared with the VSM engine's free-text decode); this file
+// owns the weights, the vision side (CLIP tower, mm_projector, Perceiver object projector) and the feature table.
 #ifndef VSTAR_LP_F16
 #error "vqa_engine.hip is the fp16 instantiation: build with -DVSTAR_LP_F16"
 #endif
-#include "engine_base.hpp"
+#include "llm_cached.hpp"
 #include "../../include/vstar_vqa.h"
+
 
 namespace {
 struct PcvLayer { lp_t *nm_g, *nm_b, *nl_g, *nl_b, *ff_g, *ff_b; Lin to_q, to_kv, to_out, ff1, ff2; };
@@ -30,64 +28,18 @@ struct vstar_vqa_engine : EngineBase {
   std::vector<LlmBlock> llm;
   lp_t* final_norm = nullptr;
   Lin lm_head;
-  lp_t* rope = nullptr;             // [max_ctx, 128] cos | sin
-  // device state
-  lp_t* feats = nullptr;            // [max_images * (P + L), H]
-  lp_t *kcache = nullptr, *vcache = nullptr;   // [layers][slots][heads][ctx][128]
-  int64_t slot_stride = 0, layer_stride = 0;
-  // activations
-  lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
-  lp_t *wsel = nullptr, *wnorm = nullptr, *logits = nullptr;
-  int32_t *d_src = nullptr, *d_row_pos = nullptr, *d_row_slot = nullptr, *d_row_seq = nullptr, *d_seq = nullptr, *d_want = nullptr,
-          *d_argmax = nullptr, *d_latidx = nullptr, *d_patchidx = nullptr;
+  LlmCached run;                    // KV cache + the language-model forward (llm_cached.hpp)
+  lp_t* feats = nullptr;            // feature table [max_images * (P + L), H]
+  int32_t *d_latidx = nullptr, *d_patchidx = nullptr;
   lp_t* d_pix = nullptr;
   // perceiver activations
   lp_t *p_xm = nullptr, *p_nm = nullptr, *p_lat = nullptr, *p_nl = nullptr, *p_q = nullptr, *p_kv = nullptr, *p_att = nullptr,
        *p_ff = nullptr, *p_tmp = nullptr;
-  int max_want = 0, enc_batch = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double last_ms = 0;
+  int enc_batch = 0;
 
   int finalize();
   int encode(int n, const uint16_t* pix, int first_slot);
-  int forward(int nseq, const int32_t* row_off, const int32_t* src, const int32_t* kv_slot, const int32_t* prefix_slot,
-              const int32_t* past_len, int n_want, const int32_t* want, uint16_t* logits_out, int32_t* argmax_out);
-  int lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
-               const lp_t* res = nullptr, int64_t ldr = 0);
-  int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
-  int llm_layers_prefill(int nseq, int S);
-  int llm_layers_cached(int R, int nseq, int max_keys, bool single_rows);
 };
-
-// GEMM dispatch for the language model: weight-streaming kernel for decode-sized M, MFMA tile kernels otherwise
-int vstar_vqa_engine::lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi, const lp_t* res,
-                               int64_t ldr) {
-  GemmParams p{};
-  p.A = A; p.lda = lda; p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
-  if (gemm_skinny_eligible(p)) {
-    hipError_t e = gemm_skinny_lp(p, epi, false, stream);
-    if (e != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(e)); return VSTAR_ERR_HIP; }
-    return 0;
-  }
-  return gemm(p, epi, false);
-}
-
-// RMSNorm + Linear: for decode-sized M the norm is fused into the weight-streaming GEMM's operand load (bit-identical to
-// the two-kernel form), otherwise norm kernel into `scratch`, then the GEMM
-int vstar_vqa_engine::lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M,
-                               int epi) {
-  const int H = cfg.llm_hidden;
-  GemmParams p{};
-  p.A = x; p.lda = H; p.W = L.W; p.bias = L.b; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
-  if (M <= 16 && L.K == H && gemm_skinny_eligible(p)) {
-    p.norm_w = norm_w; p.norm_eps = cfg.llm_rms_eps;
-    hipError_t e = gemm_skinny_lp(p, epi, false, stream);
-    if (e != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(e)); return VSTAR_ERR_HIP; }
-    return 0;
-  }
-  KCHK(rmsnorm_lp(x, norm_w, scratch, M, H, cfg.llm_rms_eps, nullptr, stream));
-  return lin_auto(scratch, H, L, C, ldc, M, epi);
-}
 
 int vstar_vqa_engine::finalize() {
   if (finalized) { set_error("weights already finalized"); return VSTAR_ERR_STATE; }
@@ -99,7 +51,6 @@ int vstar_vqa_engine::finalize() {
   RC(build_tower(clip, "clip.vision_model.", "pre_layrnorm", c.clip_image_size, c.clip_patch, c.clip_hidden, c.clip_heads,
                  c.clip_mlp, clip_blocks, enc_batch));
   const int C = c.clip_hidden, H = c.llm_hidden, P = clip.P, L = c.pcv_latents;
-  if (H != c.llm_heads * 128) { set_error("LLaMA head dim must be 128"); return VSTAR_ERR_INVALID; }
   if (c.llm_mlp % 16) { set_error("llm_mlp must be a multiple of 16"); return VSTAR_ERR_INVALID; }
   // ---- mm_projector (builder.py:39-49) ----
   if (c.projector_type == 0) {
@@ -155,42 +106,17 @@ int vstar_vqa_engine::finalize() {
   }
   RC(upload_vec("model.norm.weight", &final_norm, H));
   RC(make_lin({"lm_head.weight"}, {}, &lm_head, H));
-  {  // HF LlamaRotaryEmbedding: fp32 cos/sin cast to the activation dtype before use
-    std::vector<lp_t> tab((size_t)c.max_ctx * 128);
-    for (int s = 0; s < c.max_ctx; ++s)
-      for (int i = 0; i < 64; ++i) {
-        const float inv = 1.0f / powf(c.llm_rope_theta, (float)(2 * i) / 128.0f);
-        const float f = (float)s * inv;
-        tab[(size_t)s * 128 + i] = f2lp(cosf(f));
-        tab[(size_t)s * 128 + 64 + i] = f2lp(sinf(f));
-      }
-    RC(dalloc(&rope, tab.size()));
-    HIPCHK(hipMemcpy(rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
-  }
-  // ---- feature table, KV cache, activations ----
+  // ---- feature table, language-model runner (KV cache, activations) ----
   RC(dalloc(&feats, (size_t)c.max_images * (P + L) * H));
-  slot_stride = (int64_t)c.llm_heads * c.max_ctx * 128;
-  layer_stride = slot_stride * c.max_slots;
-  RC(dalloc(&kcache, (size_t)layer_stride * c.llm_layers));
-  RC(dalloc(&vcache, (size_t)layer_stride * c.llm_layers));
-  const size_t R = (size_t)c.max_rows;
-  RC(dalloc(&lx, R * H));
-  RC(dalloc(&lh, R * H));
-  RC(dalloc(&lqkv, R * 3 * H));
-  RC(dalloc(&latt, R * H));
-  RC(dalloc(&lact, R * c.llm_mlp));
-  max_want = 256;
-  const size_t vpad = (size_t)(c.llm_vocab + 255) / 256 * 256;
-  RC(dalloc(&wsel, (size_t)max_want * H));
-  RC(dalloc(&wnorm, (size_t)max_want * H));
-  RC(dalloc(&logits, (size_t)max_want * vpad));
-  RC(dalloc(&d_src, R));
-  RC(dalloc(&d_row_pos, R));
-  RC(dalloc(&d_row_slot, R));
-  RC(dalloc(&d_row_seq, R));
-  RC(dalloc(&d_seq, (size_t)3 * c.max_slots * 4));
-  RC(dalloc(&d_want, (size_t)max_want));
-  RC(dalloc(&d_argmax, (size_t)max_want));
+  {
+    LlmCachedCfg rc;
+    rc.hidden = H; rc.heads = c.llm_heads; rc.mlp = c.llm_mlp; rc.layers = c.llm_layers; rc.vocab = c.llm_vocab;
+    rc.rms_eps = c.llm_rms_eps; rc.rope_theta = c.llm_rope_theta;
+    rc.max_slots = c.max_slots; rc.max_ctx = c.max_ctx; rc.max_rows = c.max_rows;
+    RC(run.init(this, rc, embed, &llm, final_norm, &lm_head));
+    run.feats = feats;
+    run.n_feat_rows = (int64_t)c.max_images * (P + L);
+  }
   const int nb = enc_batch;
   RC(dalloc(&d_pix, (size_t)nb * 3 * c.clip_image_size * c.clip_image_size));
   RC(dalloc(&p_xm, (size_t)nb * P * C));
@@ -211,8 +137,6 @@ int vstar_vqa_engine::finalize() {
     HIPCHK(hipMemcpy(d_latidx, li.data(), li.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_patchidx, pi.data(), pi.size() * 4, hipMemcpyHostToDevice));
   }
-  HIPCHK(hipEventCreate(&ev0));
-  HIPCHK(hipEventCreate(&ev1));
   staged.clear();
   finalized = true;
   return 0;
@@ -284,130 +208,6 @@ int vstar_vqa_engine::encode(int n, const uint16_t* pix, int first_slot) {
   return 0;
 }
 
-int vstar_vqa_engine::llm_layers_prefill(int nseq, int S) {
-  const vstar_vqa_config& c = cfg;
-  const int H = c.llm_hidden, rows = nseq * S;
-  const float att_scale = 1.0f / sqrtf(128.0f);
-  for (int i = 0; i < c.llm_layers; ++i) {
-    LlmBlock& b = llm[i];
-    KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin(lh, H, b.qkv, lqkv, 3 * H, rows));
-    KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kcache + (int64_t)i * layer_stride, vcache + (int64_t)i * layer_stride,
-                        slot_stride, c.max_ctx, rows, c.llm_heads, stream));
-    KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream));
-    RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-    KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
-    RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-  }
-  return 0;
-}
-
-int vstar_vqa_engine::llm_layers_cached(int R, int nseq, int max_keys, bool single_rows) {
-  const vstar_vqa_config& c = cfg;
-  const int H = c.llm_hidden;
-  const int32_t *d_kv = d_seq, *d_prefix = d_seq + c.max_slots * 4, *d_past = d_seq + 2 * c.max_slots * 4;
-  (void)nseq;
-  for (int i = 0; i < c.llm_layers; ++i) {
-    LlmBlock& b = llm[i];
-    lp_t* kc = kcache + (int64_t)i * layer_stride;
-    lp_t* vc = vcache + (int64_t)i * layer_stride;
-    RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE));
-    // decode steps (one new row per sequence): RoPE + cache append happen inside the attention kernel
-    if (!single_rows) KCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.llm_heads, stream));
-    KCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, single_rows ? rope : nullptr, latt, R,
-                          c.llm_heads, c.max_ctx, slot_stride, max_keys, stream));
-    RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
-    RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.llm_mlp, R, VSTAR_EPI_SILU_MUL));
-    RC(lin_auto(lact, c.llm_mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));
-  }
-  return 0;
-}
-
-int vstar_vqa_engine::forward(int nseq, const int32_t* row_off, const int32_t* src, const int32_t* kv_slot,
-                              const int32_t* prefix_slot, const int32_t* past_len, int n_want, const int32_t* want,
-                              uint16_t* logits_out, int32_t* argmax_out) {
-  if (!finalized) { set_error("weights not finalized"); return VSTAR_ERR_STATE; }
-  const vstar_vqa_config& c = cfg;
-  if (nseq <= 0 || nseq > c.max_slots * 4 || !row_off || !src || !kv_slot || !prefix_slot || !past_len || n_want < 0 ||
-      n_want > max_want || (n_want && !want)) {
-    set_error("vstar_vqa_forward: bad argument");
-    return VSTAR_ERR_INVALID;
-  }
-  HIPCHK(hipSetDevice(device));
-  const int H = c.llm_hidden, P = clip.P, L = c.pcv_latents;
-  const int R = row_off[nseq];
-  int maxT = 0, max_keys = 0;
-  bool all_fresh = true;
-  for (int i = 0; i < nseq; ++i) {
-    const int T = row_off[i + 1] - row_off[i];
-    if (T <= 0 || past_len[i] < 0 || past_len[i] + T > c.max_ctx) { set_error("sequence length exceeds max_ctx (or is empty)"); return VSTAR_ERR_INVALID; }
-    if (kv_slot[i] < 0 || kv_slot[i] >= c.max_slots || prefix_slot[i] < 0 || prefix_slot[i] >= c.max_slots) {
-      set_error("KV slot out of range");
-      return VSTAR_ERR_INVALID;
-    }
-    if (past_len[i] == 0 && prefix_slot[i] != kv_slot[i]) { set_error("prefix slot without a prefix"); return VSTAR_ERR_INVALID; }
-    maxT = T > maxT ? T : maxT;
-    max_keys = past_len[i] + T > max_keys ? past_len[i] + T : max_keys;
-    all_fresh = all_fresh && past_len[i] == 0;
-  }
-  for (int j = 0; j < n_want; ++j)
-    if (want[j] < 0 || want[j] >= R) { set_error("want row out of range"); return VSTAR_ERR_INVALID; }
-  const bool prefill = all_fresh && R > 64;
-  const int rows = prefill ? nseq * maxT : R;
-  if (rows > c.max_rows) { set_error("too many rows for one forward call (max_rows)"); return VSTAR_ERR_INVALID; }
-  // ---- row metadata ----
-  std::vector<int32_t> h_src((size_t)rows, VSTAR_VQA_PAD_ROW), h_pos((size_t)rows, -1), h_slot((size_t)rows, 0), h_seq((size_t)rows, 0);
-  std::vector<int32_t> h_want((size_t)(n_want ? n_want : 1), 0), remap((size_t)R);
-  for (int i = 0; i < nseq; ++i) {
-    const int T = row_off[i + 1] - row_off[i];
-    for (int t = 0; t < T; ++t) {
-      const int r = prefill ? i * maxT + t : row_off[i] + t;
-      h_src[r] = src[row_off[i] + t];
-      h_pos[r] = past_len[i] + t;
-      h_slot[r] = kv_slot[i];
-      h_seq[r] = i;
-      remap[row_off[i] + t] = r;
-    }
-  }
-  for (int j = 0; j < n_want; ++j) h_want[j] = remap[want[j]];
-  std::vector<int32_t> h_seqmeta((size_t)3 * c.max_slots * 4, 0);
-  for (int i = 0; i < nseq; ++i) {
-    h_seqmeta[i] = kv_slot[i];
-    h_seqmeta[(size_t)c.max_slots * 4 + i] = prefix_slot[i];
-    h_seqmeta[(size_t)2 * c.max_slots * 4 + i] = past_len[i];
-  }
-  HIPCHK(hipMemcpyAsync(d_src, h_src.data(), (size_t)rows * 4, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_row_pos, h_pos.data(), (size_t)rows * 4, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_row_slot, h_slot.data(), (size_t)rows * 4, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_row_seq, h_seq.data(), (size_t)rows * 4, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_seq, h_seqmeta.data(), h_seqmeta.size() * 4, hipMemcpyHostToDevice, stream));
-  if (n_want) HIPCHK(hipMemcpyAsync(d_want, h_want.data(), (size_t)n_want * 4, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipStreamSynchronize(stream));       // the host vectors above go out of scope at return; keep it simple
-  HIPCHK(hipEventRecord(ev0, stream));
-  // ---- inputs_embeds (prepare_inputs_labels_for_multimodal, llava_search_arch.py:96-266) ----
-  KCHK(embed_rows(d_src, embed, c.llm_vocab, feats, (int64_t)c.max_images * (P + L), lx, rows, H, stream));
-  if (prefill) RC(llm_layers_prefill(nseq, maxT));
-  else RC(llm_layers_cached(rows, nseq, max_keys, maxT == 1));
-  // ---- model.norm + lm_head on the wanted rows (llava_search_llama.py:92-93) ----
-  const size_t vpad = (size_t)(c.llm_vocab + 255) / 256 * 256;
-  if (n_want) {
-    KCHK(gather_rows(lx, d_want, wsel, n_want, H, stream));
-    RC(lin_norm(wsel, final_norm, wnorm, lm_head, logits, (int64_t)vpad, n_want, VSTAR_EPI_NONE));
-    KCHK(argmax_rows_lp(logits, n_want, c.llm_vocab, (int64_t)vpad, d_argmax, stream));
-  }
-  HIPCHK(hipEventRecord(ev1, stream));
-  if (n_want && logits_out)
-    HIPCHK(hipMemcpy2DAsync(logits_out, (size_t)c.llm_vocab * 2, logits, vpad * 2, (size_t)c.llm_vocab * 2, n_want,
-                            hipMemcpyDeviceToHost, stream));
-  if (n_want && argmax_out) HIPCHK(hipMemcpyAsync(argmax_out, d_argmax, (size_t)n_want * 4, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipStreamSynchronize(stream));
-  float ms = 0;
-  if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) last_ms = ms;
-  collect_profile();
-  return 0;
-}
-
 // =============================================== C ABI ===============================================
 extern "C" {
 
@@ -442,8 +242,7 @@ void vstar_vqa_destroy(vstar_vqa_handle* h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   h->release_base();
-  if (h->ev0) hipEventDestroy(h->ev0);
-  if (h->ev1) hipEventDestroy(h->ev1);
+  h->run.release();
   hipStreamDestroy(h->stream);
   delete h;
 }
@@ -470,7 +269,8 @@ int vstar_vqa_forward(vstar_vqa_handle* h, int nseq, const int32_t* row_off, con
                       const int32_t* prefix_slot, const int32_t* past_len, int n_want, const int32_t* want,
                       uint16_t* logits_f16, int32_t* argmax) {
   if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
-  return h->forward(nseq, row_off, src, kv_slot, prefix_slot, past_len, n_want, want, logits_f16, argmax);
+  if (!h->finalized) { h->set_error("weights not finalized"); return VSTAR_ERR_STATE; }
+  return h->run.forward(nseq, row_off, src, kv_slot, prefix_slot, past_len, n_want, want, logits_f16, argmax);
 }
 
 int vstar_vqa_op_gemm(const void* A, const void* W, const void* bias, const void* res, void* C, int M, int N, int K,
@@ -510,6 +310,6 @@ int64_t vstar_vqa_debug_read(vstar_vqa_handle* h, const char* name, float* out, 
   return cnt;
 }
 
-double vstar_vqa_last_forward_ms(const vstar_vqa_handle* h) { return h ? h->last_ms : 0.0; }
+double vstar_vqa_last_forward_ms(const vstar_vqa_handle* h) { return h ? h->run.last_ms : 0.0; }
 
 }  // extern "C"

@@ -67,6 +67,18 @@ class VstarEngine:
         _lib.check(self.lib.vstar_load_tensor(self.handle, key.encode(), ctypes.c_void_p(t.data_ptr()), _DT[t.dtype], t.dim(),
                                               shape), self.handle)
 
+    # ---- free-text greedy decode with a KV cache (VSM.inference mode='vqa', VSM.py:438-462) ----
+    def generate(self, clip_pix, input_ids, max_new_tokens: int = 100, eos_id: int = 2):
+        """clip_pix [1,3,I,I] (bf16-castable, CPU), input_ids [L] with one -200 -> list of generated ids (EOS included)."""
+        clip_pix = _as_bf16(clip_pix).cpu()
+        ids = np.ascontiguousarray(np.asarray(input_ids, np.int32).reshape(-1))
+        out = np.zeros((max_new_tokens,), np.int32)
+        n = ctypes.c_int32(0)
+        _lib.check(self.lib.vstar_vsm_generate(self.handle, ctypes.c_void_p(clip_pix.data_ptr()), ctypes.c_void_p(ids.ctypes.data),
+                                               ids.shape[0], max_new_tokens, eos_id, 0, ctypes.c_void_p(out.ctypes.data),
+                                               ctypes.byref(n)), self.handle)
+        return out[:n.value].tolist()
+
     # ---- the hot path ----
     def score_batch(self, clip_pix, owl_pix, input_ids, loc_pos, verify_pos=None, skip_owl: bool = False,
                     sync: bool = True, raw: bool = False):

@@ -233,14 +233,20 @@ class VSM:
             warnings.warn(msg + " — tolerated because strict_template=False (synthetic weights)")
 
     @torch.inference_mode()
-    def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100) -> List[int]:
-        """Greedy decoding as the reference runs it for mode='vqa' (VSM.py:451-458 with use_cache=False,
-        max_new_tokens=100 from visual_search.py:204): every new token costs one full CLIP + LLaMA prefill over the
-        sequence so far; the engine returns argmax(lm_head(h_last)).  Stops at EOS.  Returns the generated ids."""
+    def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100, use_cache: bool = True) -> List[int]:
+        """Greedy decoding for mode='vqa' (VSM.py:451-458, max_new_tokens=100 from visual_search.py:204).  Stops at EOS.
+        use_cache=True (default): prompt prefilled once, then one KV-cached decode step per token on the engine
+        (vstar_vsm_generate).  use_cache=False: the reference's literal schedule (generate(use_cache=False)): every new token
+        costs one full CLIP + LLaMA prefill over the sequence so far.  Both return the same arg-max tokens."""
         ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end), self.vsm_tokenizer)
         clip = torch.from_numpy(clip_preprocess(image, self.cfg.clip_image_size)).bfloat16()[None]
         P = self.cfg.n_img_tokens
         eos = getattr(self.vsm_tokenizer, "eos_token_id", 2)
+        if use_cache and hasattr(self.engine, "generate"):
+            room = self.cfg.max_text_len - len(ids)
+            if room <= 0:
+                return []
+            return self.engine.generate(clip, ids, min(max_new_tokens, room), eos)
         new: List[int] = []
         for _ in range(max_new_tokens):
             if len(ids) >= self.cfg.max_text_len:
