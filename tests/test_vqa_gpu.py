@@ -341,3 +341,23 @@ def test_eval_loop_end_to_end_on_synthetic_benchmark(cuda, tmp_path):
     searched = [r for s in out.values() for r in s if r["missing_objects"]]
     assert searched and all(len(r["search_result"]) >= 1 and 0 <= r["option_chosen"] < 4 for r in searched)
     assert results == out
+
+
+def test_vqa_engine_reports_errors(cuda):
+    """Limits are enforced with messages; nothing falls back or clamps silently."""
+    from vstar_amd._lib import VstarError
+    cfg = VQAConfig.tiny()
+    eng = engine_for(cfg, 0)
+    with pytest.raises(VstarError, match="max_ctx"):
+        eng.forward([Seq([5] * 10, kv_slot=0, past_len=cfg.max_ctx - 4)], [(0, -1)])
+    with pytest.raises(VstarError, match="slot"):
+        eng.forward([Seq([5, 6], kv_slot=cfg.max_slots)], [(0, -1)])
+    with pytest.raises(VstarError, match="prefix"):
+        eng.forward([Seq([5, 6], kv_slot=1, prefix_slot=0, past_len=0)], [(0, -1)])
+    with pytest.raises(VstarError, match="max_rows"):
+        eng.forward([Seq([5] * 600, kv_slot=i) for i in range(4)], [(0, -1)])      # 4 x 600 padded rows > 2048
+    with pytest.raises(VstarError, match="slot range"):
+        eng.encode_images(torch.zeros(2, 3, 224, 224), cfg.max_images - 1)
+    # a sequence of one row and an empty want list are legal
+    lg, arg = eng.forward([Seq([7], kv_slot=2)], [])
+    assert lg is None and len(arg) == 0

@@ -4,8 +4,7 @@ Same constructor role, same methods and return conventions:
     get_patch / get_object_crop ............ vstar_bench_eval.py:49-77
     free_form_inference(image, question, ...) -> str ................ :78-113   (temperature 0: greedy, KV cache)
     multiple_choices_inference(image, question, options, ...) -> int  :115-165  (shared-prefix option scoring)
-plus batched forms (`free_form_batch`, `multiple_choices_batch`) that decode / score many samples in one engine call per
-step — the reference runs batch 1; on an MI355X a decode step is bound by the 13.5 GB weight sweep, so sequences are
+plus a batched form (`free_form_batch`) that decodes many samples in one engine call per step — the reference runs batch 1; on an MI355X a decode step is bound by the 13.5 GB weight sweep, so sequences are
 advanced together.
 
 MI355X-first differences that do not change results: the question prefix of the multiple-choice scoring is prefilled
