@@ -189,6 +189,13 @@ enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_E
 int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
                   const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,
                   int M, int N, int K, int epilogue);
+/* W8A8 GEMM (BASELINE config 5: fp8 weights on the CDNA4 fp8 MFMA), op level, all pointers DEVICE pointers: quantises the
+ * rows of A [M,K] (per token) and of W [ceil(N/256)*256, K] (per output channel) to OCP fp8 e4m3 with scale = absmax/448,
+ * then C[M,N] = epilogue((A_q . W_q^T) * a_scale[m] * w_scale[n] + bias) (+ residual) with fp32 accumulation on
+ * v_mfma_scale_f32_16x16x128_f8f6f4.  Requires M >= 1024, N >= 256, K % 256 == 0; epilogue NONE or SILU_MUL.
+ * iters > 0: the GEMM alone is repeated `iters` times between HIP events and *gemm_ms receives the mean (benchmarks). */
+int vstar_op_gemm_fp8(void* stream, const uint16_t* dev_A, const uint16_t* dev_W, const uint16_t* dev_bias,
+                      const uint16_t* dev_residual, uint16_t* dev_C, int M, int N, int K, int epilogue, int iters, float* gemm_ms);
 /* LayerNorm over the last dim (eps, affine) / LLaMA RMSNorm.  bf16 in/out. */
 int vstar_op_layernorm(void* stream, const uint16_t* dev_x, const uint16_t* dev_gamma, const uint16_t* dev_beta,
                        uint16_t* dev_y, int rows, int cols, float eps);

@@ -241,3 +241,49 @@ def test_gemm256_race_screen(lib, cuda):
     for _ in range(10):
         again = _gemm(lib, a, w, f32=True)
         assert torch.equal(again, first)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (1300, 768, 1024, 0), (2048, 1024, 4096, 4), (1056, 300, 512, 0)])
+def test_gemm_w8a8_fp8(cuda, lib, M, N, K, epi):
+    """W8A8 GEMM on the fp8 MFMA (BASELINE config 5) vs torch on the SAME quantised operands: per-token / per-output-channel
+    absmax/448 scales, OCP e4m3 round-to-nearest-even, fp32 accumulation, then the usual epilogue."""
+    g = torch.Generator().manual_seed(M + N + K)
+    Npad = (N + 255) // 256 * 256
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g) * torch.rand(M, 1, generator=g) * 3).bfloat16()
+    W = torch.zeros(Npad, K, dtype=torch.bfloat16)
+    W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5 * (0.5 + torch.rand(N, 1, generator=g))).bfloat16()
+    bias = (torch.randn(Npad, generator=g) * 0.1).bfloat16() if epi == 0 else None
+    res = (torch.randn(M, n_out, generator=g) * 0.5).bfloat16() if epi == 0 else None
+    dA, dW = A.cuda(), W.cuda()
+    dB = bias.cuda() if bias is not None else None
+    dR = res.cuda() if res is not None else None
+    C = torch.zeros(M, n_out, dtype=torch.bfloat16, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = lib.vstar_op_gemm_fp8(None, P(dA), P(dW), P(dB), P(dR), P(C), M, N, K, epi, 0, None)
+    assert rc == 0, lib.vstar_last_error(None)
+
+    def fq(x):                                    # fake-quant: what the engine's operands decode to
+        s = x.float().abs().amax(dim=1, keepdim=True) / 448.0
+        s = torch.where(s > 0, s, torch.ones_like(s))
+        return (x.float() * (1.0 / s)).to(torch.float8_e4m3fn).float(), s      # multiply by the fp32 reciprocal, like the kernel
+    aq, sa = fq(A)
+    wq, sw = fq(W[:N])
+    ref = (aq @ wq.T) * sa * sw.T
+    if bias is not None:
+        ref = ref + bias[:N].float()
+    if epi == 4:
+        r = ref.view(M, N // 32, 2, 16)
+        ref = (torch.nn.functional.silu(r[:, :, 0].bfloat16().float()).bfloat16().float() * r[:, :, 1].bfloat16().float()).reshape(M, n_out)
+    if res is not None:
+        ref = ref.bfloat16().float() + res.float()
+    got = C.float().cpu()
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    assert err <= 1.2e-2 * scale, (err, scale)                # one bf16 ulp of the largest outputs
+    assert float((got - ref).abs().mean()) <= 1.5e-3 * scale
+    # and the quantisation itself is sane: W8A8 vs the unquantised product within a few percent
+    full = A.float() @ W[:N].float().T
+    if epi == 0:
+        full = (full + bias[:N].float()).bfloat16().float() + res.float()
+        assert float((got - full).norm() / full.norm()) < 0.06

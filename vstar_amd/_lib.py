@@ -18,7 +18,7 @@ EXPORTS = [
     "vstar_create", "vstar_destroy", "vstar_last_error", "vstar_load_tensor", "vstar_finalize_weights",
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
-    "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_vsm_generate",
+    "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_vsm_generate", "vstar_op_gemm_fp8",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -98,6 +98,9 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_gemm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_int]
     lib.vstar_op_gemm.restype = c_int
+    lib.vstar_op_gemm_fp8.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                      POINTER(c_float)]
+    lib.vstar_op_gemm_fp8.restype = c_int
     lib.vstar_op_layernorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
     lib.vstar_op_layernorm.restype = c_int
     lib.vstar_op_rmsnorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]

@@ -66,6 +66,18 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(lpx8 a, lpx8 b, f32x16 c) {
 #endif
 __device__ __forceinline__ float rlp(float f) { return lp2f(f2lp(f)); }  // round through the storage type
 
+// fp8 e4m3 (OCP) x fp8 e4m3 -> fp32, K = 128, block scales fixed at 1.0 (E8M0 0x7F): operands are 32 bytes per lane, any
+// k order as long as both operands use the same one (the dot product does not care)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x4 mfma_16x16x128_fp8(lpx8 a_lo, lpx8 a_hi, lpx8 b_lo, lpx8 b_hi, f32x4 c) {
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  const i32x4 al = __builtin_bit_cast(i32x4, a_lo), ah = __builtin_bit_cast(i32x4, a_hi);
+  const i32x4 bl = __builtin_bit_cast(i32x4, b_lo), bh = __builtin_bit_cast(i32x4, b_hi);
+  const i32x8 a = {al[0], al[1], al[2], al[3], ah[0], ah[1], ah[2], ah[3]};
+  const i32x8 b = {bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

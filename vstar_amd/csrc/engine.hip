@@ -805,6 +805,41 @@ int vstar_op_rmsnorm(void* stream, const uint16_t* x, const uint16_t* g, uint16_
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
+int vstar_op_gemm_fp8(void* stream, const uint16_t* A, const uint16_t* W, const uint16_t* bias, const uint16_t* res, uint16_t* C,
+                      int M, int N, int K, int epilogue, int iters, float* gemm_ms) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const int Npad = (N + 255) / 256 * 256;
+  const int n_out = epilogue == VSTAR_EPI_SILU_MUL ? N / 2 : N;
+  uint8_t *Aq = nullptr, *Wq = nullptr;
+  float *sa = nullptr, *sw = nullptr;
+  hipError_t e = hipMalloc((void**)&Aq, (size_t)M * K);
+  if (e == hipSuccess) e = hipMalloc((void**)&Wq, (size_t)Npad * K);
+  if (e == hipSuccess) e = hipMalloc((void**)&sa, (size_t)M * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&sw, (size_t)Npad * 4);
+  if (e == hipSuccess) e = quantize_rows_fp8(A, K, Aq, K, sa, M, K, s);
+  if (e == hipSuccess) e = quantize_rows_fp8(W, K, Wq, K, sw, Npad, K, s);
+  GemmParams p{};
+  p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.bias = bias; p.res = res; p.ldr = n_out; p.C = C; p.ldc = n_out;
+  p.M = M; p.N = N; p.K = K; p.a_scale = sa; p.w_scale = sw;
+  if (e == hipSuccess && !gemm256_eligible(p)) { tls_error() = "shape not accepted by the W8A8 kernel"; e = hipErrorInvalidValue; }
+  if (e == hipSuccess) e = gemm_lp(p, epilogue, false, s);
+  if (e == hipSuccess && iters > 0 && gemm_ms) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = gemm_lp(p, epilogue, false, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *gemm_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(Aq); hipFree(Wq); hipFree(sa); hipFree(sw);
+  return op_rc(e);
+}
 size_t vstar_op_attention_workspace(int B, int S, int H, int D) {
   (void)B; (void)H;
   return (size_t)S * D * 2 + 256;     // the RoPE cos|sin table only: V is transposed inside the kernel (no V^T buffer)

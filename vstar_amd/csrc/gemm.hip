@@ -174,7 +174,7 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   if (force != 128 && gemm256_eligible(p)) return gemm256_lp(p, epilogue, out_f32, s);   // W is padded to 256 rows
-  if (p.rope_cs) return hipErrorInvalidValue;   // fused RoPE exists only in the 256^2 kernel: callers check gemm256_eligible
+  if (p.rope_cs || p.a_scale) return hipErrorInvalidValue;   // fused RoPE / W8A8 exist only in the 256^2 kernel: callers check gemm256_eligible
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);

@@ -46,8 +46,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     __builtin_amdgcn_sched_barrier(0);                              \
   } while (0)
 
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool F8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
+  constexpr int ES = F8 ? 1 : 2;                    // bytes per operand element; a K-tile is 128 bytes of every row either way
+  constexpr int BKE = 128 / ES;                     // elements per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // current one, whose LDS slabs live in ring buffer 1 (where the last K-tile — K/64 is even — was just consumed): the
   // pipeline fill of a tile overlaps the output stores of its predecessor.
   const int st_r = lane >> 3, st_c = lane & 7;
-  uint32_t src_off[4][2];   // element offset of this lane's 16-B chunk at k0 = 0, per piece type and u
+  uint32_t src_off[4][2];   // BYTE offset of this lane's 16-B chunk at k0 = 0, per piece type and u
   int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
   int m0 = 0, n0 = 0;
   // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering; DMA source offsets of that tile ----
@@ -100,19 +102,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         if (isA) {
           int ar = m0 + row;
           ar = ar < p.M ? ar : p.M - 1;
-          src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8);
+          src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda * ES + cg * 16);
         } else {
-          src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K + cg * 8);
+          src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K * ES + cg * 16);
         }
       }
     }
   };
-  const int total_pieces = (p.K / BK) * 4;
   // piece type J is a compile-time constant at every call site, so src_off / lds_off stay in registers
   auto issue_piece = [&](auto jc, int T) {
     constexpr int J = decltype(jc)::value;
     char* base = smem + (T & 1) * TILE_BYTES;
-    const lp_t* gb = ((J == 0 || J == 3) ? p.A : p.W) + T * BK;
+    const char* gb = (const char*)((J == 0 || J == 3) ? p.A : p.W) + T * 128;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_global_load_lds((gptr_t)(gb + src_off[J][u]), (lptr_t)(base + lds_off[J][u]), 16, 0, 0);
@@ -163,20 +164,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // each overwrites a region whose last reader retired at least one phase (= one barrier on both groups) earlier — and
   // waits until everything the NEXT phase reads has landed: vmcnt(8) in A (4 pieces may stay in flight), vmcnt(6) in B.
   lpx8 af[8], w0f[4], w1f[4];
-  const int nkt = p.K / BK;
+  const int nkt = p.K / BKE;
   for (int T = 0; T < nkt; ++T) {
     const char* base = smem + (T & 1) * TILE_BYTES;
 #define MFMA_PAIR(mh, WFA, nha, WFB, nhb)                                                \
   {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                       \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                     \
+    if constexpr (F8) {                                                                  \
       _Pragma("unroll") for (int m = 0; m < 4; ++m)                                      \
         _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                  \
-          acc[(mh) * 4 + m][(nha) * 2 + n] = mfma_16x16x32(    \
-              WFA[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nha) * 2 + n]);          \
-          acc[(mh) * 4 + m][(nhb) * 2 + n] = mfma_16x16x32(    \
-              WFB[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n]);          \
+          acc[(mh) * 4 + m][(nha) * 2 + n] = mfma_16x16x128_fp8(                         \
+              WFA[n], WFA[2 + n], af[m], af[4 + m], acc[(mh) * 4 + m][(nha) * 2 + n]);   \
+          acc[(mh) * 4 + m][(nhb) * 2 + n] = mfma_16x16x128_fp8(                         \
+              WFB[n], WFB[2 + n], af[m], af[4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n]);   \
         }                                                                                \
+    } else {                                                                             \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                   \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                    \
+          _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                \
+            acc[(mh) * 4 + m][(nha) * 2 + n] = mfma_16x16x32(                            \
+                WFA[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nha) * 2 + n]);      \
+            acc[(mh) * 4 + m][(nhb) * 2 + n] = mfma_16x16x32(                            \
+                WFB[kk * 2 + n], af[kk * 4 + m], acc[(mh) * 4 + m][(nhb) * 2 + n]);      \
+          }                                                                              \
+    }                                                                                    \
     __builtin_amdgcn_s_setprio(0);                                                       \
     BAR();                                                                               \
   }
@@ -229,6 +240,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     issue_piece(std::integral_constant<int, 1>{}, 0);
     issue_piece(std::integral_constant<int, 2>{}, 0);
     issue_piece(std::integral_constant<int, 3>{}, 0);
+  }
+
+  // ---- W8A8: dequantise the accumulators (per-row activation scale x per-output-channel weight scale, packed-row order) ----
+  if constexpr (F8) {
+    float swv[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 t = *(const f32x4*)(p.w_scale + en0 + wc * 64 + n * 16 + fq * 4);      // w_scale is padded like W
+#pragma unroll
+      for (int e = 0; e < 4; ++e) swv[n][e] = t[e];
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int row = em0 + wr * 128 + m * 16 + fr;
+      const float sa = p.a_scale[row < p.M ? row : p.M - 1];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][n][e] *= sa * swv[n][e];
+    }
   }
 
   // ---- epilogue ----
@@ -340,10 +371,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   }  // persistent tile loop
 }
 
-template <int EPI, bool OUT_F32>
+template <int EPI, bool OUT_F32, bool F8 = false>
 hipError_t launch(const GemmParams& p, hipStream_t s) {
   static bool attr_done = false;
-  auto kern = gemm256_kernel<EPI, OUT_F32>;
+  auto kern = gemm256_kernel<EPI, OUT_F32, F8>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return e;
@@ -366,6 +397,9 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 
 // Shapes this kernel accepts: K/64 even and >= 2, operands addressable with 32-bit element offsets.
 bool gemm256_eligible(const GemmParams& p) {
+  if (p.a_scale) {      // W8A8: K counts fp8 elements, a K-tile is 128 of them, K/128 even
+    if (p.K % 256 != 0 || p.K < 256 || !p.w_scale || p.rope_cs) return false;
+  }
   if (p.K % 128 != 0 || p.K < 128) return false;
   if (p.M < 1024 || p.N < 256) return false;
   const int64_t amax = (p.a_group > 0 ? ((int64_t)(p.M / p.a_group) + 1) * p.a_gstride + p.a_off + p.a_group : (int64_t)p.M) * p.lda;
@@ -375,6 +409,12 @@ bool gemm256_eligible(const GemmParams& p) {
 }
 
 hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+  if (p.a_scale) {       // W8A8 instantiations: the two epilogues the LLaMA linears use
+    if (out_f32) return hipErrorInvalidValue;
+    if (epilogue == VSTAR_EPI_NONE) return launch<VSTAR_EPI_NONE, false, true>(p, s);
+    if (epilogue == VSTAR_EPI_SILU_MUL) return launch<VSTAR_EPI_SILU_MUL, false, true>(p, s);
+    return hipErrorInvalidValue;
+  }
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);

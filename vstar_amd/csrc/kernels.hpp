@@ -25,6 +25,11 @@ struct GemmParams {
   // (col < rope_cols, heads of 128): out = rlp(x*cos) + rlp(-/+ partner*sin) with position = row % rope_S and the table
   // rope_cs [rope_S, 128] = cos(64)|sin(64) — the rounding points of rope_kernel, one pass over q,k less
   const lp_t* rope_cs; int rope_S; int rope_cols;
+  // gemm256 only: W8A8 mode (BASELINE config 5).  a_scale != null => A and W point at OCP fp8 e4m3 bytes (lda / K count
+  // fp8 elements, K % 256 == 0), a_scale [M] and w_scale [N] are the per-row / per-output-channel dequantisation factors:
+  // C = epilogue((A_q · W_q^T) * a_scale[m] * w_scale[n]).  One v_mfma_scale_f32_16x16x128_f8f6f4 (scales 1.0) replaces two
+  // 16x16x32 bf16 MFMAs on the same LDS bytes, i.e. twice the K per K-tile at the same LDS/DMA traffic.
+  const float* a_scale; const float* w_scale;
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 kernel (the only one that honours rope_cs)
@@ -50,6 +55,13 @@ hipError_t cached_attention(const lp_t* qkv, lp_t* kc, lp_t* vc, const int32_t* 
 // q [n*L, H*DH], kv [n*NK, 2*H*DH] (k | v) -> out [n*L, H*DH]
 hipError_t perceiver_attention(const lp_t* q, const lp_t* kv, lp_t* out, int n, int L, int NK, int H, int DH, hipStream_t s);
 hipError_t argmax_rows_lp(const lp_t* x, int rows, int cols, int64_t ld, int32_t* out, hipStream_t s);
+
+// ---- W8A8 (quant.hip): per-row symmetric fp8 e4m3 quantisation, scale = absmax / 448 ----
+hipError_t quantize_rows_fp8(const lp_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int cols,
+                             hipStream_t s);
+// LlamaRMSNorm whose 16-bit output row is quantised on the way out (cols <= 4096)
+hipError_t rmsnorm_quant_fp8(const lp_t* x, const lp_t* gamma, uint8_t* q, float* scale, int rows, int cols, float eps,
+                             hipStream_t s);
 
 // ---- norms (norm.hip) ----
 // y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
