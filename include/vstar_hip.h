@@ -77,7 +77,9 @@ typedef struct vstar_config {
   /* limits used to size the workspace */
   int32_t max_batch;          /* crops per vstar_vsm_score_batch call */
   int32_t max_text_len;       /* L_max: input_ids length incl. the single -200 */
-  int32_t reserved[8];
+  int32_t llm_w8a8;           /* 1: LLaMA linears run W8A8 on the fp8 MFMA (BASELINE config 5) whenever a call has >= 1024 rows;
+                                 per-output-channel weight scales, per-token activation scales, OCP e4m3.  0 (default): bf16 */
+  int32_t reserved[7];
 } vstar_config;
 
 typedef struct vstar_engine vstar_handle;

@@ -119,27 +119,47 @@ def rotate_half(x: torch.Tensor) -> torch.Tensor:
     return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
 
 
+def fp8_fake_quant(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-row symmetric OCP e4m3 quantisation as the engine's W8A8 mode does it (vstar_amd/csrc/quant.hip; BASELINE config 5
+    — the reference has no fp8 path): scale = absmax / 448, value * (1 / scale) rounded to nearest-even e4m3.  Returns the
+    decoded codes (fp32) and the scales."""
+    s = x.float().abs().amax(dim=-1, keepdim=True) / 448.0
+    s = torch.where(s > 0, s, torch.ones_like(s))
+    return (x.float() * (1.0 / s)).to(torch.float8_e4m3fn).float(), s
+
+
+def linear_w8a8(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x @ w.T with per-token activation scales and per-output-channel weight scales, fp32 accumulation."""
+    xq, sx = fp8_fake_quant(x)
+    wq, sw = fp8_fake_quant(w)
+    return ((xq @ wq.T) * sx * sw.transpose(-1, -2)).to(x.dtype)
+
+
 def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, theta: float,
-                  final_norm: bool = True) -> torch.Tensor:
+                  final_norm: bool = True, w8a8: bool = False) -> torch.Tensor:
+    """w8a8: the four big linears of every block on fake-quantised operands, as the engine's config-5 mode runs them —
+    except o_proj / MLP of the LAST block, which the engine evaluates on the few needed rows with the 16-bit weights."""
     B, S, H = x.shape
+    lin8 = (lambda key, t: linear_w8a8(t, sd[key + ".weight"])) if w8a8 else None
     hd = H // heads
     cos, sin = rope_tables(S, hd, theta, x.dtype)
     mask = torch.full((S, S), float("-inf")).triu(1)
     for i in range(layers):
         lp = f"model.layers.{i}."
         h = rms_norm(x, sd[lp + "input_layernorm.weight"], eps)
-        q = _lin(sd, lp + "self_attn.q_proj", h, False).view(B, S, heads, hd).transpose(1, 2)
-        k = _lin(sd, lp + "self_attn.k_proj", h, False).view(B, S, heads, hd).transpose(1, 2)
-        v = _lin(sd, lp + "self_attn.v_proj", h, False).view(B, S, heads, hd).transpose(1, 2)
+        proj = (lambda key, t, last_ok=True: lin8(key, t)) if w8a8 else (lambda key, t, last_ok=True: _lin(sd, key, t, False))
+        post = proj if (not w8a8 or i + 1 < layers) else (lambda key, t: _lin(sd, key, t, False))
+        q = proj(lp + "self_attn.q_proj", h).view(B, S, heads, hd).transpose(1, 2)
+        k = proj(lp + "self_attn.k_proj", h).view(B, S, heads, hd).transpose(1, 2)
+        v = proj(lp + "self_attn.v_proj", h).view(B, S, heads, hd).transpose(1, 2)
         q = q * cos + rotate_half(q) * sin
         k = k * cos + rotate_half(k) * sin
         w = (q @ k.transpose(-1, -2)) / math.sqrt(hd) + mask.to(q.dtype)
         w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
         att = (w @ v).transpose(1, 2).reshape(B, S, H)
-        x = x + _lin(sd, lp + "self_attn.o_proj", att, False)
+        x = x + post(lp + "self_attn.o_proj", att)
         h = rms_norm(x, sd[lp + "post_attention_layernorm.weight"], eps)
-        x = x + _lin(sd, lp + "mlp.down_proj",
-                     F.silu(_lin(sd, lp + "mlp.gate_proj", h, False)) * _lin(sd, lp + "mlp.up_proj", h, False), False)
+        x = x + post(lp + "mlp.down_proj", F.silu(post(lp + "mlp.gate_proj", h)) * post(lp + "mlp.up_proj", h))
     return rms_norm(x, sd["model.norm.weight"], eps) if final_norm else x
 
 
@@ -307,7 +327,8 @@ def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.T
     feats = clip_features(sd, images_clip.to(dt), cfg.clip_heads, cfg.clip_layers, cfg.clip_select_layer)
     proj = _lin(sd, "model.mm_projector", feats)
     x = splice(sd, input_ids, proj)
-    hidden = llama_prefill(sd, x, cfg.llm_heads, cfg.llm_layers, cfg.llm_rms_eps, cfg.llm_rope_theta)
+    hidden = llama_prefill(sd, x, cfg.llm_heads, cfg.llm_layers, cfg.llm_rms_eps, cfg.llm_rope_theta,
+                           w8a8=bool(getattr(cfg, "llm_w8a8", 0)))
     # loc_token_mask = (input_ids[:,1:] == loc) shifted right by P-1 (VSM.py:224-235,465-473): selects the hidden
     # state at spliced index idx([LOC]) - 1 + (P - 1)
     B = input_ids.shape[0]

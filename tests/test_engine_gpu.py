@@ -203,3 +203,45 @@ def test_fused_rope_epilogue_is_bit_identical_to_separate_pass(cuda, monkeypatch
         del eng
     for k in ("pred_logits", "pred_boxes", "low_res_masks"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_w8a8_mode_matches_fake_quant_oracle(cuda):
+    """BASELINE config 5 (fp8 weights / fp8 MFMA): with llm_w8a8=1 and >= 1024 rows the LLaMA linears run W8A8.  Parity target
+    = the oracle with the same fake quantisation (per-token / per-output-channel absmax/448 e4m3) evaluated in bf16; the
+    bf16 engine is compared too, to show what the quantisation itself costs."""
+    base = VSMConfig.tiny()
+    cfg8 = VSMConfig.tiny(llm_w8a8=1)
+    loc_id = base.llm_vocab - 1
+    sd = random_state_dict(base, seed=0, dtype=torch.bfloat16)
+    B, L = 4, 24
+    g = torch.Generator().manual_seed(78)
+    clip = torch.randn(B, 3, 224, 224, generator=g).bfloat16()
+    owl = torch.randn(B, 3, 768, 768, generator=g).bfloat16()
+    ids = torch.randint(3, loc_id - 3, (B, L), generator=g)
+    ids[:, 0] = 1
+    ids[:, 5] = -200
+    ids[:, L - 3] = loc_id
+    loc = loc_positions(ids.numpy(), loc_id, base.n_img_tokens)
+    e8 = VstarEngine(cfg8, 0)
+    e8.load_state_dict(sd)
+    out8 = e8.score_batch(clip, owl, ids.numpy(), loc)
+    h8 = e8.debug_read("llm_hidden_loc", B * base.llm_hidden).reshape(B, -1)
+    e16 = engine_for(base, 0)
+    out16 = e16.score_batch(clip, owl, ids.numpy(), loc)
+    h16 = e16.debug_read("llm_hidden_loc", B * base.llm_hidden).reshape(B, -1)
+    ref8 = vsm_oracle.vsm_forward(sd, cfg8, clip, owl, ids, loc_id)              # bf16 arithmetic + fake quant
+    ref16 = vsm_oracle.vsm_forward(sd, base, clip, owl, ids, loc_id)
+    rep = {
+        "hidden: engine8 vs oracle8": rel_l2(h8, ref8["llm_hidden_loc"].float().numpy()),
+        "hidden: engine16 vs oracle16": rel_l2(h16, ref16["llm_hidden_loc"].float().numpy()),
+        "hidden: engine8 vs engine16": rel_l2(h8, h16),
+        "logits: engine8 vs oracle8": rel_l2(out8["pred_logits"], ref8["pred_logits"].float().numpy()),
+        "logits: engine8 vs engine16": rel_l2(out8["pred_logits"], out16["pred_logits"]),
+        "masks: engine8 vs oracle8": rel_l2(out8["low_res_masks"], ref8["low_res_masks"].float().numpy()),
+    }
+    print({k: "%.2e" % v for k, v in rep.items()})
+    assert rep["hidden: engine8 vs engine16"] > 1e-4                   # the fp8 path really ran
+    noise = max(rep["hidden: engine16 vs oracle16"], 5e-3)
+    assert rep["hidden: engine8 vs oracle8"] <= 6 * noise               # same order as the bf16 path's own noise
+    assert rep["hidden: engine8 vs engine16"] <= 0.15                  # and the quantisation costs a few percent
+    assert rep["logits: engine8 vs oracle8"] <= 6e-2 and rep["masks: engine8 vs oracle8"] <= 8e-2

@@ -44,7 +44,8 @@ class CVstarConfig(ctypes.Structure):
         ("owl_query_dim", ctypes.c_int32),
         ("max_batch", ctypes.c_int32),
         ("max_text_len", ctypes.c_int32),
-        ("reserved", ctypes.c_int32 * 8),
+        ("llm_w8a8", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 7),
     ]
 
 
@@ -73,6 +74,7 @@ class VSMConfig:
     owl_query_dim: int = 512
     max_batch: int = 32
     max_text_len: int = 192
+    llm_w8a8: int = 0               # 1: LLaMA linears on the fp8 MFMA (BASELINE config 5); default bf16
 
     # ---- derived ----
     @property

@@ -31,6 +31,10 @@ struct vstar_engine : EngineBase {
 
   // LLM activations
   int Smax = 0;
+  uint8_t* lq8 = nullptr; float* lsa = nullptr;      // W8A8: quantised activation rows + per-token scales
+  int make_lin8(const Lin& L, Lin8* out);
+  int lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
+           const lp_t* res, int64_t ldr, const lp_t* rope_cs = nullptr, int rope_S = 0, int rope_cols = 0);
   bool fused_rope = true;      // VSTAR_FUSED_ROPE=0 keeps RoPE as a separate pass (A/B and the bit-identity test)
   lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
   lp_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
@@ -84,6 +88,25 @@ int vstar_engine::make_sam_attn(const std::string& pre, SamAttn* a) {
   return 0;
 }
 
+// W8A8 twin of a packed Linear: quantise the packed bf16 rows on the device (per output channel)
+int vstar_engine::make_lin8(const Lin& L, Lin8* out) {
+  const int Npad = (L.N + 255) / 256 * 256;
+  if (L.K % 256) { set_error("W8A8 needs K % 256 == 0"); return VSTAR_ERR_INVALID; }
+  RC(dalloc(&out->W, (size_t)Npad * L.K));
+  RC(dalloc(&out->s, (size_t)Npad));
+  KCHK(quantize_rows_fp8(L.W, L.K, out->W, L.K, out->s, Npad, L.K, stream));
+  return 0;
+}
+
+int vstar_engine::lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
+                       const lp_t* res, int64_t ldr, const lp_t* rope_cs, int rope_S, int rope_cols) {
+  GemmParams p{};
+  p.A = (const lp_t*)Aq; p.lda = L.K; p.W = (const lp_t*)L8.W; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = L.N; p.K = L.K; p.a_scale = sa; p.w_scale = L8.s;
+  p.rope_cs = rope_cs; p.rope_S = rope_S; p.rope_cols = rope_cols;
+  return gemm(p, epi, false);
+}
+
 int vstar_engine::finalize() {
   if (finalized) { set_error("weights already finalized"); return VSTAR_ERR_STATE; }
   const vstar_config& c = cfg;
@@ -116,6 +139,14 @@ int vstar_engine::finalize() {
     RC(make_lin({lp + "mlp.gate_proj.weight", lp + "mlp.up_proj.weight"}, {}, &b.gate_up, H, &perm));
     RC(make_lin({lp + "mlp.down_proj.weight"}, {}, &b.down, c.llm_mlp));
   }
+  if (c.llm_w8a8) {
+    for (auto& b : llm) {
+      RC(make_lin8(b.qkv, &b.qkv8));
+      RC(make_lin8(b.o, &b.o8));
+      RC(make_lin8(b.gate_up, &b.gate_up8));
+      RC(make_lin8(b.down, &b.down8));
+    }
+  }
   RC(upload_vec("model.norm.weight", &final_norm, H));
   RC(make_lin({"lm_head.weight"}, {}, &lm_head, H));
   Smax = c.max_text_len - 1 + clip.P;
@@ -137,6 +168,10 @@ int vstar_engine::finalize() {
   RC(dalloc(&lqkv, lrows * 3 * H));
   RC(dalloc(&latt, lrows * H));
   RC(dalloc(&lact, lrows * c.llm_mlp));
+  if (c.llm_w8a8) {
+    RC(dalloc(&lq8, lrows * (size_t)(c.llm_mlp > H ? c.llm_mlp : H)));
+    RC(dalloc(&lsa, lrows));
+  }
   RC(dalloc(&hsel, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_att, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_x, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
@@ -405,10 +440,19 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   const int rows = B * S;
   const float att_scale = 1.0f / sqrtf(128.0f);
   const int nsel = B * (1 + n_verify);
+  // W8A8 (config 5): the four big linears of every block run on the fp8 MFMA when the call has enough rows for the 256^2
+  // kernel; activations are quantised per token right where they are produced (inside the RMSNorm for q|k|v and gate|up,
+  // by one pass over the attention output / the SiLU*up product for o_proj and down_proj)
+  const bool w8 = c.llm_w8a8 && rows >= 1024;
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
-    KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-    {  // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
+    if (w8) {
+      KCHK(rmsnorm_quant_fp8(lx, b.in_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
+      RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
+      if (!fused_rope) KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
+    } else {
+      KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+      // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
       GemmParams p{};
       p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = rows; p.N = b.qkv.N; p.K = b.qkv.K;
       const bool fused = fused_rope && gemm256_eligible(p);
@@ -420,6 +464,7 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
     if (i + 1 == c.llm_layers) {
       // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
       // attention is row-wise, so o_proj / MLP run on those B*(1+V) gathered rows only (row-wise ops: bit-identical).
+      // (W8A8 mode: these few rows stay on the bf16 weights — the weight-bound regime gains nothing from fp8 MFMA.)
       KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
       KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
       RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
@@ -428,10 +473,19 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
       RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
       break;
     }
-    RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-    KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-    RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
-    RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    if (w8) {
+      KCHK(quantize_rows_fp8(latt, H, lq8, H, lsa, rows, H, stream));
+      RC(lin8(lq8, lsa, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+      KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
+      RC(lin8(lq8, lsa, b.gate_up, b.gate_up8, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0));
+      KCHK(quantize_rows_fp8(lact, c.llm_mlp, lq8, c.llm_mlp, lsa, rows, c.llm_mlp, stream));
+      RC(lin8(lq8, lsa, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    } else {
+      RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+      KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
+      RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    }
   }
   // ---- a6/a7: final norm on the needed rows only, lm_head argmax at the verify rows, [LOC]-1 gather ----
   KCHK(rmsnorm_lp(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));

@@ -37,7 +37,9 @@ struct VitTower {
   // activations
   lp_t *im2col = nullptr, *patch_out = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp_buf = nullptr;
 };
-struct LlmBlock { lp_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; };
+// fp8 twin of a packed Linear (W8A8 mode): e4m3 rows + per-output-channel scales, same row order/padding as Lin::W
+struct Lin8 { uint8_t* W = nullptr; float* s = nullptr; };
+struct LlmBlock { lp_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; Lin8 qkv8, o8, gate_up8, down8; };
 
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \

@@ -398,7 +398,7 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 // Shapes this kernel accepts: K/64 even and >= 2, operands addressable with 32-bit element offsets.
 bool gemm256_eligible(const GemmParams& p) {
   if (p.a_scale) {      // W8A8: K counts fp8 elements, a K-tile is 128 of them, K/128 even
-    if (p.K % 256 != 0 || p.K < 256 || !p.w_scale || p.rope_cs) return false;
+    if (p.K % 256 != 0 || p.K < 256 || !p.w_scale) return false;
   }
   if (p.K % 128 != 0 || p.K < 128) return false;
   if (p.M < 1024 || p.N < 256) return false;
