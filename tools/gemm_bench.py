@@ -20,7 +20,8 @@ dev = torch.device("cuda:0")
 B = args.batch
 S, Nc, No = 640, 577, 2305
 # (name, M, N, K, epilogue, residual?) exactly as the engine launches them
-shapes = [("llama qkv", B * S, 12288, 4096, 0, 0), ("llama o +res", B * S, 4096, 4096, 0, 1), ("llama gate_up silu", B * S, 22016, 4096, 4, 0),
+shapes = [("llama qkv", B * S, 12288, 4096, 0, 0), ("llama o +res", B * S, 4096, 4096, 0, 1), ("llama o (no res)", B * S, 4096, 4096, 0, 0),
+          ("llama down (no res)", B * S, 4096, 11008, 0, 0), ("llama gate_up silu", B * S, 22016, 4096, 4, 0),
           ("llama down +res", B * S, 4096, 11008, 0, 1), ("clip qkv", B * Nc, 3072, 1024, 0, 0), ("clip out +res", B * Nc, 1024, 1024, 0, 1),
           ("clip fc1 qgelu", B * Nc, 4096, 1024, 1, 0), ("clip fc2 +res", B * Nc, 1024, 4096, 0, 1), ("owl qkv", B * No, 2304, 768, 0, 0),
           ("owl out +res", B * No, 768, 768, 0, 1), ("owl fc1 qgelu", B * No, 3072, 768, 1, 0), ("owl fc2 +res", B * No, 768, 3072, 0, 1),
