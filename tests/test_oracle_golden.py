@@ -49,3 +49,19 @@ def test_oracle_matches_reference_golden(path):
         close("pred_boxes", o["pred_boxes"][0])
         close("low_res_masks", o["low_res_masks"][0, 0])
         assert int(o["loc_pos"][0]) == int(loc_col) - 1 + cfg.n_img_tokens - 1
+
+
+def test_fp8_fake_quant_helpers():
+    """The W8A8 restatement (config 5): codes are exact e4m3 values, scales map the row absmax to 448, and the quantised
+    product stays within a few percent of the exact one."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(7, 512, generator=g) * torch.rand(7, 1, generator=g) * 5
+    q, s = vsm_oracle.fp8_fake_quant(x)
+    assert torch.allclose(q.abs().amax(dim=1), torch.full((7,), 448.0))
+    assert torch.equal(q, q.to(torch.float8_e4m3fn).float())                 # already representable
+    assert float(((q * s) - x).abs().max() / x.abs().max()) < 0.07            # 3 mantissa bits
+    zero, sz = vsm_oracle.fp8_fake_quant(torch.zeros(2, 16))
+    assert torch.equal(zero, torch.zeros(2, 16)) and torch.equal(sz, torch.ones(2, 1))
+    w = torch.randn(64, 512, generator=g) / 512 ** 0.5
+    y, ref = vsm_oracle.linear_w8a8(x, w), x @ w.T
+    assert float((y - ref).norm() / ref.norm()) < 0.05
