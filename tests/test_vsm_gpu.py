@@ -12,7 +12,7 @@ from oracle.gen_search_golden import synthetic_image
 from vstar_amd import preprocess as pp
 from vstar_amd.config import VSMConfig
 from vstar_amd.engine import VstarEngine
-from vstar_amd.search import smallest_size_for, visual_search
+from vstar_amd.search import smallest_size_for, visual_search, visual_search_many
 from vstar_amd.vsm import VSM
 from vstar_amd.weights import random_state_dict
 
@@ -85,6 +85,29 @@ def test_batched_search_equals_sequential(vsm):
     # exhaustive search (confidence_high=2 is unreachable): 1 + 4 + 16 nodes for 1280x720 with smallest_size 224
     assert s_seq["path_visited"] == 21 and s_seq["engine_batches"] == 21
     assert s_bat["engine_batches"] <= 4 and s_bat["crops_scored"] == 21
+
+
+def test_multi_target_search_equals_per_target_loop(vsm):
+    """visual_search_many (first engine step of all targets batched together, prompts of different lengths right-padded in
+    the same batch) returns exactly what the reference's per-object loop returns."""
+    img = synthetic_image(1280, 720, 33)
+    smallest = smallest_size_for(1280, 720)
+    names = ["kite", "small red umbrella on the beach", "dog"]          # different prompt lengths
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        loop, st_loop = [], []
+        for n in names:
+            st = {}
+            loop.append(visual_search(vsm, img, n, None, smallest, stats=st, **kw))
+            st_loop.append(st)
+        st_many = [{} for _ in names]
+        many = visual_search_many(vsm, img, names, None, smallest, **kw)
+    assert len(many) == len(loop)
+    for a, b in zip(loop, many):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert torch.equal(a[0]["detection_result"], b[0]["detection_result"])          # bit-identical scores
+        assert float(a[0]["score"] if a[0]["score"] is not None else 0) == float(b[0]["score"] if b[0]["score"] is not None else 0)
 
 
 @pytest.mark.parametrize("use_cache", [True, False])

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.gen_search_golden import synthetic_image  # noqa: E402  (test-infrastructure image generator only)
 from vstar_amd.config import VSMConfig  # noqa: E402
 from vstar_amd.preprocess import SyntheticTokenizer  # noqa: E402
-from vstar_amd.search import smallest_size_for, visual_search  # noqa: E402
+from vstar_amd.search import smallest_size_for, visual_search, visual_search_many  # noqa: E402
 from vstar_amd.vsm import VSM  # noqa: E402
 
 ap = argparse.ArgumentParser()
@@ -26,6 +26,7 @@ ap.add_argument("--image-size", type=int, default=336)
 ap.add_argument("--tiny", action="store_true")
 ap.add_argument("--device-reductions", action="store_true")
 ap.add_argument("--host-preprocess", action="store_true")
+ap.add_argument("--many", action="store_true", help="visual_search_many: first step of all targets batched together")
 args = ap.parse_args()
 cfg = (VSMConfig.tiny if args.tiny else VSMConfig.seal_7b)(clip_image_size=args.image_size, max_batch=32, max_text_len=128) \
     if args.tiny else VSMConfig.seal_7b(args.image_size, max_batch=32, max_text_len=128)
@@ -41,11 +42,15 @@ with warnings.catch_warnings():
         vsm.timers[k] = 0
     t0 = time.perf_counter()
     tot = {"crops_scored": 0, "engine_batches": 0, "path_visited": 0}
-    for i in range(args.targets):
-        st = {}
-        visual_search(vsm, img, f"object {i}", None, smallest, stats=st, **kw)
-        for k in tot:
-            tot[k] += st[k]
+    if args.many:
+        visual_search_many(vsm, img, [f"object {i}" for i in range(args.targets)], None, smallest, **kw)
+        tot["crops_scored"] = vsm.timers["crops"]
+    else:
+        for i in range(args.targets):
+            st = {}
+            visual_search(vsm, img, f"object {i}", None, smallest, stats=st, **kw)
+            for k in tot:
+                tot[k] += st[k]
     dt = time.perf_counter() - t0
 print(json.dumps({"mode": {"gpu_preprocess": not args.host_preprocess, "device_reductions": args.device_reductions},
                   "search_crops_per_s": round(tot["crops_scored"] / dt, 2), "wall_s": round(dt, 3), **tot,

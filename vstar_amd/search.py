@@ -13,7 +13,7 @@ from __future__ import annotations
 import copy
 import functools
 from queue import PriorityQueue
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Sequence,  Callable, Dict, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -132,28 +132,39 @@ class _NodeScorer:
             return []
         return get_sub_patches(bbox, *split_4subpatches(bbox))[0]
 
+    def plan(self, bbox, queue: PriorityQueue) -> List[list]:
+        """The crops one engine step would score for this node: the node itself plus, when speculating, breadth-first its
+        children, the queue's entries best-first and their children, ... up to one batch."""
+        key = tuple(bbox)
+        todo = [list(bbox)]
+        if self.speculate:
+            frontier = self._children(bbox)
+            frontier += [e.item["bbox"] for e in sorted(queue.queue)]
+            seen = {key}
+            while frontier and len(todo) < self.batch_size:
+                nxt = []
+                for b in frontier:
+                    k = tuple(b)
+                    if k in seen:
+                        continue
+                    seen.add(k)
+                    if k not in self.cache:
+                        todo.append(list(b))
+                        if len(todo) >= self.batch_size:
+                            break
+                    nxt += self._children(b)
+                frontier = nxt
+        return todo
+
+    def store(self, todo: List[list], res: List, sizes: List[Tuple[int, int]]) -> None:
+        for b, sz, r in zip(todo, sizes, res):
+            self.cache[tuple(b)] = [r, sz, not self.batched]     # [result, (w, h), heatmap already full-res?]
+        self.n_scored += len(todo)
+
     def get(self, bbox, queue: PriorityQueue):
         key = tuple(bbox)
         if key not in self.cache:
-            todo = [list(bbox)]
-            if self.speculate:
-                # breadth-first over: the node's children, then the queue's entries best-first and their children, ...
-                frontier = self._children(bbox)
-                frontier += [e.item["bbox"] for e in sorted(queue.queue)]
-                seen = {key}
-                while frontier and len(todo) < self.batch_size:
-                    nxt = []
-                    for b in frontier:
-                        k = tuple(b)
-                        if k in seen:
-                            continue
-                        seen.add(k)
-                        if k not in self.cache:
-                            todo.append(list(b))
-                            if len(todo) >= self.batch_size:
-                                break
-                        nxt += self._children(b)
-                    frontier = nxt
+            todo = self.plan(bbox, queue)
             if self.on_device:
                 res = self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False)
                 sizes = [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1])) for b in todo]
@@ -164,9 +175,7 @@ class _NodeScorer:
                     res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False)
                 else:
                     res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
-            for b, sz, r in zip(todo, sizes, res):
-                self.cache[tuple(b)] = [r, sz, not self.batched]     # [result, (w, h), heatmap already full-res?]
-            self.n_scored += len(todo)
+            self.store(todo, res, sizes)
             self.n_batches += 1
         (boxes, scores, heat), (w, h), full = self.cache[key]
         if not full and self.device_reductions:
@@ -181,7 +190,7 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                   target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
                   visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
                   noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
-                  gpu_preprocess: bool = True, device_reductions: bool = False):
+                  gpu_preprocess: bool = True, device_reductions: bool = False, _scorer: Optional["_NodeScorer"] = None):
     """Same contract as the reference's visual_search (visual_search.py:484-516): returns
     (final_step, path_length, search_successful, all_valid_boxes)."""
     if visualize:
@@ -190,7 +199,8 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
     search_path = [init_patch]
     queue: PriorityQueue = PriorityQueue()
     question = LOCATE_QUESTION.format(target_object_name)
-    scorer = _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate, gpu_preprocess, device_reductions)
+    scorer = _scorer or _NodeScorer(vsm, image, question, smallest_size, batch_size, speculate, gpu_preprocess,
+                                    device_reductions)
     on_dev = scorer.device_reductions
 
     search_successful, all_valid_boxes = False, None
@@ -335,3 +345,29 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
         stats.update(crops_scored=scorer.n_scored, engine_batches=scorer.n_batches, path_visited=len(search_path),
                      search_path=search_path)
     return final_step, path_length, search_successful, all_valid_boxes
+
+
+def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, **kw):
+    """Several targets on ONE image (the reference loops `visual_search` per missing object, vstar_bench_eval.py:205-209):
+    same per-target results as that loop — each entry is visual_search's 4-tuple — but the first engine step of every
+    target (root crop + its speculative sub-tree) is scored together, different prompts in the same 32-crop batches, so
+    small per-target steps still fill the GPU.  Later steps of a search run per target as usual."""
+    names = list(target_object_names)
+    gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
+    batch_size, speculate = kw.get("batch_size"), kw.get("speculate", True)
+    scorers = [_NodeScorer(vsm, image, LOCATE_QUESTION.format(n), smallest_size, batch_size, speculate,
+                           kw.get("gpu_preprocess", True), kw.get("device_reductions", False)) for n in names]
+    if scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1:
+        root = [0, 0, image.width, image.height]
+        pairs = [(sc, b) for sc in scorers for b in sc.plan(root, PriorityQueue())]
+        step = scorers[0].batch_size
+        for i0 in range(0, len(pairs), step):
+            chunk = pairs[i0:i0 + step]
+            boxes = [b for _, b in chunk]
+            res = vsm.inference_boxes(boxes, [sc.question for sc, _ in chunk], mode="detection", upsample=False)
+            for (sc, b), r in zip(chunk, res):
+                sc.store([b], [r], [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1]))])
+            for sc in {id(sc): sc for sc, _ in chunk}.values():
+                sc.n_batches += 1
+    kw = {k: v for k, v in kw.items()}
+    return [visual_search(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]

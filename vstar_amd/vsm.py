@@ -175,14 +175,31 @@ class VSM:
         self.engine.set_image(image)
 
     @torch.inference_mode()
-    def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question: str, mode: str = "detection",
+    def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question, mode: str = "detection",
                         upsample: bool = True):
         """Like inference_batch for crops `image.crop((int(x), int(y), int(x+w), int(y+h)))` of the image given to
-        set_image(), but crop / pad / resize / normalise run on the GPU (bit-identical to the PIL + HF-processor path)."""
+        set_image(), but crop / pad / resize / normalise run on the GPU (bit-identical to the PIL + HF-processor path).
+        `question` is one string for all boxes or one string PER box (several search targets sharing a batch): shorter
+        prompts are right-padded to the longest — under the causal mask the padding cannot reach the scored positions."""
         assert mode in ("segmentation", "detection")
-        ids, loc_pos, ver_pos, ver_tok = self._ids(question)
-        nv = min(len(ver_pos), 8)
-        ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
+        n_boxes = len(boxes_xywh)
+        qs = [question] * n_boxes if isinstance(question, str) else list(question)
+        assert len(qs) == n_boxes
+        per_q = {q: self._ids(q) for q in dict.fromkeys(qs)}
+        nv = min(min(len(v[2]) for v in per_q.values()), 8)
+        Lmax = max(len(v[0]) for v in per_q.values())
+        if Lmax > self.cfg.max_text_len:
+            raise ValueError(f"prompt of {Lmax} tokens exceeds max_text_len={self.cfg.max_text_len}")
+        ids_rows = np.zeros((n_boxes, Lmax), np.int32)
+        loc_rows = np.zeros((n_boxes,), np.int32)
+        ver_rows = np.zeros((n_boxes, nv), np.int32)
+        tok_rows = np.zeros((n_boxes, nv), np.int32)
+        for i, q in enumerate(qs):
+            ids, loc_pos, ver_pos, ver_tok = per_q[q]
+            ids_rows[i, :len(ids)] = ids
+            loc_rows[i] = loc_pos
+            ver_rows[i] = ver_pos[-nv:]
+            tok_rows[i] = ver_tok[-nv:]
         xyxy = np.asarray([[int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])] for b in boxes_xywh], np.int32)
         world, rank = self._dist()
         n = len(xyxy)
@@ -193,16 +210,14 @@ class VSM:
             sel = mine[s0:s0 + mb]
             B = len(sel)
             t1 = time.perf_counter()
-            local[s0:s0 + B] = self.engine.score_boxes(
-                xyxy[sel], np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
-                verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True)
+            local[s0:s0 + B] = self.engine.score_boxes(xyxy[sel], ids_rows[sel], loc_rows[sel], verify_pos=ver_rows[sel], raw=True)
             self.timers["engine_s"] += time.perf_counter() - t1
             self.timers["crops"] += B
         t2 = time.perf_counter()
         records = self._allgather(local, n) if world > 1 else local[:n]
         self.timers["gather_s"] += time.perf_counter() - t2
         res = self.engine.unpack(records, nv)
-        self.last_template_ok = (res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)
+        self.last_template_ok = (res["tf_argmax"] == tok_rows).all(axis=1)
         self._check_template(n)
         out: List = []
         for b in range(n):
