@@ -171,10 +171,10 @@ def main():
     fl = cfg.flops_per_crop(T, full=not args.skip_owl)
     per_crop = fl["core"] if args.skip_owl else fl["full"]
     # HBM-side traffic of the GEMM family per launch, from the committed rocprofv3 PMC passes of this same command
-    # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v6.json) — not re-measured live
+    # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v7.json) — not re-measured live
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_v6.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_v7.json")))
         gem = [k for k in pmc if "gemm" in k["kernel"]]
         traffic = round(sum(k["fetch_GB_corrected"] + k["write_GB"] for k in gem) * 1e9 / sum(k["launches"] for k in gem))
     except Exception:
@@ -182,7 +182,7 @@ def main():
     peak = 5000.0 if args.fp8 else PEAK_BF16_TFLOPS      # --fp8: 93 % of the GEMM FLOPs run on the fp8 MFMA (dense peak ~5 PF)
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None if args.fp8 else traffic,
-                "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v6; "
+                "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v7; "
                                 "includes Infinity-Cache hits); algorithmic operand+output bytes per launch ~0.3 GB",
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
