@@ -19,7 +19,7 @@ for f in gemm gemm256 norm attention elementwise decode quant heads preprocess e
   if stale build/$f.o $f.hip; then $HIPCC $FLAGS -c $f.hip -o build/$f.o & pids+=($!); fi
 done
 # fp16 instantiation (-DVSTAR_LP_F16): the dtype-generic kernel files + the VQA-LLM engine
-for f in gemm gemm256 norm attention elementwise decode quant vqa_engine; do
+for f in gemm gemm256 norm attention elementwise decode vqa_engine; do
   [ -f $f.hip ] || continue
   if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
 done

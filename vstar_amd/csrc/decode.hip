@@ -169,164 +169,6 @@ hipError_t launch_skinny(const GemmParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
-// ------------------------------------------------ skinny GEMM, W8A8 ------------------------------------------------
-// Decode-sized M on fp8 weights: half the bytes to stream.  W is OCP e4m3 [Npad, K] with per-output-channel scales
-// (p.w_scale, packed-row order); A stays 16-bit in memory and is quantised per token INSIDE the kernel: a pre-pass computes
-// each row's (optional LlamaRMSNorm statistic and) absmax of the 16-bit values the unfused path would have produced ->
-// scale = absmax/448, exactly what quantize_rows_fp8 / rmsnorm_quant_fp8 do for the large-M path; the main loop converts
-// the activation fragment to e4m3 in registers (v_cvt_pk_fp8_f32) and issues one 16x16x128 fp8 MFMA per 128 k.
-// Lane (fr, g) holds k = 128*ks + 32*g .. +31 of row fr for both operands (the dot product does not care about the order).
-template <int EPI, int MT>
-__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_f8_kernel(const GemmParams p) {
-  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
-  __shared__ float red[SK_WAVES][MT][64][4];
-  __shared__ float row_rstd[64], row_scale[64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int fr = lane & 15, g = lane >> 4;
-  const int n0 = blockIdx.x * 16 * NT;
-  const bool fuse_norm = p.norm_w != nullptr;
-
-  // ---- pre-pass: per-row RMS statistic (same summation order as norm_kernel<true>) and absmax -> quantisation scale ----
-  for (int row = wave; row < p.M; row += SK_WAVES) {
-    const lp_t* xr = p.A + (int64_t)row * p.lda;
-    float rs = 1.0f;
-    if (fuse_norm) {
-      float sum = 0.f;
-      for (int vi = lane; vi * 8 < p.K; vi += 64) {
-        const lpx8 t = *(const lpx8*)(xr + vi * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = lp2f((lp_t)t[e]);
-          sum += v * v;
-        }
-      }
-      sum = wave_sum(sum);
-      rs = rsqrtf(sum / (float)p.K + p.norm_eps);
-    }
-    float mx = 0.f;
-    for (int vi = lane; vi * 8 < p.K; vi += 64) {
-      const lpx8 t = *(const lpx8*)(xr + vi * 8);
-      lpx8 w = {0, 0, 0, 0, 0, 0, 0, 0};
-      if (fuse_norm) w = *(const lpx8*)(p.norm_w + vi * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = lp2f((lp_t)t[e]);
-        if (fuse_norm) v = rlp(lp2f((lp_t)w[e]) * rlp(v * rs));
-        mx = fmaxf(mx, fabsf(v));
-      }
-    }
-    mx = wave_max(mx);
-    if (lane == 0) {
-      row_rstd[row] = rs;
-      row_scale[row] = mx > 0.f ? mx / 448.0f : 1.0f;
-    }
-  }
-  __syncthreads();
-  float rstd[MT], inv[MT];
-  const lp_t* ap[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    int row = m * 16 + fr;
-    row = row < p.M ? row : p.M - 1;
-    rstd[m] = row_rstd[row];
-    inv[m] = 1.0f / row_scale[row];
-    ap[m] = p.A + (int64_t)row * p.lda + g * 32;
-  }
-  const uint8_t* wp[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) wp[t] = (const uint8_t*)p.W + (int64_t)(n0 + t * 16 + fr) * p.K + g * 32;
-  const lp_t* nwp = p.norm_w + g * 32;
-  f32x4 acc[NT][MT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nst = p.K >> 7;
-  for (int ks = wave; ks < nst; ks += SK_WAVES) {
-    const int k = ks * 128;
-    lpx8 wl[NT], wh[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      wl[t] = __builtin_nontemporal_load((const lpx8*)(wp[t] + k));
-      wh[t] = __builtin_nontemporal_load((const lpx8*)(wp[t] + k + 16));
-    }
-    lpx8 nw[4];
-    if (fuse_norm) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) nw[c] = *(const lpx8*)(nwp + k + c * 8);
-    }
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      uint32_t q[8];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const lpx8 a = *(const lpx8*)(ap[m] + k + c * 8);
-        float f[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          f[e] = lp2f((lp_t)a[e]);
-          if (fuse_norm) f[e] = rlp(lp2f((lp_t)nw[c][e]) * rlp(f[e] * rstd[m]));
-          f[e] *= inv[m];
-        }
-        uint32_t v0 = 0, v1 = 0;
-        v0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], v0, false);
-        v0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], v0, true);
-        v1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], v1, false);
-        v1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], v1, true);
-        q[2 * c] = v0;
-        q[2 * c + 1] = v1;
-      }
-      typedef __attribute__((ext_vector_type(4))) int i32x4q;
-      const lpx8 alo = __builtin_bit_cast(lpx8, (i32x4q){(int)q[0], (int)q[1], (int)q[2], (int)q[3]});
-      const lpx8 ahi = __builtin_bit_cast(lpx8, (i32x4q){(int)q[4], (int)q[5], (int)q[6], (int)q[7]});
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][m] = mfma_16x16x128_fp8(wl[t], wh[t], alo, ahi, acc[t][m]);
-    }
-  }
-  // ---- cross-wave reduction (fixed order), dequantisation, epilogue ----
-  f32x4 s[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t) __syncthreads();
-#pragma unroll
-    for (int m = 0; m < MT; ++m) *(f32x4*)red[wave][m][lane] = acc[t][m];
-    __syncthreads();
-    if (wave < MT) {
-      s[t] = *(const f32x4*)red[0][wave][lane];
-#pragma unroll
-      for (int w = 1; w < SK_WAVES; ++w) s[t] += *(const f32x4*)red[w][wave][lane];
-    }
-  }
-  if (wave >= MT) return;
-  const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
-  const int row = wave * 16 + fr;
-  if (row >= p.M) return;
-  const float sa = row_scale[row];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const f32x4 sw = *(const f32x4*)(p.w_scale + n0 + t * 16 + g * 4);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) s[t][e] *= sa * sw[e];
-  }
-  if (EPI == VSTAR_EPI_SILU_MUL) gemm_epilogue_store<EPI, false>(p, row, n0 / 2 + g * 4, n_out, s[0], s[NT - 1]);
-  else gemm_epilogue_store<EPI, false>(p, row, n0 + g * 4, n_out, s[0], s[0]);
-}
-
-template <int EPI>
-hipError_t launch_skinny_f8(const GemmParams& p, hipStream_t s) {
-  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
-  const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
-  switch ((p.M + 15) / 16) {
-    case 1: hipLaunchKernelGGL((gemm_skinny_f8_kernel<EPI, 1>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((gemm_skinny_f8_kernel<EPI, 2>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
-    case 3: hipLaunchKernelGGL((gemm_skinny_f8_kernel<EPI, 3>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
-    case 4: hipLaunchKernelGGL((gemm_skinny_f8_kernel<EPI, 4>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 // ------------------------------------------------ embedding rows ------------------------------------------------
 __global__ void embed_rows_kernel(const int32_t* __restrict__ src, const lp_t* __restrict__ table, int vocab,
                                   const lp_t* __restrict__ feats, int64_t n_feat_rows, lp_t* __restrict__ x, int R, int C) {
@@ -649,15 +491,6 @@ hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipSt
     SK_CASE(VSTAR_EPI_SILU_MUL)
   }
 #undef SK_CASE
-  return hipErrorInvalidValue;
-}
-
-// W8A8 decode GEMM: p.W = fp8 rows, p.w_scale = per-output-channel scales, p.A = 16-bit activations (quantised in-kernel)
-hipError_t gemm_skinny_f8_lp(const GemmParams& p, int epilogue, hipStream_t s) {
-  if (!(p.M > 0 && p.M <= 64 && p.a_group <= 0 && p.c_group <= 0 && p.K % 128 == 0 && (p.lda % 8) == 0 && p.w_scale && !p.a_scale))
-    return hipErrorInvalidValue;
-  if (epilogue == VSTAR_EPI_NONE) return launch_skinny_f8<VSTAR_EPI_NONE>(p, s);
-  if (epilogue == VSTAR_EPI_SILU_MUL) return launch_skinny_f8<VSTAR_EPI_SILU_MUL>(p, s);
   return hipErrorInvalidValue;
 }
 

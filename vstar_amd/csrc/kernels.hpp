@@ -37,8 +37,6 @@ bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 ke
 // decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp
 bool gemm_skinny_eligible(const GemmParams& p);
 hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
-// W8A8 form: W = fp8 e4m3 rows + w_scale, A 16-bit (quantised per token inside the kernel, optional fused RMSNorm); M <= 64
-hipError_t gemm_skinny_f8_lp(const GemmParams& p, int epilogue, hipStream_t s);
 
 // ---- KV-cached language model + Perceiver resampler (decode.hip) ----
 // x[r,:] = src[r] >= 0 ? table[src[r]] : (src[r] == INT32_MIN ? 0 : feats[-(src[r]+1)])

@@ -282,18 +282,8 @@ int vstar_vqa_op_gemm(const void* A, const void* W, const void* bias, const void
   p.C = C; p.ldc = n_out; p.M = M; p.N = N; p.K = K;
   p.norm_w = (const lp_t*)norm_w; p.norm_eps = norm_eps;
   hipError_t e;
-  if (kernel == 3) {        // W8A8 decode kernel: quantise W's rows to e4m3 here, A inside the kernel
-    const int Npad = (N + 255) / 256 * 256;
-    uint8_t* Wq = nullptr;
-    float* sw = nullptr;
-    e = hipMalloc((void**)&Wq, (size_t)Npad * K);
-    if (e == hipSuccess) e = hipMalloc((void**)&sw, (size_t)Npad * 4);
-    if (e == hipSuccess) e = quantize_rows_fp8((const lp_t*)W, K, Wq, K, sw, Npad, K, nullptr);
-    p.W = (const lp_t*)Wq; p.w_scale = sw;
-    if (e == hipSuccess) e = gemm_skinny_f8_lp(p, epilogue, nullptr);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    hipFree(Wq); hipFree(sw);
-  } else if (kernel == 1 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
+  if (kernel == 1 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
+  else e = gemm_lp(p, epilogue, false, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { tls_error() = std::string("vstar_vqa_op_gemm: ") + hipGetErrorString(e); return VSTAR_ERR_HIP; }
   return VSTAR_OK;
