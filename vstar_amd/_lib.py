@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64
 
 from .config import CVqaConfig, CVstarConfig, MASK_RES, MAX_VERIFY, N_BOXES
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvstar_hip.so")
+LIB_PATH = os.environ.get("VSTAR_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvstar_hip.so")   # VSTAR_LIB: A/B builds
 
 # every symbol include/vstar_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [

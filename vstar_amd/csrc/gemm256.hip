@@ -80,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
       t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    constexpr int GROUP_M = 8;
+    constexpr int GROUP_M = 4;
     const int in_group = GROUP_M * tiles_n;
     const int grp = t / in_group;
     const int first_m = grp * GROUP_M;
