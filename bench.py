@@ -74,6 +74,51 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
                       f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
 
 
+def fake_engine_run(args, world, rank, dist):
+    """The multi-process skeleton of main() with a stub in place of the engine (CPU, gloo): same collectives, same timing
+    protocol, same JSON keys.  Used by tests/test_host.py to cover the N>1 launch path without GPUs."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
+    B = args.batch
+    rec = torch.full((B, _lib.RESULT_FLOATS), float(rank), dtype=torch.float32)
+
+    def step():
+        time.sleep(0.01 * (1 + rank))                       # ranks finish at different times: the MAX must win
+        if world > 1:
+            out = torch.empty((world * B, _lib.RESULT_FLOATS), dtype=torch.float32)
+            dist.all_gather_into_tensor(out, rec)
+            return out
+        return rec
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        assert [float(out[r * B, 0]) for r in range(world)] == [float(r) for r in range(world)]     # rank order of the gather
+    if rank == 0:
+        print(json.dumps({"metric": "FAKE-ENGINE plumbing check (not a measurement)", "value": round(world * B * args.steps / dt, 3),
+                          "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub", "config": {"workload": "stub", "parallelism": f"dp{world}"},
+                          "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,6 +130,8 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="plumbing check with the tiny-width model (NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--skip-owl", action="store_true", help="core path only (diagnostic; NOT the headline metric)")
+    ap.add_argument("--fake-engine", action="store_true", help="CPU plumbing check of the N-process path (gloo, stub step): "
+                    "exercises rank/world handling, the per-step all-gather, the barrier and the max-over-ranks timing. NOT a bench")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
@@ -92,11 +139,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if args.fake_engine:
+        return fake_engine_run(args, world, rank, dist)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

@@ -212,3 +212,29 @@ def test_data_parallel_search_world2_equals_single_process():
         assert res[r][:5] == single[:5]                    # same path, boxes and decisions on every rank
     assert res[0][5] + res[1][5] == single[5]              # the crops were split between the ranks, none scored twice
     assert min(res[0][5], res[1][5]) >= single[5] // 2 - 2
+
+
+def test_bench_multiprocess_launch_path_on_cpu():
+    """The driver's N>1 launch line (torch.distributed.run, one rank per GPU) against bench.py's own collectives and timing
+    protocol, with the engine stubbed out (--fake-engine, gloo): rank 0 prints ONE JSON line, n_gpus = world, the gather is in
+    rank order and the slowest rank's time is the one reported."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--fake-engine"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 20.0          # rank 1 sleeps 20 ms per step: max over ranks, not rank 0's 10 ms
+    for k in ("metric", "value", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d
