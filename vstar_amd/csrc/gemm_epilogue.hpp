@@ -125,7 +125,7 @@ __device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, in
     }
   }
   if (full) {
-    *(lpx8*)c = v;
+    __builtin_nontemporal_store(v, (lpx8*)c);
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (lp_t)v[e];
