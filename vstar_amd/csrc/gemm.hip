@@ -173,7 +173,15 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   if (p.K % BK != 0 || p.K <= 0 || p.norm_w) return hipErrorInvalidValue;   // fused RMSNorm: skinny kernel only
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
   static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  if (force != 128 && gemm256_eligible(p)) return gemm256_lp(p, epilogue, out_f32, s);   // W is padded to 256 rows
+  if (force != 128 && gemm256_eligible(p)) {   // W is padded to 256 rows
+    // Under-filled grids (small batches: e.g. o_proj at 1280 rows = 80 tiles of 256^2 on 256 CUs): the 128^2 kernel has four
+    // times the tiles; one of its tiles takes ~0.36 of a 256^2 tile (1/4 of the work at ~0.7 of the efficiency), so compare
+    // whole rounds over the CUs.  Both kernels accumulate K in the same order: results are bit-identical either way.
+    const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const bool prefer128 = force != 256 && !p.rope_cs && !p.a_scale && t256 < 256 &&
+                           0.36 * (double)((t128 + 255) / 256) < (double)((t256 + 255) / 256);
+    if (!prefer128) return gemm256_lp(p, epilogue, out_f32, s);
+  }
   if (p.rope_cs || p.a_scale) return hipErrorInvalidValue;   // fused RoPE / W8A8 exist only in the 256^2 kernel: callers check gemm256_eligible
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
