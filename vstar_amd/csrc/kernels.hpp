@@ -12,7 +12,7 @@ namespace VS_NS {
 //   mapped(r) = (r / group) * gstride + off + r % group      (group <= 0: identity)
 struct GemmParams {
   const lp_t* A; int64_t lda; int a_group; int64_t a_gstride; int64_t a_off;
-  const lp_t* W;          // [ceil(N/128)*128, K], K % 64 == 0
+  const lp_t* W;          // [ceil(N/256)*256, K] K-contiguous rows (nn.Linear layout), zero padded; K % 64 == 0
   const lp_t* bias;       // [N] or null
   const lp_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
   void* C; int64_t ldc; int c_group; int64_t c_gstride; int64_t c_off;
