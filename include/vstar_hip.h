@@ -182,7 +182,10 @@ int vstar_profile_read(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches,
  * All tensors are dense row-major; "ld" = leading dimension in elements.  stream may be NULL.
  * ---------------------------------------------------------------------------------------------- */
 enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_EPI_RELU = 3, VSTAR_EPI_SILU_MUL = 4,
-       VSTAR_EPI_NOSYNC = 0x100 /* OR-ed into `epilogue`: launch only, do not synchronise (micro-benchmarks) */ };
+       VSTAR_EPI_NOSYNC = 0x100, /* OR-ed into `epilogue`: launch only, do not synchronise (micro-benchmarks) */
+       VSTAR_EPI_TILE128 = 0x200, /* OR-ed into `epilogue`: force the 128x128 kernel for this call */
+       VSTAR_EPI_TILE256 = 0x400  /* OR-ed into `epilogue`: force the 256x256 kernel; VSTAR_ERR_INVALID when the shape is outside
+                                     its domain (M >= 1024, N >= 256, K % 128 == 0) — never silently re-routed */ };
 
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate (MFMA), bf16 or fp32 out.
  * Replaces every nn.Linear / conv-as-GEMM on the path (SURVEY.md §8d GEMM shape list).
@@ -191,6 +194,9 @@ enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_E
 int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
                   const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,
                   int M, int N, int K, int epilogue);
+/* Which GEMM kernel the calling thread's last vstar_op_gemm / vstar_op_gemm_fp8 launched: 128, 256, or 0 (nothing launched).
+ * Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */
+int vstar_op_gemm_last_tile(void);
 /* W8A8 GEMM (BASELINE config 5: fp8 weights on the CDNA4 fp8 MFMA), op level, all pointers DEVICE pointers: quantises the
  * rows of A [M,K] (per token) and of W [ceil(N/256)*256, K] (per output channel) to OCP fp8 e4m3 with scale = absmax/448,
  * then C[M,N] = epilogue((A_q . W_q^T) * a_scale[m] * w_scale[n] + bias) (+ residual) with fp32 accumulation on

@@ -11,6 +11,7 @@ from PIL import Image
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle.search_oracle import FakeVSM, load_reference_search  # noqa: E402
+from vstar_amd.synthetic import synthetic_image  # noqa: E402,F401  (the generator lives in the product package; re-exported)
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "search_paths.json")
 
@@ -18,12 +19,6 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 CASES = [(1920, 1080, 0, 0, -2.5, 4.0), (1920, 1080, 1, 1, -6.0, 4.0), (3840, 2160, 2, 2, -6.0, 4.0), (900, 2400, 3, 3, -4.0, 4.0),
          (2400, 700, 4, 4, -4.0, 4.0), (1500, 1500, 5, 5, -1.0, 4.0), (2048, 1536, 6, 6, -6.0, 8.0), (640, 480, 7, 7, -6.0, 4.0),
          (1920, 1080, 8, 8, 2.0, 4.0)]
-
-
-def synthetic_image(w, h, seed):
-    rng = np.random.default_rng(seed)
-    low = rng.integers(0, 255, size=(h // 64 + 1, w // 64 + 1, 3), dtype=np.uint8)
-    return Image.fromarray(low).resize((w, h), Image.BILINEAR)
 
 
 CUE_TEXT = "The object is most likely to appear on the wooden table near the window."

@@ -174,7 +174,7 @@ class _FakeEngine:
 
 def _search_once():
     import warnings
-    from oracle.gen_search_golden import synthetic_image
+    from vstar_amd.synthetic import synthetic_image
     from vstar_amd.search import smallest_size_for, visual_search
     from vstar_amd.vsm import VSM
     eng = _FakeEngine()

@@ -22,15 +22,21 @@ def _pad_w(w):  # library contract: W allocated to a multiple of 256 rows
     return out
 
 
-def _gemm(lib, a, w, bias=None, res=None, epi=0, f32=False, n=None):
+def _gemm(lib, a, w, bias=None, res=None, epi=0, f32=False, n=None, tile=0):
+    """tile: 0 = dispatcher's choice, 128 / 256 = force that kernel AND assert it is the one that ran."""
     M, K = a.shape
     N = n if n is not None else w.shape[0]
     n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
     c = torch.full((M, n_out), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16, device=a.device)
     wp = _pad_w(w)
+    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256}[tile]
     rc = lib.vstar_op_gemm(None, P(a), K, P(wp), P(bias), P(res), n_out if res is not None else 0, P(c), n_out,
-                           1 if f32 else 0, M, N, K, epi)
+                           1 if f32 else 0, M, N, K, epi | flag)
     assert rc == 0, lib.vstar_last_error(None)
+    ran = lib.vstar_op_gemm_last_tile()
+    assert ran in (128, 256)
+    if tile:
+        assert ran == tile, f"asked for the {tile}^2 kernel, the {ran}^2 kernel ran"
     torch.cuda.synchronize()
     return c
 
@@ -174,7 +180,7 @@ def test_gemm256_f32_out(lib, cuda, M, N, K):
     a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
     w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
     bias = torch.randn(N, generator=g, device=cuda).bfloat16()
-    c = _gemm(lib, a, w, bias, f32=True)
+    c = _gemm(lib, a, w, bias, f32=True, tile=256)
     ref = a.float() @ w.float().T + bias.float()          # device fp32 GEMM as the large-shape checker
     assert not torch.isnan(c).any()
     assert _rel(c, ref) < 1e-3
@@ -187,7 +193,7 @@ def test_gemm256_transpose_and_rowmajor(lib, cuda):
     a = torch.zeros(1024, K)
     a[:K] = torch.eye(K)
     w = torch.arange(N * K, dtype=torch.float32).reshape(N, K).remainder(251)
-    c = _gemm(lib, a.bfloat16().to(cuda), w.bfloat16().to(cuda), f32=True)
+    c = _gemm(lib, a.bfloat16().to(cuda), w.bfloat16().to(cuda), f32=True, tile=256)
     assert torch.equal(c[:K].cpu(), w.bfloat16().float().T)
     assert (c[K:] == 0).all()
 
@@ -200,7 +206,7 @@ def test_gemm256_bf16_epilogues(lib, cuda, epi):
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(cuda)
     bias = torch.randn(N, generator=g).bfloat16().to(cuda)
     res = torch.randn(M, N, generator=g).bfloat16().to(cuda)
-    c = _gemm(lib, a, w, bias, res, epi=epi)
+    c = _gemm(lib, a, w, bias, res, epi=epi, tile=256)
     t = (a.float().cpu() @ w.float().cpu().T + bias.float().cpu()).bfloat16().float()
     if epi == _lib.EPI_QUICK_GELU:
         t = t * torch.sigmoid(1.702 * t)
@@ -220,7 +226,7 @@ def test_gemm256_silu_mul(lib, cuda):
     idx = torch.arange(2 * F_)
     blk, wi = idx // 32, idx % 32
     packed = torch.where((wi < 16)[:, None], gate[(blk * 16 + wi.clamp(max=15))], up[(blk * 16 + (wi - 16).clamp(min=0))])
-    c = _gemm(lib, a, packed.to(cuda), epi=_lib.EPI_SILU_MUL)
+    c = _gemm(lib, a, packed.to(cuda), epi=_lib.EPI_SILU_MUL, tile=256)
     gf = (a.float().cpu() @ gate.float().T).bfloat16().float()
     uf = (a.float().cpu() @ up.float().T).bfloat16().float()
     ref = F.silu(gf).bfloat16().float() * uf
@@ -235,12 +241,107 @@ def test_gemm256_race_screen(lib, cuda):
     g = torch.Generator(device=cuda).manual_seed(77)
     a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
     w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
-    first = _gemm(lib, a, w, f32=True)
+    first = _gemm(lib, a, w, f32=True, tile=256)
     ref = a.float() @ w.float().T
     assert ((first - ref).abs() <= 1e-3 * ref.abs().max()).all()
     for _ in range(10):
-        again = _gemm(lib, a, w, f32=True)
+        again = _gemm(lib, a, w, f32=True, tile=256)
         assert torch.equal(again, first)
+
+
+def _pack_gate_up(gate, up):
+    F_ = gate.shape[0]
+    idx = torch.arange(2 * F_)
+    blk, wi = idx // 32, idx % 32
+    return torch.where((wi < 16)[:, None], gate[(blk * 16 + wi.clamp(max=15))], up[(blk * 16 + (wi - 16).clamp(min=0))])
+
+
+def test_gemm_tile_override_contract(lib, cuda):
+    """The per-call tile override is honoured or refused, never silently re-routed; the dispatcher's own choice is observable."""
+    a = torch.randn(300, 128).bfloat16().to(cuda)
+    w = torch.randn(256, 128).bfloat16().to(cuda)
+    c = torch.empty(300, 256, dtype=torch.bfloat16, device=cuda)
+    rc = lib.vstar_op_gemm(None, P(a), 128, P(w), None, None, 0, P(c), 256, 0, 300, 256, 128, _lib.EPI_TILE256)
+    assert rc != 0 and b"256x256" in lib.vstar_last_error(None)          # M < 1024: outside the 256^2 kernel's domain
+    rc = lib.vstar_op_gemm(None, P(a), 128, P(w), None, None, 0, P(c), 256, 0, 300, 256, 128, _lib.EPI_TILE256 | _lib.EPI_TILE128)
+    assert rc != 0
+    _gemm(lib, a, w, tile=128)
+    # dispatcher defaults: a full grid of 256^2 tiles stays on the 256^2 kernel, an under-filled one moves to 128^2
+    big_a = torch.randn(20480, 256).bfloat16().to(cuda)
+    big_w = torch.randn(4096, 256).bfloat16().to(cuda)
+    _gemm(lib, big_a, big_w)
+    assert lib.vstar_op_gemm_last_tile() == 256
+    _gemm(lib, big_a[:1200], big_w[:384])
+    assert lib.vstar_op_gemm_last_tile() == 128
+
+
+@pytest.mark.parametrize("M,N,K,epi,use_bias,use_res,f32", [
+    (1030, 300, 384, 0, True, False, True),        # M and N tails, fp32 out
+    (1500, 768, 256, 1, True, False, False),       # QUICK_GELU + bias (ViT fc1 form)
+    (1300, 4096, 1024, 0, False, True, False),     # residual (o_proj / fc2 form)
+    (2048, 512, 11008, 0, False, True, False),     # long K (down_proj)
+    (1100, 512, 256, 4, False, False, False),      # SiLU(gate)*up
+    (1200, 384, 128, 3, True, True, False),        # RELU + bias + residual, N tail
+    (1056, 514, 768, 0, True, False, True),        # fused class-head width (N = 514)
+])
+def test_gemm128_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res, f32):
+    """Both kernels accumulate K in the same order with the same epilogue arithmetic: forced onto the same operands they
+    must agree BIT FOR BIT (this is what lets the dispatcher pick either by grid fill without changing results)."""
+    g = torch.Generator().manual_seed(M * 3 + N + K + epi)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    if epi == _lib.EPI_SILU_MUL:
+        w = _pack_gate_up(w[: N // 2], w[N // 2:])
+    w = w.to(cuda)
+    n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
+    bias = torch.randn(N, generator=g).bfloat16().to(cuda) if use_bias else None
+    res = torch.randn(M, n_out, generator=g).bfloat16().to(cuda) if use_res else None
+    c256 = _gemm(lib, a, w, bias, res, epi=epi, f32=f32, tile=256)
+    c128 = _gemm(lib, a, w, bias, res, epi=epi, f32=f32, tile=128)
+    assert not torch.isnan(c256.float()).any()
+    assert torch.equal(c256, c128)
+
+
+@pytest.mark.parametrize("name,M,N,K,epi,use_bias,use_res", [
+    ("clip_qkv", 18464, 3072, 1024, 0, True, False),          # 32 crops x 577 tokens: M tail of 32 rows
+    ("clip_fc1", 18464, 4096, 1024, 1, True, False),          # QUICK_GELU + bias, short K
+    ("clip_fc2", 18464, 1024, 4096, 0, True, True),           # bias + residual
+    ("owl_qkv", 73760, 2304, 768, 0, True, False),            # 32 x 2305 tokens: M tail of 32 rows, N = 9 tiles
+    ("owl_fc1", 73760, 3072, 768, 1, True, False),
+    ("llm_gate_up", 20480, 22016, 4096, 4, False, False),     # SiLU(gate)*up, N = 86 tiles
+    ("llm_down", 20480, 4096, 11008, 0, False, True),         # K = 11008 + residual
+    ("llm_o", 20480, 4096, 4096, 0, False, True),
+])
+def test_gemm256_bench_shapes(lib, cuda, name, M, N, K, epi, use_bias, use_res):
+    """The shapes the headline bench actually launches (B = 32, I = 336), each forced onto the 256^2 kernel and checked on
+    every element against a device fp32 GEMM + the reference's bf16 rounding points."""
+    g = torch.Generator(device=cuda).manual_seed(len(name) + M + N)
+    a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
+    bias = torch.randn(N, generator=g, device=cuda).bfloat16() if use_bias else None
+    res = torch.randn(M, n_out, generator=g, device=cuda).bfloat16() if use_res else None
+    wk = _pack_gate_up(w[: N // 2].cpu(), w[N // 2:].cpu()).to(cuda) if epi == _lib.EPI_SILU_MUL else w
+    c = _gemm(lib, a, wk, bias, res, epi=epi, tile=256).float()
+    del wk
+    if epi == _lib.EPI_SILU_MUL:
+        gf = (a.float() @ w[: N // 2].float().T).bfloat16().float()
+        uf = (a.float() @ w[N // 2:].float().T).bfloat16().float()
+        ref = F.silu(gf).bfloat16().float() * uf
+        del gf, uf
+    else:
+        t = a.float() @ w.float().T
+        if bias is not None:
+            t += bias.float()
+        t = t.bfloat16().float()
+        if epi == _lib.EPI_QUICK_GELU:
+            t = t * torch.sigmoid(1.702 * t)
+        ref = t.bfloat16().float() + res.float() if res is not None else t
+    assert not torch.isnan(c).any()
+    err = (c - ref).abs()
+    tol = ref.abs() * 2 ** -7 + 2e-2
+    bad = (err > tol).sum().item()
+    assert bad == 0, (name, bad, err.max().item())
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (1300, 768, 1024, 0), (2048, 1024, 4096, 4), (1056, 300, 512, 0)])

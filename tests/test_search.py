@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle.gen_search_golden import synthetic_image
+from vstar_amd.synthetic import synthetic_image
 from oracle.search_oracle import FakeVSM
 from vstar_amd import search
 
@@ -143,3 +143,48 @@ def test_contextual_cue_branch_needs_vqa():
     vsm = FakeVSM(seed=1, conf_shift=-6.0, gain=0.1)
     with pytest.raises(NotImplementedError):
         search.visual_search(vsm, img, "object", [0, 0, 1, 1], 270)
+
+
+class _MismatchFake(BatchedFake):
+    """BatchedFake whose crops smaller than `min_side` fail the template check: with defer_mismatch the slot holds a
+    DeferredMismatch that raises the reference's IndexError only when resolved."""
+    supports_deferred_mismatch = True
+
+    def __init__(self, min_side, **kw):
+        super().__init__(**kw)
+        self.min_side = min_side
+        self.resolved = 0
+
+    def inference_batch(self, images, question, mode="detection", upsample=False, defer_mismatch=False):
+        from vstar_amd.vsm import DeferredMismatch
+        out = super().inference_batch(images, question, mode, upsample)
+
+        def boom():
+            self.resolved += 1
+            raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
+        for i, im in enumerate(images):
+            if min(im.size) < self.min_side:
+                assert defer_mismatch, "the scheduler must ask for deferred mismatches"
+                out[i] = DeferredMismatch(boom)
+        return out
+
+
+def test_speculative_template_mismatch_only_raises_when_visited():
+    """Round-1 advisor finding: a template mismatch on a speculative crop the best-first order never visits must not abort a
+    search the reference would complete; on a crop the search DOES visit, the reference's IndexError surfaces."""
+    # case 8: confident detection on the whole image (path_length 1) — children are speculated but never visited
+    gold = [g for g in GOLD if g["case"][2] == 8][0]
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    vsm = _MismatchFake(min(w, h), max_batch=32, seed=vseed, conf_shift=shift)
+    stats = {}
+    _check(search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"], stats=stats), gold)
+    assert stats["crops_scored"] > 1 and vsm.resolved == 0          # speculated, mismatching, never consumed
+    # case 1: low confidence everywhere, the search descends — the first visited child raises like the reference would
+    gold = [g for g in GOLD if g["case"][2] == 1][0]
+    w, h, iseed, vseed, shift, scale = gold["case"]
+    img = synthetic_image(w, h, iseed)
+    vsm = _MismatchFake(min(w, h), max_batch=32, seed=vseed, conf_shift=shift)
+    with pytest.raises(IndexError):
+        search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"])
+    assert vsm.resolved == 1

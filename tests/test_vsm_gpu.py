@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from oracle import vsm_oracle
-from oracle.gen_search_golden import synthetic_image
+from vstar_amd.synthetic import synthetic_image
 from vstar_amd import preprocess as pp
 from vstar_amd.config import VSMConfig
 from vstar_amd.engine import VstarEngine
@@ -196,6 +196,26 @@ def test_heatmap_stats_kernel_matches_host_reductions(vsm):
         assert abs(st[2] - H.sum()) <= 1e-9 * H.sum()
         for k, (x, y, rw, rh) in enumerate(rects):
             assert abs(st[3 + k] - H[y:y + rh, x:x + rw].sum()) <= 1e-9 * max(H.sum(), 1.0)
+
+
+def test_heatmap_stats_survives_image_regrow(vsm):
+    """Regression (round-1 advisor finding): vstar_image_set used to hipFree the heat-map statistics scratch when a LARGER image
+    forced a regrow and kept the dangling pointer — the next vstar_heatmap_stats then DMA'd into freed memory that the new image
+    allocation could own.  Sequence: stats -> bigger image -> stats -> crops of the new image must still be the image's bytes."""
+    g = torch.Generator().manual_seed(11)
+    low = (torch.randn(192, 192, generator=g) * 3).numpy()
+    rects = [[0, 0, 100, 100], [50, 60, 70, 80]]
+    vsm.set_image(synthetic_image(320, 240, 1))
+    first = vsm.heatmap_stats(low, 240, 320, rects)
+    for k, (w, h) in enumerate([(1600, 1200), (3840, 2160)]):           # two successive regrows
+        img = synthetic_image(w, h, 40 + k)
+        vsm.set_image(img)
+        again = vsm.heatmap_stats(low, 240, 320, rects)
+        assert np.array_equal(np.asarray(first), np.asarray(again))
+        box = [w - 300, h - 260, w, h]
+        clip_gpu, _ = vsm.engine.preprocess_only([box])
+        ref = torch.from_numpy(pp.clip_preprocess(img.crop(tuple(box)), vsm.cfg.clip_image_size)).bfloat16().float().numpy()
+        assert np.array_equal(clip_gpu[0], ref)                           # the resident image was not overwritten
 
 
 def test_search_with_device_reductions_equals_host_path(vsm):

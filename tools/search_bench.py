@@ -14,7 +14,7 @@ import warnings
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle.gen_search_golden import synthetic_image  # noqa: E402  (test-infrastructure image generator only)
+from vstar_amd.synthetic import synthetic_image  # noqa: E402
 from vstar_amd.config import VSMConfig  # noqa: E402
 from vstar_amd.preprocess import SyntheticTokenizer  # noqa: E402
 from vstar_amd.search import smallest_size_for, visual_search, visual_search_many  # noqa: E402

@@ -19,6 +19,7 @@ EXPORTS = [
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_vsm_generate", "vstar_op_gemm_fp8",
+    "vstar_op_gemm_last_tile",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -29,6 +30,7 @@ EXPORTS_VQA = [
 
 F32, F16, BF16 = 0, 1, 2
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
+EPI_NOSYNC, EPI_TILE128, EPI_TILE256 = 0x100, 0x200, 0x400
 F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS = 1, 2, 4, 8, 16
 
 
@@ -98,6 +100,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_gemm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_int]
     lib.vstar_op_gemm.restype = c_int
+    lib.vstar_op_gemm_last_tile.argtypes = []
+    lib.vstar_op_gemm_last_tile.restype = c_int
     lib.vstar_op_gemm_fp8.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       POINTER(c_float)]
     lib.vstar_op_gemm_fp8.restype = c_int

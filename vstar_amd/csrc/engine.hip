@@ -718,9 +718,10 @@ int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) 
   const size_t bytes = (size_t)height * width * 3;
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
   if (bytes > h->image_cap) {
-    if (h->d_stats) hipFree(h->d_stats);
-  if (h->d_image) hipFree(h->d_image);
+    // (d_stats is a fixed-size scratch of vstar_heatmap_stats, independent of the image: it is NOT touched here)
+    if (h->d_image) hipFree(h->d_image);
     h->d_image = nullptr;
+    h->image_cap = 0;
     if (hipMalloc((void**)&h->d_image, bytes) != hipSuccess) { h->set_error("hipMalloc(image) failed"); return VSTAR_ERR_NOMEM; }
     h->image_cap = bytes;
   }
@@ -844,10 +845,17 @@ int vstar_op_gemm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* 
   p.M = M; p.N = N; p.K = K;
   { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   const bool nosync = (epilogue & VSTAR_EPI_NOSYNC) != 0;
+  if ((epilogue & VSTAR_EPI_TILE128) && (epilogue & VSTAR_EPI_TILE256)) { tls_error() = "both tile overrides set"; return VSTAR_ERR_INVALID; }
+  p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
+  if (p.tile_force == 256 && !gemm256_eligible(p)) {
+    tls_error() = "VSTAR_EPI_TILE256: shape outside the 256x256 kernel's domain (M >= 1024, N >= 256, K % 128 == 0)";
+    return VSTAR_ERR_INVALID;
+  }
   hipError_t e = gemm_lp(p, epilogue & 0xff, out_f32 != 0, (hipStream_t)stream);
   if (e == hipSuccess && !nosync) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
+int vstar_op_gemm_last_tile(void) { return gemm_last_tile(); }
 int vstar_op_layernorm(void* stream, const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y, int rows,
                        int cols, float eps) {
   hipError_t e = layernorm_lp(x, g, b, y, rows, cols, eps, nullptr, 0, (hipStream_t)stream);

@@ -168,21 +168,44 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 bool gemm256_eligible(const GemmParams& p);
 hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 
+static thread_local int t_last_tile = 0;
+int gemm_last_tile() { return t_last_tile; }
+
+int gemm_device_cus() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 8;
+    n_cu = prop.multiProcessorCount / 8 * 8;
+    if (n_cu <= 0) n_cu = 8;
+  }
+  return n_cu;
+}
+
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+  t_last_tile = 0;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % BK != 0 || p.K <= 0 || p.norm_w) return hipErrorInvalidValue;   // fused RMSNorm: skinny kernel only
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
-  static const int force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  if (force != 128 && gemm256_eligible(p)) {   // W is padded to 256 rows
+  static const int env_force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const int force = p.tile_force ? p.tile_force : env_force;
+  if (force != 0 && force != 128 && force != 256) return hipErrorInvalidValue;
+  const bool elig = gemm256_eligible(p);
+  if (p.tile_force == 256 && !elig) return hipErrorInvalidValue;   // an explicit per-call request must not be silently re-routed
+  if (force != 128 && elig) {   // W is padded to 256 rows
     // Under-filled grids (small batches: e.g. o_proj at 1280 rows = 80 tiles of 256^2 on 256 CUs): the 128^2 kernel has four
     // times the tiles; one of its tiles takes ~0.36 of a 256^2 tile (1/4 of the work at ~0.7 of the efficiency), so compare
-    // whole rounds over the CUs.  Both kernels accumulate K in the same order: results are bit-identical either way.
+    // whole rounds over the CUs.  Both kernels accumulate K in the same order: results are bit-identical either way
+    // (tests/test_ops_gpu.py::test_gemm128_equals_gemm256).
+    const int64_t cus = gemm_device_cus();
     const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    const bool prefer128 = force != 256 && !p.rope_cs && !p.a_scale && t256 < 256 &&
-                           0.36 * (double)((t128 + 255) / 256) < (double)((t256 + 255) / 256);
-    if (!prefer128) return gemm256_lp(p, epilogue, out_f32, s);
+    const bool prefer128 = force != 256 && !p.rope_cs && !p.a_scale && t256 < cus &&
+                           0.36 * (double)((t128 + cus - 1) / cus) < (double)((t256 + cus - 1) / cus);
+    if (!prefer128) { t_last_tile = 256; return gemm256_lp(p, epilogue, out_f32, s); }
   }
   if (p.rope_cs || p.a_scale) return hipErrorInvalidValue;   // fused RoPE / W8A8 exist only in the 256^2 kernel: callers check gemm256_eligible
+  t_last_tile = 128;
 #define GEMM_CASE(E)                                                   \
   case E:                                                              \
     return out_f32 ? launch<E, true>(p, s) : launch<E, false>(p, s);
@@ -194,6 +217,7 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
     GEMM_CASE(VSTAR_EPI_SILU_MUL)
   }
 #undef GEMM_CASE
+  t_last_tile = 0;
   return hipErrorInvalidValue;
 }
 

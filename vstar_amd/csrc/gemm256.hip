@@ -380,14 +380,7 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorUnknown;
-    n_cu = prop.multiProcessorCount / 8 * 8;
-    if (n_cu <= 0) n_cu = 8;
-  }
+  const int n_cu = gemm_device_cus();
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS_TOTAL, s, p);
   return hipGetLastError();

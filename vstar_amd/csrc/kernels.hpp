@@ -30,8 +30,16 @@ struct GemmParams {
   // C = epilogue((A_q · W_q^T) * a_scale[m] * w_scale[n]).  One v_mfma_scale_f32_16x16x128_f8f6f4 (scales 1.0) replaces two
   // 16x16x32 bf16 MFMAs on the same LDS bytes, i.e. twice the K per K-tile at the same LDS/DMA traffic.
   const float* a_scale; const float* w_scale;
+  // kernel choice: 0 = the dispatcher decides, 128 / 256 = force that tile (256 fails with hipErrorInvalidValue when the shape
+  // is not gemm256_eligible).  Process-wide default for 0 calls: environment VSTAR_GEMM_TILE (A/B runs).
+  int tile_force;
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+// which kernel the last gemm_lp call of THIS thread launched: 128, 256, or 0 when nothing was launched (observability for the
+// op-level tests: a dispatcher change must not silently move a test onto the other kernel)
+int gemm_last_tile();
+// compute units of the current device, rounded down to a multiple of 8 (>= 8); cached per process
+int gemm_device_cus();
 bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 kernel (the only one that honours rope_cs)
 
 // decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp

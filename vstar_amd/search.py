@@ -165,18 +165,24 @@ class _NodeScorer:
         key = tuple(bbox)
         if key not in self.cache:
             todo = self.plan(bbox, queue)
+            # defer_mismatch: a crop whose template check fails is only re-decoded (and can only raise the reference's
+            # IndexError) when the best-first order really visits it — speculative crops the reference never evaluates cannot
+            # abort a search the reference would complete
+            kw = {"defer_mismatch": True} if getattr(self.vsm, "supports_deferred_mismatch", False) else {}
             if self.on_device:
-                res = self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False)
+                res = self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False, **kw)
                 sizes = [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1])) for b in todo]
             else:
                 crops = [_crop(self.image, b) for b in todo]
                 sizes = [c.size for c in crops]
                 if self.batched:
-                    res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False)
+                    res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False, **kw)
                 else:
                     res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
             self.store(todo, res, sizes)
             self.n_batches += 1
+        if hasattr(self.cache[key][0], "resolve"):              # DeferredMismatch: the node is being consumed NOW
+            self.cache[key][0] = self.cache[key][0].resolve()
         (boxes, scores, heat), (w, h), full = self.cache[key]
         if not full and self.device_reductions:
             return boxes, scores, heat                          # 192x192 low-res logits; statistics are taken on the GPU
@@ -364,7 +370,8 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
         for i0 in range(0, len(pairs), step):
             chunk = pairs[i0:i0 + step]
             boxes = [b for _, b in chunk]
-            res = vsm.inference_boxes(boxes, [sc.question for sc, _ in chunk], mode="detection", upsample=False)
+            dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
+            res = vsm.inference_boxes(boxes, [sc.question for sc, _ in chunk], mode="detection", upsample=False, **dkw)
             for (sc, b), r in zip(chunk, res):
                 sc.store([b], [r], [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1]))])
             for sc in {id(sc): sc for sc, _ in chunk}.values():

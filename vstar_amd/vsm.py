@@ -34,8 +34,23 @@ from .weights import load_checkpoint_dir, random_state_dict
 
 
 class TemplateMismatch(RuntimeError):
-    """Greedy decoding would not have produced "Sure, [LOC]." for this crop (the reference would then index an empty
-    pred_mask and raise IndexError, visual_search.py:209-225)."""
+    """Kept for callers that caught it in round 1; no longer raised: a failed template check now falls back to the reference's
+    own stepwise greedy decode (see VSM._decode_fallback)."""
+
+
+class DeferredMismatch:
+    """Placeholder result of a crop whose teacher-forced template check failed inside a SPECULATIVE batch.  The reference only
+    ever evaluates crops it visits, so the stepwise-decode fallback (and the IndexError it may end in) is postponed until the
+    search actually consumes the node (`_NodeScorer.get` calls `resolve()`); unvisited speculative crops cost nothing."""
+
+    def __init__(self, fn):
+        self._fn, self._done, self._value = fn, False, None
+
+    def resolve(self):
+        if not self._done:
+            self._value = self._fn()          # may raise IndexError exactly like visual_search.py:209-225
+            self._done = True
+        return self._value
 
 
 class VSM:
@@ -76,6 +91,7 @@ class VSM:
         self.loc_token_idx = self.vsm_tokenizer("[LOC]", add_special_tokens=False).input_ids[0]
         self.strict_template = real if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
+        self.fallback_log: List[dict] = []      # one entry per stepwise-decode fallback (diagnostics / tests)
         self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0}
 
     # ---- multi-GPU plumbing ----
@@ -114,9 +130,11 @@ class VSM:
 
     @torch.inference_mode()
     def inference_batch(self, images: Sequence[Image.Image], question: str, mode: str = "detection",
-                        upsample: bool = True):
+                        upsample: bool = True, defer_mismatch: bool = False):
         """Scores all `images` (crops) for one question in engine batches of cfg.max_batch.  Returns a list of per-crop
-        results in the `inference` convention (with `upsample=False` the heatmap slot holds the 192x192 low-res logits)."""
+        results in the `inference` convention (with `upsample=False` the heatmap slot holds the 192x192 low-res logits).
+        Crops whose teacher-forced template check fails are re-run through the stepwise greedy decode (reference semantics);
+        with `defer_mismatch=True` that happens lazily (the slot holds a DeferredMismatch)."""
         assert mode in ("vqa", "segmentation", "detection")
         if mode == "vqa":
             return [self.generate(im, question) for im in images]
@@ -162,10 +180,12 @@ class VSM:
                 scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
                 out.append((boxes, scores, heat))
         self.last_template_ok = np.concatenate(ok_all) if ok_all else np.zeros((0,), bool)
-        self._check_template(len(images))
+        self._handle_mismatches(out, lambda b: images[b], question, mode, upsample, defer_mismatch)
         return out
 
     # ---- GPU-side preprocessing path: the image lives in HBM, crops are boxes ----
+    supports_deferred_mismatch = True
+
     @property
     def supports_gpu_preprocess(self) -> bool:
         return hasattr(self.engine, "score_boxes") and hasattr(self.engine, "set_image")
@@ -176,7 +196,7 @@ class VSM:
 
     @torch.inference_mode()
     def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question, mode: str = "detection",
-                        upsample: bool = True):
+                        upsample: bool = True, defer_mismatch: bool = False):
         """Like inference_batch for crops `image.crop((int(x), int(y), int(x+w), int(y+h)))` of the image given to
         set_image(), but crop / pad / resize / normalise run on the GPU (bit-identical to the PIL + HF-processor path).
         `question` is one string for all boxes or one string PER box (several search targets sharing a batch): shorter
@@ -218,7 +238,6 @@ class VSM:
         self.timers["gather_s"] += time.perf_counter() - t2
         res = self.engine.unpack(records, nv)
         self.last_template_ok = (res["tf_argmax"] == tok_rows).all(axis=1)
-        self._check_template(n)
         out: List = []
         for b in range(n):
             w, h = int(xyxy[b, 2] - xyxy[b, 0]), int(xyxy[b, 3] - xyxy[b, 1])
@@ -229,6 +248,9 @@ class VSM:
             else:
                 out.append((torch.from_numpy(res["pred_boxes"][b].copy()),
                             torch.from_numpy(res["pred_logits"][b].copy()).sigmoid(), heat))
+        # the fallback decodes from the host-side crop (bit-identical pixels: test_gpu_preprocess_is_bit_identical...)
+        self._handle_mismatches(out, lambda b: self._image.crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
+                                defer_mismatch)
         return out
 
     def heatmap_stats(self, low_res, h: int, w: int, rects_xywh=None) -> np.ndarray:
@@ -239,13 +261,64 @@ class VSM:
         self.timers["post_s"] += time.perf_counter() - t0
         return out
 
-    def _check_template(self, n: int) -> None:
-        if self.last_template_ok is not None and not self.last_template_ok.all():
-            msg = (f"{int((~self.last_template_ok).sum())}/{n} crops: greedy decoding would not emit "
-                   f"'{ANSWER_TEMPLATE}' (teacher-forced argmax check failed)")
-            if self.strict_template:
-                raise TemplateMismatch(msg)
-            warnings.warn(msg + " — tolerated because strict_template=False (synthetic weights)")
+    def _handle_mismatches(self, out: List, crop_of, question, mode: str, upsample: bool, defer: bool) -> None:
+        """Per-crop consequence of the teacher-forced template check (`last_template_ok`).
+
+        The single-prefill result is exact only if greedy decoding emits "Sure, [LOC]." (module docstring).  For a crop where
+        it would not, the reference's result is whatever `generate()` produces (VSM.py:451-473): the engine therefore falls
+        back to the stepwise greedy decode for THAT crop — `_decode_fallback` — and raises the reference's IndexError when no
+        [LOC] is emitted.  `strict_template=False` (seeded random weights, whose decode is noise) keeps the teacher-forced
+        result and warns instead."""
+        ok = self.last_template_ok
+        if ok is None or ok.all():
+            return
+        bad = [int(b) for b in np.nonzero(~ok)[0]]
+        if not self.strict_template:
+            warnings.warn(f"{len(bad)}/{len(out)} crops: greedy decoding would not emit '{ANSWER_TEMPLATE}' (teacher-forced "
+                          "argmax check failed) - tolerated because strict_template=False (synthetic weights)")
+            return
+        for b in bad:
+            q = question if isinstance(question, str) else question[b]
+            fn = (lambda b=b, q=q: self._decode_fallback(crop_of(b), q, mode, upsample))
+            out[b] = DeferredMismatch(fn) if defer else fn()
+
+    @torch.inference_mode()
+    def _decode_fallback(self, image: Image.Image, question: str, mode: str, upsample: bool = True):
+        """Reference semantics for a crop whose greedy decode is NOT the template (VSM.py:451-553 + visual_search.py:208-225):
+        decode stepwise (KV-cached greedy = the tokens `generate(use_cache=False)` emits), find the [LOC] tokens in the output,
+        and score the crop with the GENERATED answer teacher-forced — under causal attention the hidden state in front of a
+        [LOC] equals the one of the reference's last decode step.  Like the reference, boxes/logits come from the FIRST [LOC]
+        (`det_result[...][0]`) and the mask from the LAST (`pred_mask[-1]`); no [LOC] at all -> IndexError (`pred_mask[-1]` on
+        an empty tensor)."""
+        prompt_ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end), self.vsm_tokenizer)
+        gen = self.generate_ids(image, question, max_new_tokens=100)
+        locs = [i for i, t in enumerate(gen) if t == self.loc_token_idx]
+        self.fallback_log.append({"question": question, "generated": list(gen), "loc_positions": locs})
+        if not locs:
+            raise IndexError("index -1 is out of bounds for dimension 0 with size 0 "
+                             "(greedy decoding emitted no [LOC] token: visual_search.py:209-225 fails the same way)")
+        P = self.cfg.n_img_tokens
+        ids = prompt_ids + list(gen[:locs[-1] + 1])         # tokens after the last [LOC] cannot influence it (causal)
+        if len(ids) > self.cfg.max_text_len:
+            raise ValueError(f"prompt + generated answer ({len(ids)} tokens) exceeds max_text_len={self.cfg.max_text_len}")
+        pos = lambda k: len(prompt_ids) + k - 1 + (P - 1)   # spliced position of the state that predicts gen[k]  # noqa: E731
+        rows = [locs[0]] if locs[0] == locs[-1] else [locs[0], locs[-1]]
+        B = len(rows)
+        clip = torch.from_numpy(clip_preprocess(image, self.cfg.clip_image_size)).bfloat16()[None].repeat(B, 1, 1, 1)
+        owl = torch.from_numpy(owl_preprocess(image, self.cfg.owl_image_size)).bfloat16()[None].repeat(B, 1, 1, 1)
+        nv = min(locs[-1] + 1, 8)
+        ver_k = list(range(locs[-1] + 1 - nv, locs[-1] + 1))
+        res = self.engine.score_batch(clip, owl, np.tile(np.asarray(ids, np.int32)[None], (B, 1)),
+                                      np.asarray([pos(k) for k in rows], np.int32),
+                                      verify_pos=np.tile(np.asarray([pos(k) for k in ver_k], np.int32)[None], (B, 1)))
+        if not (res["tf_argmax"][0] == np.asarray([gen[k] for k in ver_k], np.int32)).all():
+            warnings.warn("stepwise decode and teacher-forced prefill disagree on an arg-max (near-tie under bf16 rounding)")
+        w, h = image.size
+        low = res["low_res_masks"][B - 1, 0]
+        heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
+        if mode == "segmentation":
+            return heat
+        return (torch.from_numpy(res["pred_boxes"][0].copy()), torch.from_numpy(res["pred_logits"][0].copy()).sigmoid(), heat)
 
     @torch.inference_mode()
     def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100, use_cache: bool = True) -> List[int]:
