@@ -339,7 +339,9 @@ def test_gemm256_bench_shapes(lib, cuda, name, M, N, K, epi, use_bias, use_res):
         ref = t.bfloat16().float() + res.float() if res is not None else t
     assert not torch.isnan(c).any()
     err = (c - ref).abs()
-    tol = ref.abs() * 2 ** -7 + 2e-2
+    # bf16 output = one rounding (2^-8 relative); SiLU(g)*u rounds g, u and SiLU(g) first, and a 1e-6 difference in the fp32
+    # accumulation order can flip any of them by one ulp on a rounding boundary (a handful of the 2e8 outputs): 4 x 2^-8
+    tol = ref.abs() * (2 ** -6 if epi in (_lib.EPI_SILU_MUL, _lib.EPI_QUICK_GELU) else 2 ** -7) + 2e-2
     bad = (err > tol).sum().item()
     assert bad == 0, (name, bad, err.max().item())
 
