@@ -50,7 +50,7 @@ def main():
         cfg = VSMConfig.tiny(**kw)
         loc_id = cfg.llm_vocab - 1
         rec = {k: [] for k in ("pred_logits", "pred_boxes", "low_res_masks", "clip_features", "llm_hidden_loc",
-                               "embed_det", "embed_seg", "ids", "in_checksum")}
+                               "embed_det", "embed_seg", "ids", "in_checksum", "sam_hyper", "sam_upscaled_mean")}
         P = cfg.n_img_tokens
         for (seed, L, img_col, loc_col) in crops:
             # A fresh reference model per crop: under transformers 5.x the reference's nested HF forwards leave
@@ -76,6 +76,11 @@ def main():
             h1 = vt.register_forward_hook(hook_clip)
             h2 = model.model.text_hidden_fcs_det[0].register_forward_hook(hook_det)
             h3 = model.model.text_hidden_fcs_seg[0].register_forward_hook(hook_seg)
+            # operands of the final mask product (mask_decoder.py:176-186): hyper_in [32] and the upscaled embedding [32,192,192]
+            # (only its per-channel mean is stored: the common-mode vector that conditions the mask's offset)
+            md = model.model.mask_decoder
+            md.output_hypernetworks_mlps[0].register_forward_hook(lambda m, i, o: taps.__setitem__("sam_hyper", o.detach().float().clone()))
+            md.output_upscaling.register_forward_hook(lambda m, i, o: taps.__setitem__("sam_up", o.detach().float().clone()))
             clip, owl, ids = make_inputs(cfg, seed, L, img_col, loc_col, loc_id)
             out = ref_shim.reference_forward(model, clip, owl, ids)
             pos = loc_col - 1 + (P - 1)
@@ -86,6 +91,8 @@ def main():
             rec["llm_hidden_loc"].append(taps["hidden"][0, pos].numpy())
             rec["embed_det"].append(taps["det_all"][0, pos].numpy())
             rec["embed_seg"].append(taps["seg_all"][0, pos].numpy())
+            rec["sam_hyper"].append(taps["sam_hyper"].reshape(-1).numpy())
+            rec["sam_upscaled_mean"].append(taps["sam_up"][0].double().mean(dim=(1, 2)).float().numpy())
             rec["ids"].append(ids[0].numpy().astype(np.int32))
             rec["in_checksum"].append(np.array([clip.double().sum().item(), owl.double().sum().item()]))
         meta = dict(weight_seed=wseed, crops=np.array(crops, dtype=np.int64), loc_id=loc_id,

@@ -278,7 +278,7 @@ def _upsample_conv(sd: SD, key: str, x: torch.Tensor) -> torch.Tensor:
     return F.conv2d(x, sd[key + ".conv.weight"], sd[key + ".conv.bias"], padding=1)
 
 
-def sam_mask_head(sd: SD, feature_map: torch.Tensor, seg_embed: torch.Tensor) -> torch.Tensor:
+def sam_mask_head(sd: SD, feature_map: torch.Tensor, seg_embed: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
     """visual_projection + PromptEncoder(text_embeds) + MaskDecoder(multimask_output=False) for ONE [LOC] per crop
     (VSM.py:515-533; prompt_encoder.py:140-186; mask_decoder.py:96-186).  feature_map [B,g,g,C], seg_embed [B,256]
     -> low-res mask logits [B,1,4g,4g]."""
@@ -297,13 +297,23 @@ def sam_mask_head(sd: SD, feature_map: torch.Tensor, seg_embed: torch.Tensor) ->
         mask_tokens_out = hs[:, 1:5, :]
         x = keys.transpose(1, 2).view(1, 256, g, g)
         x = _upsample_conv(sd, md + "output_upscaling.0", x)
+        if taps is not None:       # stage taps (channels-last, like the engine's buffers) for the mask-head error budget
+            taps.setdefault("sam_src", []).append(src.permute(0, 2, 3, 1).reshape(-1, 256) - dense.permute(0, 2, 3, 1).reshape(-1, 256))
+            taps.setdefault("sam_tokens", []).append(hs[0])
+            taps.setdefault("sam_keys", []).append(keys[0])
+            taps.setdefault("sam_c1", []).append(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
         x = F.gelu(_layer_norm_2d(x, sd[md + "output_upscaling.1.weight"], sd[md + "output_upscaling.1.bias"]))
+        if taps is not None:
+            taps.setdefault("sam_c1n", []).append(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
         x = F.gelu(_upsample_conv(sd, md + "output_upscaling.3", x))
         t = mask_tokens_out[:, 0, :]
         for j in range(3):
             t = _lin(sd, md + f"output_hypernetworks_mlps.0.layers.{j}", t)
             if j < 2:
                 t = F.relu(t)
+        if taps is not None:
+            taps.setdefault("sam_c2", []).append(x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]))
+            taps.setdefault("sam_hyper", []).append(t[0])
         b, c, h, w = x.shape
         out.append((t.unsqueeze(1) @ x.view(b, c, h * w)).view(b, 1, h, w))
     return torch.cat(out, dim=0)
@@ -343,13 +353,16 @@ def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.T
            "embed_det": text_hidden_fcs(sd, "det", h_loc), "embed_seg": text_hidden_fcs(sd, "seg", h_loc)}
     if verify_pos is not None:
         hv = hidden[torch.arange(B).unsqueeze(1), verify_pos]
-        out["tf_argmax"] = F.linear(hv, sd["lm_head.weight"]).float().argmax(-1)
+        out["tf_logits"] = F.linear(hv, sd["lm_head.weight"]).float()        # [B, V, vocab]: lets a test judge arg-max margins
+        out["tf_argmax"] = out["tf_logits"].argmax(-1)
     if images is not None:
         fmap = owl_visual_embs(sd, images.to(dt), cfg.owl_heads, cfg.owl_layers)
         out["owl_feats"] = fmap
         logits, boxes = owl_heads(sd, fmap, out["embed_det"].unsqueeze(1))
         out["pred_logits"], out["pred_boxes"] = logits, boxes
-        out["low_res_masks"] = sam_mask_head(sd, fmap, out["embed_seg"])
+        taps: dict = {}
+        out["low_res_masks"] = sam_mask_head(sd, fmap, out["embed_seg"], taps)
+        out["sam_taps"] = {k: torch.stack(v) for k, v in taps.items()}
     return out
 
 

@@ -19,6 +19,7 @@ import numpy as np
 import pytest
 import torch
 
+from _parity import assert_mask_within_bf16_noise, assert_within_bf16_noise, fmt
 from oracle import vsm_oracle
 from oracle.gen_golden import make_inputs
 from vstar_amd.config import VSMConfig
@@ -26,7 +27,7 @@ from vstar_amd.engine import VstarEngine, loc_positions
 from vstar_amd.weights import random_state_dict
 
 pytestmark = pytest.mark.gpu
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tiny*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tiny*.npz")) if not p.endswith("_bf16.npz"))
 
 
 def rel_l2(got, ref):
@@ -47,19 +48,51 @@ def engine_for(cfg, wseed):
     return _ENGINES[key]
 
 
+def margin_aware_topk_equal(got, ref, k, noise_abs):
+    """Top-k ORDER of `got` equals that of `ref`, except that neighbours whose reference values are closer than `noise_abs`
+    (the measured bf16 noise of this output) may swap.  Returns (ok, message)."""
+    got, ref = np.asarray(got, np.float64).ravel(), np.asarray(ref, np.float64).ravel()
+    order_ref = np.argsort(-ref)[:k + 1]
+    order_got = np.argsort(-got)[:k]
+    for r in range(k):
+        if order_got[r] == order_ref[r]:
+            continue
+        # a swap is legitimate only among reference entries within the noise of each other
+        if abs(ref[order_got[r]] - ref[order_ref[r]]) > noise_abs:
+            return False, f"rank {r}: got index {order_got[r]} (ref value {ref[order_got[r]]:.5f}) vs {order_ref[r]} ({ref[order_ref[r]]:.5f}), noise {noise_abs:.2e}"
+    return True, ""
+
+
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_engine_matches_reference_golden(cuda, path):
+    """Gate: per tap, the engine's distance from the reference's fp32 output must not exceed 1.5 x the
+    distance of the REFERENCE ITSELF evaluated in bf16 (tests/golden/*_bf16.npz, oracle/gen_golden_bf16.py) from its own fp32
+    output — no fixed floor; errors pooled (RMS) over the crops of a fixture.
+
+    The mask needs care (profiles/r02_mask_head_error_budget.txt, tools/mask_head_probe.py): mask(p) = hyper . upscaled(p) and
+    upscaled(p) = mu + r(p) with |mu| ~ 5 |r| (post-GELU features share a common mode), so the mask is a large, partly
+    cancelling OFFSET hyper.mu plus a PATTERN hyper.r(p).  Its plain rel-L2 is heavy-tailed per crop (0.7e-2 .. 7e-2 for the
+    reference's own bf16 run across seeds) because the offset's error is one scalar draw divided by a small norm.  So the mask
+    is gated in its two parts: the pattern (mean removed) at the same 1.5 x rule, and the offset against the 3-sigma band of a
+    noise model fed ONLY with the reference's measured bf16 noise:  sigma = sqrt(eps_h^2 + eps_mu^2) |h| |mu| / sqrt(32)
+    (eps_* = rel. error of the reference-bf16 operands; random direction in 32 dims).  The reference's own bf16 offsets are
+    checked against the same band, which validates the model.  The two operands are gated as taps of their own."""
     z = np.load(path)
+    zb = np.load(path[:-4] + "_bf16.npz")
     kw = {str(k): int(v) for k, v in zip(z["cfg_keys"], z["cfg_vals"])}
     cfg = VSMConfig.tiny(**kw)
     wseed, loc_id = int(z["weight_seed"]), int(z["loc_id"])
+    assert int(zb["weight_seed"]) == wseed and np.array_equal(zb["crops"], z["crops"])
     eng = engine_for(cfg, wseed)
-    sd_bf16 = random_state_dict(cfg, seed=wseed, dtype=torch.bfloat16)
     P = cfg.n_img_tokens
-    report, noise = {}, {}
+    n = len(z["crops"])
+    names = ("clip_features", "llm_hidden_loc", "embed_det", "embed_seg", "pred_logits", "pred_boxes", "sam_hyper",
+             "sam_upscaled_mean", "mask_pattern")
+    e_eng = {k: np.zeros(n) for k in names + ("low_res_masks",)}
+    e_ref = {k: np.zeros(n) for k in names + ("low_res_masks",)}
+    off_eng, off_ref, off_sigma = np.zeros(n), np.zeros(n), np.zeros(n)
     for i, (seed, L, img_col, loc_col) in enumerate(z["crops"]):
         clip, owl, ids = make_inputs(cfg, int(seed), int(L), int(img_col), int(loc_col), loc_id)
-        ob = vsm_oracle.vsm_forward(sd_bf16, cfg, clip.bfloat16(), owl.bfloat16(), ids, loc_id)
         loc = loc_positions(ids.numpy(), loc_id, P)
         out = eng.score_batch(clip, owl, ids.numpy(), loc)
         H = cfg.llm_hidden
@@ -71,17 +104,40 @@ def test_engine_matches_reference_golden(cuda, path):
             "pred_logits": out["pred_logits"][0, :, 0],
             "pred_boxes": out["pred_boxes"][0],
             "low_res_masks": out["low_res_masks"][0, 0],
+            "sam_hyper": eng.debug_read("sam_hyper", 32),
+            "sam_upscaled_mean": eng.debug_read("sam_c2", 192 * 192 * 32).reshape(-1, 32).astype(np.float64).mean(axis=0),
         }
-        for k, v in taps.items():
-            assert np.isfinite(v).all(), k
-            report[(i, k)] = rel_l2(v, z[k][i])
-            noise[(i, k)] = rel_l2(ob[k].float().numpy(), z[k][i])
+        gold, goldb = {k: z[k][i] for k in taps}, {k: zb[k][i] for k in taps}
+        for d in (taps, gold, goldb):
+            m = np.asarray(d["low_res_masks"], np.float64)
+            d["mask_pattern"] = m - m.mean()
+        for k in names + ("low_res_masks",):
+            assert np.isfinite(taps[k]).all(), k
+            e_eng[k][i] = rel_l2(taps[k], gold[k])
+            e_ref[k][i] = rel_l2(goldb[k], gold[k])
+        h, mu = gold["sam_hyper"].astype(np.float64), gold["sam_upscaled_mean"].astype(np.float64)
+        off_sigma[i] = np.hypot(e_ref["sam_hyper"][i], e_ref["sam_upscaled_mean"][i]) * np.linalg.norm(h) * np.linalg.norm(mu) / np.sqrt(32.0)
+        off_eng[i] = float(np.mean(taps["low_res_masks"], dtype=np.float64) - np.mean(gold["low_res_masks"], dtype=np.float64))
+        off_ref[i] = float(np.mean(goldb["low_res_masks"], dtype=np.float64) - np.mean(gold["low_res_masks"], dtype=np.float64))
         assert np.abs(taps["pred_boxes"] - z["pred_boxes"][i]).max() < 1e-2
-        assert int(np.argmax(taps["pred_logits"])) == int(np.argmax(z["pred_logits"][i]))
-    print("\nrel-L2 vs reference golden  engine / bf16-reference-algorithm:")
-    for key, v in report.items():
-        print(f"  crop {key[0]} {key[1]:<16s} {v:.2e} / {noise[key]:.2e}")
-        assert v <= max(2e-2, 3.0 * noise[key]), (key, v, noise[key])
+        # identical arg-max box and top-5 order, up to swaps of entries the reference's own bf16 run cannot separate
+        noise_abs = 2.0 * float(np.abs(zb["pred_logits"][i] - z["pred_logits"][i]).max())
+        ok, msg = margin_aware_topk_equal(taps["pred_logits"], z["pred_logits"][i], 5, noise_abs)
+        assert ok, msg
+        assert int(np.argmax(taps["pred_logits"])) == int(np.argmax(z["pred_logits"][i])) or noise_abs > 0 and \
+            abs(np.sort(z["pred_logits"][i])[-1] - np.sort(z["pred_logits"][i])[-2]) <= noise_abs
+    print("\nrel-L2 vs the reference's fp32 output:   engine (per crop)  |  reference in bf16 (per crop)  |  pooled ratio")
+    rms = lambda v: float(np.sqrt(np.mean(np.square(v))))  # noqa: E731
+    for k in names + ("low_res_masks",):
+        ratio = rms(e_eng[k]) / rms(e_ref[k])
+        print(f"  {k:<18s} {' '.join('%.2e' % v for v in e_eng[k])}  |  {' '.join('%.2e' % v for v in e_ref[k])}  |  {ratio:.2f}"
+              + ("   (informational: heavy-tailed, gated as pattern + offset)" if k == "low_res_masks" else ""))
+    print("  mask offset / sigma  engine " + " ".join("%.2f" % abs(a / s) for a, s in zip(off_eng, off_sigma)) +
+          "  |  reference in bf16 " + " ".join("%.2f" % abs(a / s) for a, s in zip(off_ref, off_sigma)))
+    for k in names:
+        assert rms(e_eng[k]) <= 1.5 * rms(e_ref[k]), (k, e_eng[k], e_ref[k])
+    assert (np.abs(off_ref) <= 3.0 * off_sigma).all(), ("offset noise model does not cover the reference's own bf16 run", off_ref, off_sigma)
+    assert (np.abs(off_eng) <= 3.0 * off_sigma).all(), ("mask offset outside the reference's bf16 noise band", off_eng, off_sigma)
 
 
 @pytest.mark.parametrize("image_size,B,L", [(224, 3, 20), (336, 4, 27)])
@@ -106,12 +162,27 @@ def test_engine_batched_vs_oracle(cuda, image_size, B, L):
     out = eng.score_batch(clip, owl, ids.numpy(), loc, verify_pos=verify)
     ref = vsm_oracle.vsm_forward(sd32, cfg, clip.float(), owl.float(), ids, loc_id,
                                  verify_pos=torch.from_numpy(verify).long())
-    assert rel_l2(out["pred_logits"], ref["pred_logits"].numpy()) < 2e-2
+    sd16 = random_state_dict(cfg, seed=wseed, dtype=torch.bfloat16)
+    r16 = vsm_oracle.vsm_forward(sd16, cfg, clip, owl, ids, loc_id)          # the same algorithm in bf16: the noise yardstick
+    rep = {}
+    assert_within_bf16_noise("pred_logits", out["pred_logits"], ref["pred_logits"].numpy(), r16["pred_logits"].float().numpy(), report=rep)
+    assert_within_bf16_noise("pred_boxes", out["pred_boxes"], ref["pred_boxes"].numpy(), r16["pred_boxes"].float().numpy(), report=rep)
     assert np.abs(out["pred_boxes"] - ref["pred_boxes"].numpy()).max() < 1e-2
-    assert rel_l2(out["low_res_masks"], ref["low_res_masks"].numpy()) < 2e-2
-    # teacher-forcing check rows: identical argmax except where the top-2 logits are within bf16 noise
-    same = (out["tf_argmax"] == ref["tf_argmax"].numpy()).mean()
-    assert same >= 0.75, (out["tf_argmax"], ref["tf_argmax"])
+    assert_mask_within_bf16_noise(out["low_res_masks"], ref["low_res_masks"].numpy(), r16["low_res_masks"].float().numpy(),
+                                  ref["sam_taps"]["sam_hyper"].numpy(), r16["sam_taps"]["sam_hyper"].float().numpy(),
+                                  ref["sam_taps"]["sam_c2"].mean(dim=1).numpy(), r16["sam_taps"]["sam_c2"].float().mean(dim=1).numpy(),
+                                  report=rep)
+    print("\nengine / bf16-oracle noise:", fmt(rep))
+    # teacher-forcing check rows: identical arg-max, except where the oracle's own decision margin (its logit at the engine's
+    # choice vs its maximum) is inside the bf16 noise of a logit row.  Noise scale: lm_head is a K=hidden dot product of a
+    # hidden state carrying ~1e-2 relative bf16 noise (measured above) -> ~1e-2 x the row's logit spread.
+    tl = ref["tf_logits"].numpy()
+    for b in range(B):
+        for v in range(verify.shape[1]):
+            row, got, want = tl[b, v], int(out["tf_argmax"][b, v]), int(ref["tf_argmax"][b, v])
+            if got != want:
+                spread = float(row.max() - row.min())
+                assert row[want] - row[got] <= 2e-2 * spread, (b, v, got, want, float(row[want] - row[got]), spread)
     # batch invariance: crop 0 alone gives bit-identical records (fixed reduction order, no split-K)
     solo = eng.score_batch(clip[:1], owl[:1], ids[:1].numpy(), loc[:1])
     assert np.array_equal(solo["pred_logits"][0], out["pred_logits"][0])
@@ -172,11 +243,24 @@ def test_engine_real_widths_vs_oracle(cuda):
         "embed_det": eng.debug_read("embed_det", B * 512).reshape(B, -1),
         "pred_logits": out["pred_logits"], "pred_boxes": out["pred_boxes"], "low_res_masks": out["low_res_masks"],
     }
-    errs = {k: rel_l2(v, ref[k].numpy()) for k, v in taps.items()}
-    print("\nreal-width rel-L2 vs fp32 oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
-    for k, v in errs.items():
-        assert np.isfinite(v) and v < (6e-2 if k == "low_res_masks" else 3e-2), (k, v)
+    r16 = vsm_oracle.vsm_forward(sd, cfg, clip, owl, ids, loc_id)           # the same algorithm in bf16 on torch-CPU
+    rep = {}
+    for k, v in taps.items():
+        if k != "low_res_masks":
+            assert_within_bf16_noise(k, v, ref[k].numpy(), r16[k].float().numpy(), report=rep)
+    assert_mask_within_bf16_noise(out["low_res_masks"], ref["low_res_masks"].numpy(), r16["low_res_masks"].float().numpy(),
+                                  ref["sam_taps"]["sam_hyper"].numpy(), r16["sam_taps"]["sam_hyper"].float().numpy(),
+                                  ref["sam_taps"]["sam_c2"].mean(dim=1).numpy(), r16["sam_taps"]["sam_c2"].float().mean(dim=1).numpy(),
+                                  report=rep)
+    print("\nreal-width engine / bf16-oracle noise (rel-L2 vs fp32 oracle):", fmt(rep))
     assert np.abs(out["pred_boxes"] - ref["pred_boxes"].numpy()).max() < 2e-2
+    # teacher-forced arg-max at the verify rows: equal unless the oracle's own margin is inside the logit noise
+    tl = ref["tf_logits"].numpy()
+    for b in range(B):
+        for v in range(2):
+            got, want = int(out["tf_argmax"][b, v]), int(ref["tf_argmax"][b, v])
+            if got != want:
+                assert tl[b, v, want] - tl[b, v, got] <= 2e-2 * float(tl[b, v].max() - tl[b, v].min()), (b, v, got, want)
     eng.close()
 
 

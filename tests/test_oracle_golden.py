@@ -12,7 +12,7 @@ from oracle.gen_golden import make_inputs
 from vstar_amd.config import VSMConfig
 from vstar_amd.weights import random_state_dict
 
-GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tiny*.npz")))
+GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "tiny*.npz")) if not p.endswith("_bf16.npz"))
 
 
 def load_case(path):

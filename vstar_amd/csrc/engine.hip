@@ -800,6 +800,11 @@ int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t 
   else if (n == "owl_feats") { src = h->owl_feats; cnt = (int64_t)B * h->owl.P * h->owl.hidden; }
   else if (n == "sam_tokens") { src = h->s_q; cnt = (int64_t)B * 6 * 256; }
   else if (n == "sam_keys") { src = h->s_keys; cnt = (int64_t)B * h->owl.P * 256; }
+  else if (n == "sam_src") { src = h->s_src; cnt = (int64_t)B * h->owl.P * 256; }
+  else if (n == "sam_c1") { src = h->s_c1; cnt = (int64_t)B * 96 * 96 * 64; }       // Upsample(256->64) output, channels-last
+  else if (n == "sam_c1n") { src = h->s_c1n; cnt = (int64_t)B * 96 * 96 * 64; }     // LayerNorm2d + GELU
+  else if (n == "sam_c2") { src = h->s_c2; cnt = (int64_t)B * 192 * 192 * 32; }     // Upsample(64->32) + GELU
+  else if (n == "sam_hyper") { src = h->s_hyper; cnt = (int64_t)B * 32; }
   else { h->set_error("unknown debug tensor: " + n); return VSTAR_ERR_INVALID; }
   if (cnt > cap) cnt = cap;
   std::vector<lp_t> tmp((size_t)cnt);
