@@ -164,16 +164,11 @@ def main():
     eng.load_state_dict(random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True))
     t_load = time.perf_counter() - t0
 
-    # synthetic crop batch, resident in HBM before the timed region
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    clip = torch.randn(B, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g, device=dev).bfloat16()
-    owl = torch.randn(B, 3, cfg.owl_image_size, cfg.owl_image_size, generator=g, device=dev).bfloat16()
-    rng = np.random.default_rng(rank)
-    ids = rng.integers(3, cfg.llm_vocab - 5, size=(B, L), dtype=np.int32)
-    ids[:, 0] = 1
-    ids[:, 35 if L > 40 else 2] = -200
-    loc = np.full((B,), (L - 3) - 1 + (P - 1), dtype=np.int32)
-    verify = np.stack([loc, loc + 1, loc + 2], axis=1).astype(np.int32)
+    # synthetic crop batch (vstar_amd.synthetic.bench_inputs: the same batch the full-depth reference golden was recorded on,
+    # tests/test_fulldepth_gpu.py), resident in HBM before the timed region
+    from vstar_amd.synthetic import bench_inputs
+    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T, rank)
+    clip, owl = clip.to(dev), owl.to(dev)
     nv = verify.shape[1]
     rec_dev = torch.empty((B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
     flags = _lib.F_DEVICE_INPUTS | _lib.F_DEVICE_OUTPUT | (_lib.F_SKIP_OWL if args.skip_owl else 0)

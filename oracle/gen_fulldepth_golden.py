@@ -1,0 +1,119 @@
+"""One-off FULL-DEPTH, REAL-WIDTH golden: the reference's own model_forward(inference=True) at the
+headline-bench geometry — CLIP-ViT-L/14@336 (23 blocks), LLaMA-7B (32 layers, S=640), OWL-ViT-B/16@768 (12 layers), SAM head —
+on crops of the EXACT batch bench.py scores (vstar_amd.synthetic.bench_inputs, B=32) with the bench's weights
+(random_state_dict(seed=0, bf16, share_layers=True), upcast to fp32 for the reference's fp32 run).
+
+TEST INFRASTRUCTURE.  Run once in the build container (needs /root/reference, ~45 GB RAM, ~6 min on 8 cores):
+    python -m oracle.gen_fulldepth_golden
+Writes tests/golden/full7b_336.npz (outputs only: fp32 reference + the reference in bf16 as the noise yardstick).
+The GPU test (tests/test_fulldepth_gpu.py) scores the whole 32-crop batch and compares the recorded crops: this is what pins
+error growth over 32+23+12 layers and arg-max / top-k stability at the bench shape.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import ref_shim  # noqa: E402
+from vstar_amd.config import VSMConfig  # noqa: E402
+from vstar_amd.synthetic import bench_inputs  # noqa: E402
+from vstar_amd.weights import random_state_dict  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "full7b_336.npz")
+CROPS = (0, 17)          # indices into the bench batch
+B, T = 32, 64
+
+
+def build_reference(cfg, loc_id, sd):
+    """7B random-init is slow and pointless (every used parameter is overwritten): build with the initialisers patched out."""
+    import torch.nn as nn
+    saved = {c: c.reset_parameters for c in (nn.Linear, nn.Embedding, nn.Conv2d, nn.LayerNorm)}
+    for c in saved:
+        c.reset_parameters = lambda self: None
+    inits = {n: getattr(nn.init, n) for n in ("normal_", "trunc_normal_", "uniform_", "kaiming_uniform_", "xavier_uniform_")}
+    for n in inits:
+        setattr(nn.init, n, lambda t, *a, **k: t)
+    try:
+        _, model = ref_shim.load_reference(cfg, loc_id)
+    finally:
+        for c, f in saved.items():
+            c.reset_parameters = f
+        for n, f in inits.items():
+            setattr(nn.init, n, f)
+    with torch.no_grad():                      # parameters the engine never reads (IoU head, masks 1-3, ...) -> finite values
+        for p in model.parameters():
+            if not torch.isfinite(p).all() or p.abs().max() > 1e3:
+                p.zero_()
+    missing = ref_shim.load_state(model, sd)
+    assert not missing, missing[:5]
+    return model
+
+
+def run(model, cfg, loc_id, clip, owl, ids, verify, dtype):
+    P = cfg.n_img_tokens
+    rec = {}
+    for ci in CROPS:
+        # fresh CLIP tower per call (transformers 5.x harness artefact, see gen_golden.py; verified to reproduce the tiny goldens)
+        from transformers import CLIPVisionModel
+        vt = model.get_model().get_vision_tower()
+        ccfg = vt.vision_tower.config
+        clip_sd = {k: v for k, v in vt.vision_tower.state_dict().items()}
+        vt.vision_tower = CLIPVisionModel(ccfg).eval().to(dtype)
+        vt.vision_tower.load_state_dict(clip_sd)
+        taps = {}
+        hooks = [
+            model.model.text_hidden_fcs_det[0].register_forward_hook(
+                lambda m, i, o: taps.update(hidden=i[0].detach().float().clone(), det=o.detach().float().clone())),
+            model.model.text_hidden_fcs_seg[0].register_forward_hook(lambda m, i, o: taps.update(seg=o.detach().float().clone())),
+            model.model.mask_decoder.output_hypernetworks_mlps[0].register_forward_hook(
+                lambda m, i, o: taps.update(hyper=o.detach().float().clone())),
+            model.model.mask_decoder.output_upscaling.register_forward_hook(lambda m, i, o: taps.update(up=o.detach().float().clone())),
+            model.lm_head.register_forward_hook(lambda m, i, o: taps.update(logits=o.detach()[0, torch.as_tensor(verify[ci]).long()].float().clone())),
+        ]
+        t0 = time.time()
+        out = ref_shim.reference_forward(model, clip[ci:ci + 1].to(dtype), owl[ci:ci + 1].to(dtype), torch.from_numpy(ids[ci:ci + 1].astype(np.int64)))
+        for h in hooks:
+            h.remove()
+        pos = int(np.where(ids[ci] == loc_id)[0][-1]) - 1 + (P - 1)
+        top2 = torch.topk(taps["logits"], 2, dim=-1)
+        r = {"pred_logits": out["pred_logits"][0, :, 0].float().numpy(), "pred_boxes": out["pred_boxes"][0].float().numpy(),
+             "low_res_masks": out["pred_masks"][0][0].float().numpy(), "llm_hidden_loc": taps["hidden"][0, pos].numpy(),
+             "embed_det": taps["det"][0, pos].numpy(), "embed_seg": taps["seg"][0, pos].numpy(),
+             "sam_hyper": taps["hyper"].reshape(-1).numpy(), "sam_upscaled_mean": taps["up"][0].double().mean(dim=(1, 2)).float().numpy(),
+             "tf_argmax": top2.indices[:, 0].numpy().astype(np.int32), "tf_top2_gap": (top2.values[:, 0] - top2.values[:, 1]).numpy(),
+             "tf_logit_spread": (taps["logits"].max(-1).values - taps["logits"].min(-1).values).numpy()}
+        print(f"  crop {ci} [{dtype}] {time.time() - t0:.1f}s  logits max {r['pred_logits'].max():.4f}", flush=True)
+        for k, v in r.items():
+            rec.setdefault(k, []).append(v)
+    return {k: np.stack(v) for k, v in rec.items()}
+
+
+def main():
+    assert ref_shim.available(), "reference tree not found"
+    torch.set_num_threads(len(os.sched_getaffinity(0)))
+    cfg = VSMConfig.seal_7b(336, max_batch=B, max_text_len=T + 1)
+    loc_id = cfg.llm_vocab - 1
+    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
+    t0 = time.time()
+    sd = {k: v.float() for k, v in random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True).items()}
+    model = build_reference(cfg, loc_id, sd)
+    del sd
+    print(f"reference built + loaded in {time.time() - t0:.0f}s", flush=True)
+    f32 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.float32)
+    model = model.bfloat16()
+    b16 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.bfloat16)
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))  # noqa: E731
+    print("reference-bf16 vs reference-fp32 rel-L2:", {k: "%.2e" % rel(b16[k], f32[k]) for k in f32 if k.startswith(("pred", "low", "llm", "embed", "sam"))})
+    np.savez_compressed(OUT, crops=np.asarray(CROPS), batch=B, text_tokens=T, weight_seed=0,
+                        **{k: v for k, v in f32.items()}, **{"bf16_" + k: v for k, v in b16.items()})
+    print("->", OUT, os.path.getsize(OUT) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -142,34 +142,7 @@ def test_allgather_records_world2_gloo(n_items):
 
 
 # ---- data-parallel VSM.inference_batch / visual_search over 2 ranks (gloo), with a deterministic fake engine ----
-class _FakeEngine:
-    """Stands in for VstarEngine on CPU: a record is a deterministic function of the crop's preprocessed pixels."""
-    device = 0
-
-    def __init__(self, max_batch=3):
-        from vstar_amd.config import VSMConfig
-        self.cfg = VSMConfig.tiny(max_batch=max_batch, max_text_len=96)
-        self.calls = []
-
-    def score_batch(self, clip, owl, ids, loc, verify_pos=None, skip_owl=False, sync=True, raw=False):
-        from vstar_amd import _lib
-        B = clip.shape[0]
-        self.calls.append(B)
-        rec = np.zeros((B, _lib.RESULT_FLOATS), np.float32)
-        for b in range(B):
-            seed = int(abs(float(clip[b].float().sum()) * 1000 + float(owl[b].float().sum()))) % (2 ** 31)
-            g = torch.Generator().manual_seed(seed)
-            rec[b, :2304] = (torch.randn(2304, generator=g) * 1.5 - 6).numpy()
-            rec[b, 2304:2304 * 5] = torch.rand(2304 * 4, generator=g).numpy()
-            low = torch.nn.functional.interpolate(torch.randn(1, 1, 12, 12, generator=g) * 9, (192, 192), mode="bilinear")
-            rec[b, 2304 * 5:2304 * 5 + 192 * 192] = low.reshape(-1).numpy()
-        return rec if raw else VstarEngine.unpack(rec, 0)
-
-    unpack = staticmethod(VstarEngine.unpack)
-
-    def upsample_mask(self, low, h, w):
-        t = torch.from_numpy(np.asarray(low, np.float32)).reshape(1, 1, 192, 192)
-        return torch.clamp(torch.nn.functional.interpolate(t, (h, w), mode="bilinear", align_corners=False), min=0)[0, 0].numpy()
+from _fake_vsm import FakeEngine as _FakeEngine  # noqa: E402
 
 
 def _search_once():
@@ -238,3 +211,51 @@ def test_bench_multiprocess_launch_path_on_cpu():
     assert d["ms_per_step"] >= 20.0          # rank 1 sleeps 20 ms per step: max over ranks, not rank 0's 10 ms
     for k in ("metric", "value", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
+
+
+def _make_bench_folder(root):
+    """A miniature V*Bench tree (two splits, image + JSON annotation with bbox / target_object lists, vstar_bench layout)."""
+    import json
+    from vstar_amd.synthetic import synthetic_image
+    k = 0
+    for split, sizes in (("direct_attributes", [(900, 600), (640, 480)]), ("relative_position", [(1000, 700)])):
+        d = os.path.join(root, split)
+        os.makedirs(d)
+        for j, (w, h) in enumerate(sizes):
+            synthetic_image(w, h, 50 + k).save(os.path.join(d, f"img{j}.jpg"))
+            targets = ["kite", "dog"] if split == "relative_position" else ["umbrella"]
+            json.dump({"target_object": targets, "bbox": [[10 + 5 * t, 20, 80, 60] for t in range(len(targets))],
+                       "question": "?", "options": ["a", "b"]}, open(os.path.join(d, f"img{j}.json"), "w"))
+            k += 1
+
+
+@pytest.mark.parametrize("shard", ["crops", "samples"])
+def test_visual_search_entry_point_under_torchrun_world2(tmp_path, shard):
+    """BASELINE configs 3/4 launch path: the REAL visual_search.py entry point under torch.distributed.run with two ranks
+    (gloo on CPU, engine stubbed through --vsm-factory; the VSM class, its crop sharding and the record all-gather are the real
+    ones): process group set up and torn down, rank 0 alone prints, and the metrics equal the single-process run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    folder = str(tmp_path / "bench")
+    _make_bench_folder(folder)
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root)
+    common = ["--benchmark-folder", folder, "--vsm-factory", "_fake_vsm:make", "--confidence_high", "2.0", "--confidence_low", "0.0",
+              "--target_cue_threshold", "-1", "--target_cue_threshold_minimum", "-1"]
+    single_json = str(tmp_path / "single.json")
+    out1 = subprocess.run([sys.executable, os.path.join(root, "visual_search.py"), *common, "--output_path", single_json],
+                          capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out1.returncode == 0, out1.stderr[-2000:]
+    port = _free_port()
+    multi_json = str(tmp_path / "multi.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "visual_search.py"), *common, "--shard", shard, "--output_path", multi_json]
+    out2 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out2.returncode == 0, out2.stderr[-2000:]
+    metric_lines = lambda text: [l for l in text.splitlines() if l.startswith(("Avg search path length", "Top 1 Acc"))]  # noqa: E731
+    assert len(metric_lines(out2.stdout)) == 2                       # rank 0 only
+    assert metric_lines(out2.stdout) == metric_lines(out1.stdout)
+    a, b = json.load(open(single_json)), json.load(open(multi_json))
+    assert b["world_size"] == 2 and b["shard"] == shard
+    assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"] and len(a["hits"]) == 4

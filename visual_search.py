@@ -4,7 +4,16 @@ driven by the HIP engine: `VSM` from vstar_amd.vsm, batched `visual_search` from
 
   python visual_search.py --version /path/to/seal_vsm_7b --vision-tower /path/to/clip-vit-large-patch14 \
          --benchmark-folder vstar_bench
-Extra (additive) flags: --device, --batch, --synthetic-seed (random weights when no checkpoint is staged).
+Extra (additive) flags: --device, --batch, --synthetic-seed (random weights when no checkpoint is staged), --shard.
+
+Multi-GPU (BASELINE configs 3/4): launch with torchrun, one process per GPU —
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 visual_search.py ...
+--shard crops   (default; the north-star layout): every rank walks the same samples; each engine step's crop batch is dealt
+                round-robin over the ranks and the fixed-size records are all-gathered over RCCL, so every rank takes the same
+                next-step decision.
+--shard samples : (image, target) pairs are dealt round-robin over the ranks, each search runs on one GPU, the per-sample
+                metrics are gathered at the end (no collective on the data path).
+Rank 0 prints the metrics, which are identical to a single-process run in both modes.
 """
 from __future__ import annotations
 
@@ -17,8 +26,8 @@ import numpy as np
 from PIL import Image
 
 from vstar_amd.config import VSMConfig
+from vstar_amd.dist import finalize, gather_objects, init_from_env
 from vstar_amd.search import iou, smallest_size_for, visual_search
-from vstar_amd.vsm import VSM
 
 SPLITS = ("direct_attributes", "relative_position")
 
@@ -44,6 +53,9 @@ def parse_args(argv):
     p.add_argument("--device", default=0, type=int)
     p.add_argument("--batch", default=32, type=int, help="crops per engine pass")
     p.add_argument("--synthetic-seed", default=None, type=int)
+    p.add_argument("--shard", default="crops", choices=["crops", "samples"], help="what is dealt over the ranks under torchrun")
+    p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) returning an object with the VSM interface "
+                   "(tests substitute a CPU stand-in for the engine)")
     return p.parse_args(argv)
 
 
@@ -58,31 +70,53 @@ def iter_samples(folder):
                 yield split, os.path.join(d, name), gt_bbox, target
 
 
+def make_vsm(args, device):
+    if args.vsm_factory:
+        import importlib
+        mod, fn = args.vsm_factory.split(":")
+        return getattr(importlib.import_module(mod), fn)(args, device)
+    from vstar_amd.vsm import VSM
+    return VSM(args, cfg=VSMConfig.seal_7b(224, max_batch=args.batch), device=device, synthetic_seed=args.synthetic_seed)
+
+
 def main(argv):
     args = parse_args(argv)
     if args.visualization:
         raise SystemExit("--visualization (cv2/matplotlib rendering) is out of scope of this engine")
-    vsm = VSM(args, cfg=VSMConfig.seal_7b(224, max_batch=args.batch), device=args.device, synthetic_seed=args.synthetic_seed)
-    hits, lengths = [], []
-    for _, path, gt_bbox, target in iter_samples(args.benchmark_folder):
-        image = Image.open(path).convert("RGB")
-        smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
-        step, n_steps, ok, _ = visual_search(
-            vsm, image, target, target_bbox=gt_bbox, smallest_size=smallest, confidence_high=args.confidence_high,
-            confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
-            target_cue_threshold_decay=args.target_cue_threshold_decay,
-            target_cue_threshold_minimum=args.target_cue_threshold_minimum)
-        if not ok:
-            hits.append(0)
-            lengths.append(0)
-            continue
-        box = step["detection_result"]
-        box[0] += step["bbox"][0]
-        box[1] += step["bbox"][1]
-        hits.append(1.0 if iou(box, gt_bbox).item() > 0.5 else 0.0)
-        lengths.append(n_steps)
-    print("Avg search path length:", np.mean([n for n, h in zip(lengths, hits) if h]))
-    print("Top 1 Acc:", np.mean(hits))
+    world, rank, local_rank = init_from_env()
+    try:
+        vsm = make_vsm(args, local_rank if world > 1 else args.device)
+        if args.shard == "samples":
+            vsm.shard_crops = False                      # each search stays on its own GPU
+        results = []                                     # (sample index, hit, path length)
+        for i, (_, path, gt_bbox, target) in enumerate(iter_samples(args.benchmark_folder)):
+            if args.shard == "samples" and i % world != rank:
+                continue
+            image = Image.open(path).convert("RGB")
+            smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
+            step, n_steps, ok, _ = visual_search(
+                vsm, image, target, target_bbox=gt_bbox, smallest_size=smallest, confidence_high=args.confidence_high,
+                confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
+                target_cue_threshold_decay=args.target_cue_threshold_decay,
+                target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+            if not ok:
+                results.append((i, 0.0, 0))
+                continue
+            box = step["detection_result"]
+            box[0] += step["bbox"][0]
+            box[1] += step["bbox"][1]
+            results.append((i, 1.0 if iou(box, gt_bbox).item() > 0.5 else 0.0, n_steps))
+        if args.shard == "samples":
+            results = sorted(r for part in gather_objects(results, world) for r in part)
+        if rank == 0:
+            hits, lengths = [r[1] for r in results], [r[2] for r in results]
+            print("Avg search path length:", np.mean([n for n, h in zip(lengths, hits) if h]))
+            print("Top 1 Acc:", np.mean(hits))
+            if args.output_path:
+                json.dump({"world_size": world, "shard": args.shard, "hits": hits, "path_lengths": lengths},
+                          open(args.output_path, "w"))
+    finally:
+        finalize()
 
 
 if __name__ == "__main__":

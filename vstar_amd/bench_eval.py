@@ -68,17 +68,31 @@ def focus_question(question, found, image, pad_left, pad_top):
     return FOCUS_MSG + "; ".join(parts) + ".\n" + question
 
 
-def eval_model(args, vqa_llm, vsm=None):
+def make_vsm(args, device: int = 0):
+    """The VSM of the evaluation loop (vstar_bench_eval.py:171-177).  `--vision-tower` must name a LOCAL
+    openai/clip-vit-large-patch14 directory: the CLIP tower is not part of the VSM checkpoint and there is no hub access."""
+    tower = getattr(args, "vision_tower", None) or "openai/clip-vit-large-patch14"
+    if os.path.isdir(str(args.vsm_model_path)) and not os.path.isdir(str(tower)):
+        raise FileNotFoundError(
+            f"--vision-tower {tower!r} is not a local directory: stage openai/clip-vit-large-patch14 next to the VSM checkpoint and "
+            "pass its path (the reference downloads it from the hub, visual_search.py:157-161; this environment has no network)")
+    vsm_args = SimpleNamespace(version=args.vsm_model_path, vision_tower=tower, conv_type="llava_v1", use_mm_start_end=True,
+                               model_max_length=512)
+    return VSM(vsm_args, cfg=VSMConfig.seal_7b(224), device=device)
+
+
+def eval_model(args, vqa_llm, vsm=None, world: int = 1, rank: int = 0):
+    """world/rank: under torchrun (vstar_bench_eval.py) the VQA-LLM work is replicated on every rank (deterministic, so all
+    ranks agree) and every visual-search engine step is crop-sharded over the ranks with the record all-gather (SURVEY §8e);
+    rank 0 prints and writes the results."""
     if vsm is None:
-        vsm_args = SimpleNamespace(version=args.vsm_model_path, vision_tower="openai/clip-vit-large-patch14",
-                                   conv_type="llava_v1", use_mm_start_end=True, model_max_length=512)
-        vsm = VSM(vsm_args, cfg=VSMConfig.seal_7b(224))
+        vsm = make_vsm(args)
     mean_color = tuple(int(x * 255) for x in vqa_llm.image_processor.image_mean)
     results, per_type, everything = {}, defaultdict(list), []
     for split in ("direct_attributes", "relative_position"):
         results[split] = []
         folder = os.path.join(args.benchmark_folder, split)
-        for image_file in [f for f in os.listdir(folder) if ".json" not in f]:
+        for image_file in sorted(f for f in os.listdir(folder) if ".json" not in f):
             path = os.path.join(folder, image_file)
             ann = json.load(open(path.split(".")[0] + ".json"))
             question, options = ann["question"], ann["options"]
@@ -101,8 +115,10 @@ def eval_model(args, vqa_llm, vsm=None):
             results[split].append({"question": question, "options": options, "image": image_file,
                                    "prediction_freeform": prediction, "missing_objects": missing, "search_result": found,
                                    "option_chosen": chosen, "correct": correct})
-        print(split, np.mean(per_type[split]))
-    print(np.mean(everything))
-    with open(args.output_path, "w") as f:
-        json.dump(results, f, indent=4)
+        if rank == 0:
+            print(split, np.mean(per_type[split]))
+    if rank == 0:
+        print(np.mean(everything))
+        with open(args.output_path, "w") as f:
+            json.dump(results, f, indent=4)
     return results

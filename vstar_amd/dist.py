@@ -40,3 +40,39 @@ def allgather_records(local: torch.Tensor, n_items: int, group=None) -> torch.Te
 def allgather_numpy(local: np.ndarray, n_items: int, device: str = "cpu") -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(local)).to(device)
     return allgather_records(t, n_items).cpu().numpy()
+
+
+# ---------------- process-group lifecycle of the entry points (visual_search.py, vstar_bench_eval.py, bench.py) ----------------
+def init_from_env(backend: str | None = None):
+    """Joins the process group described by the torchrun / torch.distributed.run environment (RANK, WORLD_SIZE, LOCAL_RANK,
+    MASTER_ADDR, MASTER_PORT).  Returns (world, rank, local_rank); a plain `python script.py` launch (no WORLD_SIZE, or 1) is
+    world 1 and creates no group.  Backend: "nccl" (= RCCL over xGMI) when a GPU is visible, else "gloo"."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return world, rank, local_rank
+
+
+def finalize() -> None:
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def gather_objects(obj, world: int):
+    """Every rank's `obj`, in rank order, on every rank (sample-level data parallelism: per-rank metric lists)."""
+    if world == 1:
+        return [obj]
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out

@@ -81,9 +81,11 @@ class VstarEngine:
 
     # ---- the hot path ----
     def score_batch(self, clip_pix, owl_pix, input_ids, loc_pos, verify_pos=None, skip_owl: bool = False,
-                    sync: bool = True, raw: bool = False):
+                    sync: bool = True, raw: bool = False, out_dev: Optional[torch.Tensor] = None):
         """clip_pix [B,3,I,I], owl_pix [B,3,768,768] (bf16-castable; CPU or cuda tensors), input_ids [B,L] with one -200,
-        loc_pos [B] spliced-sequence index of the hidden state that predicts [LOC]; verify_pos [B,V] optional."""
+        loc_pos [B] spliced-sequence index of the hidden state that predicts [LOC]; verify_pos [B,V] optional.
+        out_dev: a contiguous float32 cuda tensor [B, RESULT_FLOATS] — the records stay in HBM (VSTAR_F_DEVICE_OUTPUT: what the
+        multi-GPU path all-gathers over RCCL without a host bounce); the call then returns None."""
         cfg = self.cfg
         clip_pix = _as_bf16(clip_pix)
         B = clip_pix.shape[0]
@@ -112,15 +114,25 @@ class VstarEngine:
             nv = vp.shape[1]
             assert nv <= MAX_VERIFY
             vptr = vp.ctypes.data_as(ctypes.c_void_p)
-        out = np.empty((B, _lib.RESULT_FLOATS), dtype=np.float32)
+        out, out_ptr = self._out_buffer(B, out_dev)
+        if out_dev is not None:
+            flags |= _lib.F_DEVICE_OUTPUT
         self._keep = (clip_pix, owl_pix, ids, loc, out)  # keep alive for no-sync calls
         _lib.check(self.lib.vstar_vsm_score_batch(
             self.handle, B, ctypes.c_void_p(clip_pix.data_ptr()), owl_ptr, ids.ctypes.data_as(ctypes.c_void_p),
-            ids.shape[1], loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out.ctypes.data_as(ctypes.c_void_p)),
-            self.handle)
-        if not sync:
+            ids.shape[1], loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out_ptr), self.handle)
+        if not sync or out_dev is not None:
             return None
         return out if raw else self.unpack(out, nv)
+
+    @staticmethod
+    def _out_buffer(B: int, out_dev: Optional[torch.Tensor]):
+        if out_dev is None:
+            out = np.empty((B, _lib.RESULT_FLOATS), dtype=np.float32)
+            return out, out.ctypes.data_as(ctypes.c_void_p)
+        assert out_dev.is_cuda and out_dev.dtype == torch.float32 and out_dev.is_contiguous(), "out_dev: contiguous fp32 cuda tensor"
+        assert tuple(out_dev.shape) == (B, _lib.RESULT_FLOATS), out_dev.shape
+        return out_dev, ctypes.c_void_p(out_dev.data_ptr())
 
     # ---- GPU-side preprocessing ----
     def set_image(self, image) -> None:
@@ -131,9 +143,10 @@ class VstarEngine:
         _lib.check(self.lib.vstar_image_set(self.handle, arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
                    self.handle)
 
-    def score_boxes(self, boxes_xyxy, input_ids, loc_pos, verify_pos=None, raw: bool = False):
+    def score_boxes(self, boxes_xyxy, input_ids, loc_pos, verify_pos=None, raw: bool = False,
+                    out_dev: Optional[torch.Tensor] = None):
         """Crop + pad + PIL-exact resize + normalise on the GPU for `boxes_xyxy` [B,4] (ints, as passed to image.crop),
-        then the same scoring pass as `score_batch`."""
+        then the same scoring pass as `score_batch` (out_dev: see there)."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
         B = boxes.shape[0]
         _lib.check(self.lib.vstar_preprocess_crops(self.handle, B, boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
@@ -144,11 +157,13 @@ class VstarEngine:
             vp = np.ascontiguousarray(np.asarray(verify_pos, dtype=np.int32)).reshape(B, -1)
             nv = vp.shape[1]
             vptr = vp.ctypes.data_as(ctypes.c_void_p)
-        out = np.empty((B, _lib.RESULT_FLOATS), dtype=np.float32)
+        out, out_ptr = self._out_buffer(B, out_dev)
+        flags = _lib.F_INTERNAL_PIXELS | (_lib.F_DEVICE_OUTPUT if out_dev is not None else 0)
         _lib.check(self.lib.vstar_vsm_score_batch(
             self.handle, B, None, None, ids.ctypes.data_as(ctypes.c_void_p), ids.shape[1],
-            loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, _lib.F_INTERNAL_PIXELS, out.ctypes.data_as(ctypes.c_void_p)),
-            self.handle)
+            loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out_ptr), self.handle)
+        if out_dev is not None:
+            return None
         return out if raw else self.unpack(out, nv)
 
     def preprocess_only(self, boxes_xyxy):

@@ -26,7 +26,7 @@ from PIL import Image
 
 from ._lib import RESULT_FLOATS
 from .config import VSMConfig
-from .dist import allgather_numpy, pad_count, shard_indices
+from .dist import allgather_numpy, allgather_records, pad_count, shard_indices
 from .engine import VstarEngine
 from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, SyntheticTokenizer, build_prompt, clip_preprocess,
                          owl_preprocess, tokenizer_image_token)
@@ -95,17 +95,48 @@ class VSM:
         self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0}
 
     # ---- multi-GPU plumbing ----
-    @staticmethod
-    def _dist():
+    shard_crops = True      # False: this process scores every crop itself even when a process group exists (sample-level DP)
+
+    def _dist(self):
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized():
+        if self.shard_crops and dist.is_available() and dist.is_initialized():
             return dist.get_world_size(), dist.get_rank()
         return 1, 0
 
-    def _allgather(self, local: np.ndarray, n_items: int) -> np.ndarray:
+    def _score_sharded(self, n: int, score_chunk) -> np.ndarray:
+        """Data-parallel scoring of n crops: crop i belongs to rank i % world; `score_chunk(sel, out_dev)` scores
+        the crops `sel` of this rank (returning [len(sel), R] host records, or writing them into the device tensor `out_dev`).
+        With the nccl backend (= RCCL over xGMI) the fixed-size records never leave HBM before the exchange: the engine writes
+        them into a device buffer (VSTAR_F_DEVICE_OUTPUT), ONE all_gather_into_tensor moves them, and a single D2H copy of the
+        gathered set follows.  gloo (CPU tests) and the single-process case use host records."""
         import torch.distributed as dist
-        dev = f"cuda:{self.engine.device}" if dist.get_backend() == "nccl" else "cpu"
-        return allgather_numpy(local, n_items, device=dev)
+        world, rank = self._dist()
+        mine = shard_indices(n, rank, world)
+        per = pad_count(n, world)
+        mb = self.cfg.max_batch
+        on_device = world > 1 and dist.get_backend() == "nccl"
+        if on_device:
+            local = torch.zeros((per, RESULT_FLOATS), dtype=torch.float32, device=f"cuda:{self.engine.device}")
+        else:
+            local = np.zeros((per, RESULT_FLOATS), dtype=np.float32)
+        for s0 in range(0, len(mine), mb):
+            sel = mine[s0:s0 + mb]
+            t1 = time.perf_counter()
+            if on_device:
+                score_chunk(sel, local[s0:s0 + len(sel)])
+            else:
+                local[s0:s0 + len(sel)] = score_chunk(sel, None)
+            self.timers["engine_s"] += time.perf_counter() - t1
+            self.timers["crops"] += len(sel)
+        t2 = time.perf_counter()
+        if world == 1:
+            records = local[:n]
+        elif on_device:
+            records = allgather_records(local, n).cpu().numpy()
+        else:
+            records = allgather_numpy(local, n, device="cpu")
+        self.timers["gather_s"] += time.perf_counter() - t2
+        return records
 
     # ---- prompt -> ids with the answer teacher-forced ----
     def _ids(self, question: str) -> Tuple[np.ndarray, int, List[int], List[int]]:
@@ -141,31 +172,22 @@ class VSM:
         ids, loc_pos, ver_pos, ver_tok = self._ids(question)
         nv = min(len(ver_pos), 8)
         ver_pos, ver_tok = ver_pos[-nv:], ver_tok[-nv:]
-        # ---- data-parallel sharding: crop i is scored by rank i % world; the fixed-size records are
-        # all-gathered (RCCL over xGMI with the nccl backend) so that every rank continues with identical results ----
-        world, rank = self._dist()
         n = len(images)
-        mine = shard_indices(n, rank, world)
-        per = pad_count(n, world)
-        local = np.zeros((per, RESULT_FLOATS), dtype=np.float32)
-        mb = self.cfg.max_batch
-        for s0 in range(0, len(mine), mb):
-            sel = mine[s0:s0 + mb]
+        ids_b = lambda B: np.tile(ids[None], (B, 1))  # noqa: E731
+
+        def score_chunk(sel, out_dev):
             chunk = [images[i] for i in sel]
             B = len(chunk)
             t0 = time.perf_counter()
             clip = torch.from_numpy(np.stack([clip_preprocess(im, self.cfg.clip_image_size) for im in chunk])).bfloat16()
             owl = torch.from_numpy(np.stack([owl_preprocess(im, self.cfg.owl_image_size) for im in chunk])).bfloat16()
-            t1 = time.perf_counter()
-            local[s0:s0 + B] = self.engine.score_batch(
-                clip, owl, np.tile(ids[None], (B, 1)), np.full((B,), loc_pos, np.int32),
-                verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True)
-            self.timers["preprocess_s"] += t1 - t0
-            self.timers["engine_s"] += time.perf_counter() - t1
-            self.timers["crops"] += B
-        t2 = time.perf_counter()
-        records = self._allgather(local, n) if world > 1 else local[:n]
-        self.timers["gather_s"] += time.perf_counter() - t2
+            dt = time.perf_counter() - t0
+            self.timers["preprocess_s"] += dt
+            self.timers["engine_s"] -= dt               # _score_sharded times the whole chunk as engine time
+            kw = {"out_dev": out_dev} if out_dev is not None else {}
+            return self.engine.score_batch(clip, owl, ids_b(B), np.full((B,), loc_pos, np.int32),
+                                           verify_pos=np.tile(np.asarray(ver_pos, np.int32)[None], (B, 1)), raw=True, **kw)
+        records = self._score_sharded(n, score_chunk)
         res = self.engine.unpack(records, nv)
         ok_all = [(res["tf_argmax"] == np.asarray(ver_tok, np.int32)[None]).all(axis=1)] if n else []
         out: List = []
@@ -221,21 +243,12 @@ class VSM:
             ver_rows[i] = ver_pos[-nv:]
             tok_rows[i] = ver_tok[-nv:]
         xyxy = np.asarray([[int(b[0]), int(b[1]), int(b[0] + b[2]), int(b[1] + b[3])] for b in boxes_xywh], np.int32)
-        world, rank = self._dist()
         n = len(xyxy)
-        mine = shard_indices(n, rank, world)
-        local = np.zeros((pad_count(n, world), RESULT_FLOATS), dtype=np.float32)
-        mb = self.cfg.max_batch
-        for s0 in range(0, len(mine), mb):
-            sel = mine[s0:s0 + mb]
-            B = len(sel)
-            t1 = time.perf_counter()
-            local[s0:s0 + B] = self.engine.score_boxes(xyxy[sel], ids_rows[sel], loc_rows[sel], verify_pos=ver_rows[sel], raw=True)
-            self.timers["engine_s"] += time.perf_counter() - t1
-            self.timers["crops"] += B
-        t2 = time.perf_counter()
-        records = self._allgather(local, n) if world > 1 else local[:n]
-        self.timers["gather_s"] += time.perf_counter() - t2
+
+        def score_chunk(sel, out_dev):
+            kw = {"out_dev": out_dev} if out_dev is not None else {}
+            return self.engine.score_boxes(xyxy[sel], ids_rows[sel], loc_rows[sel], verify_pos=ver_rows[sel], raw=True, **kw)
+        records = self._score_sharded(n, score_chunk)
         res = self.engine.unpack(records, nv)
         self.last_template_ok = (res["tf_argmax"] == tok_rows).all(axis=1)
         out: List = []

@@ -23,19 +23,37 @@ def parse_args(argv):
     p.add_argument("--minimum_size", default=224, type=int)
     p.add_argument("--vision-tower", dest="vision_tower", default=None, help="local openai/clip-vit-large-patch14 directory")
     p.add_argument("--vqa-llm", default=None, help="module:factory providing another VQA-LLM implementation")
+    p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) providing another VSM implementation")
+    p.add_argument("--device", default=0, type=int)
     return p.parse_args(argv)
 
 
 def main(argv):
+    """Single process: `python vstar_bench_eval.py ...`.  One node, N GPUs (BASELINE configs 3/4):
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 vstar_bench_eval.py ...` — one process
+    per GPU, weights replicated, each visual-search engine step crop-sharded with an RCCL all-gather of the records."""
     args = parse_args(argv)
-    if args.vqa_llm:
-        mod, fn = args.vqa_llm.split(":")
-        vqa_llm = getattr(importlib.import_module(mod), fn)(args)
-    else:
-        from vstar_amd.vqa import VQA_LLM
-        vqa_llm = VQA_LLM(args)
-    from vstar_amd.bench_eval import eval_model
-    eval_model(args, vqa_llm)
+    from vstar_amd.dist import finalize, init_from_env
+    world, rank, local_rank = init_from_env()
+    try:
+        if world > 1:
+            args.device = local_rank
+        if args.vqa_llm:
+            mod, fn = args.vqa_llm.split(":")
+            vqa_llm = getattr(importlib.import_module(mod), fn)(args)
+        else:
+            from vstar_amd.vqa import VQA_LLM
+            vqa_llm = VQA_LLM(args, device=local_rank if world > 1 else args.device)
+        from vstar_amd.bench_eval import eval_model, make_vsm
+        vsm = None
+        if args.vsm_factory:
+            mod, fn = args.vsm_factory.split(":")
+            vsm = getattr(importlib.import_module(mod), fn)(args, local_rank)
+        elif world > 1:
+            vsm = make_vsm(args, local_rank)
+        eval_model(args, vqa_llm, vsm, world=world, rank=rank)
+    finally:
+        finalize()
 
 
 if __name__ == "__main__":
