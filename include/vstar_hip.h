@@ -155,6 +155,9 @@ int vstar_vsm_generate(vstar_handle* h, const uint16_t* clip_pix_bf16, const int
 /* Bilinear (align_corners=False) upsample of a 192x192 low-res mask to h_out x w_out fp32, then clamp(min=0).
  * Replaces F.interpolate(...) + torch.clamp (VSM.py:534-537, visual_search.py:223-224). Host in, host out. */
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out);
+/* Same with the clamp optional (clamp_min0 = 0: the bare F.interpolate of VSM.py:534-536, which is what the model-level
+ * VSMForCausalLM.inference returns — the clamp belongs to its caller, visual_search.py:211,223). */
+int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int w_out, int clamp_min0, float* out);
 
 /* Decision statistics of a heat map without materialising it: with H = clamp(bilinear(lowres 192x192 ->
  * h_out x w_out, align_corners=False), 0) writes out[0] = min H, out[1] = max H, out[2] = sum H, out[3+k] = sum of H over

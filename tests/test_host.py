@@ -259,3 +259,63 @@ def test_visual_search_entry_point_under_torchrun_world2(tmp_path, shard):
     a, b = json.load(open(single_json)), json.load(open(multi_json))
     assert b["world_size"] == 2 and b["shard"] == shard
     assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"] and len(a["hits"]) == 4
+
+
+def test_scores_keep_the_references_bf16_sigmoid_ties():
+    """visual_search.py:225 returns det_result['pred_logits'][0].sigmoid() of a BF16 tensor: the rounding makes distinct logits
+    tie, and the scheduler's argmax() (first maximum) / `> confidence` comparisons act on the rounded values.  The drop-in keeps
+    that dtype so that the selected box is the reference's even among near-equal detections."""
+    from vstar_amd.vsm import _scores
+    logits = np.asarray([[1.0], [3.015625], [3.03125], [2.0]], np.float32)       # bf16-representable, as the engine emits them
+    s = _scores(logits)
+    assert s.dtype == torch.bfloat16 and s.shape == (4, 1)
+    assert float(s[1]) == float(s[2]) == 0.953125                                 # a tie after rounding ...
+    assert int(s.view(-1).argmax()) == 1                                          # ... resolved like the reference: first maximum
+    assert int(torch.from_numpy(logits).sigmoid().view(-1).argmax()) == 2         # fp32 scores would have picked the other box
+    # threshold semantics on rounded values: sigmoid(0.002) = 0.5005 rounds to 0.5 and is NOT > 0.5
+    assert not bool(_scores(np.asarray([0.002], np.float32))[0] > 0.5)
+
+
+def test_vsm_checkpoint_dir_roundtrip(tmp_path):
+    """A HF `save_pretrained`-layout VSM directory (two safetensors shards; a stray vision tower copy and non-engine keys inside,
+    as in craigwu/seal_vsm_7b) + a separate CLIP directory (openai/clip-vit-large-patch14: vision_model.* next to text_model.*)
+    -> the engine's key space, tensor for tensor (vstar_amd.weights.load_checkpoint_dir; visual_search.py:157-161)."""
+    from safetensors.torch import save_file
+    from vstar_amd.config import VSMConfig
+    from vstar_amd.weights import load_checkpoint_dir, random_state_dict, state_dict_spec
+    cfg = VSMConfig.tiny()
+    sd = random_state_dict(cfg, seed=3, dtype=torch.bfloat16)
+    vsm_dir, clip_dir = tmp_path / "seal_vsm", tmp_path / "clip"
+    vsm_dir.mkdir()
+    clip_dir.mkdir()
+    own = {k: v for k, v in sd.items() if not k.startswith("clip.")}
+    keys = sorted(own)
+    half = len(keys) // 2
+    shard_a = {k: own[k] for k in keys[:half]}
+    shard_b = {k: own[k] for k in keys[half:]}
+    shard_b["model.vision_tower.vision_tower.vision_model.embeddings.class_embedding"] = torch.zeros(4)   # ignored copy
+    shard_b["model.owlvit.text_model.embeddings.token_embedding.weight"] = torch.zeros(2, 2)              # not on the path
+    save_file(shard_a, str(vsm_dir / "model-00001-of-00002.safetensors"))
+    save_file(shard_b, str(vsm_dir / "model-00002-of-00002.safetensors"))
+    clip = {k[len("clip."):]: v for k, v in sd.items() if k.startswith("clip.")}
+    clip["text_model.embeddings.token_embedding.weight"] = torch.zeros(2, 2)
+    clip["visual_projection.weight"] = torch.zeros(2, 2)
+    torch.save(clip, str(clip_dir / "pytorch_model.bin"))                                                 # .bin shard form
+    got = load_checkpoint_dir(str(vsm_dir), str(clip_dir))
+    for k in state_dict_spec(cfg):
+        assert k in got, k
+        assert torch.equal(got[k], sd[k]), k
+    assert not any(".vision_tower." in k for k in got)
+    with pytest.raises(FileNotFoundError):
+        load_checkpoint_dir(str(vsm_dir), str(tmp_path / "missing"))
+
+
+def test_bench_eval_vsm_factory_requires_a_local_vision_tower(tmp_path):
+    """Round-1 advisor finding: eval_model hard-coded the hub name of the CLIP tower; with a real checkpoint directory that ended
+    in an os.listdir FileNotFoundError deep in the loader.  Now --vision-tower is honoured and its absence is reported clearly."""
+    import types
+    from vstar_amd.bench_eval import make_vsm
+    (tmp_path / "vsm").mkdir()
+    args = types.SimpleNamespace(vsm_model_path=str(tmp_path / "vsm"), vision_tower=None)
+    with pytest.raises(FileNotFoundError, match="--vision-tower"):
+        make_vsm(args)

@@ -95,7 +95,8 @@ def test_other_wording_falls_back_to_stepwise_decode(cuda):
     owl = torch.from_numpy(pp.owl_preprocess(img, 768)).bfloat16()[None]
     direct = vsm.engine.score_batch(clip, owl, ids[None], np.asarray([loc_pos], np.int32))
     assert np.array_equal(boxes.numpy(), direct["pred_boxes"][0])
-    assert np.array_equal(scores.numpy(), torch.from_numpy(direct["pred_logits"][0]).sigmoid().numpy())
+    assert scores.dtype == torch.bfloat16          # the reference's dtype: ties / thresholds act on bf16-rounded sigmoids
+    assert torch.equal(scores, torch.from_numpy(direct["pred_logits"][0]).bfloat16().sigmoid())
     assert np.array_equal(heat.numpy(), vsm.engine.upsample_mask(direct["low_res_masks"][0, 0], 300, 400))
     ref = vsm_oracle.vsm_forward({k: v.float() for k, v in sd.items()}, CFG, clip.float(), owl.float(),
                                  torch.from_numpy(ids.astype(np.int64))[None], LOC)

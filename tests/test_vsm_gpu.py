@@ -43,6 +43,7 @@ def test_inference_conventions_and_oracle(vsm):
         seg = vsm.inference(img, q, mode="segmentation")
     assert boxes.shape == (2304, 4) and scores.shape == (2304, 1) and heat.shape == (300, 500)
     assert heat.dtype == torch.float32 and float(heat.min()) >= 0 and 0 < float(scores.min()) and float(scores.max()) < 1
+    assert scores.dtype == torch.bfloat16 and boxes.dtype == torch.float32
     assert torch.equal(seg, heat)
     # oracle on the identical preprocessed tensors / ids
     cfg = vsm.cfg
@@ -57,8 +58,8 @@ def test_inference_conventions_and_oracle(vsm):
     from _parity import assert_mask_within_bf16_noise, assert_within_bf16_noise
     sd16 = random_state_dict(cfg, seed=5, dtype=torch.bfloat16)
     r16 = vsm_oracle.vsm_forward(sd16, cfg, clip, owl, torch.from_numpy(ids.astype(np.int64))[None], vsm.loc_token_idx)
-    assert_within_bf16_noise("scores", scores.numpy(), torch.sigmoid(ref["pred_logits"][0]).numpy(),
-                             torch.sigmoid(r16["pred_logits"][0].float()).numpy())
+    assert_within_bf16_noise("scores", scores.float().numpy(), torch.sigmoid(ref["pred_logits"][0]).numpy(),
+                             torch.sigmoid(r16["pred_logits"][0]).float().numpy())
     low = vsm.inference_batch([img], q, mode="segmentation", upsample=False)[0].numpy()
     assert_mask_within_bf16_noise(low, ref["low_res_masks"][0, 0].numpy(), r16["low_res_masks"][0, 0].float().numpy(),
                                   ref["sam_taps"]["sam_hyper"].numpy(), r16["sam_taps"]["sam_hyper"].float().numpy(),

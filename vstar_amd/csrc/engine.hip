@@ -758,6 +758,10 @@ int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_o
 }
 
 int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_out, float* out) {
+  return vstar_upsample_mask_ex(h, lowres, h_out, w_out, 1, out);
+}
+
+int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int w_out, int clamp_min0, float* out) {
   if (!h || !lowres || !out || h_out <= 0 || w_out <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
   float *din = nullptr, *dout = nullptr;
@@ -769,7 +773,7 @@ int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_o
   }
   int rc = VSTAR_OK;
   if (hipMemcpyAsync(din, lowres, nin * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-      resize_bilinear_clamp(din, VSTAR_MASK_RES, VSTAR_MASK_RES, dout, h_out, w_out, h->stream) != hipSuccess ||
+      resize_bilinear_clamp(din, VSTAR_MASK_RES, VSTAR_MASK_RES, dout, h_out, w_out, h->stream, clamp_min0) != hipSuccess ||
       hipMemcpyAsync(out, dout, nout * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess) {
     h->set_error("vstar_upsample_mask: HIP failure");

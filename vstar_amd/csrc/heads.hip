@@ -118,7 +118,7 @@ __global__ void hyper_mask_kernel(const lp_t* __restrict__ hyper, const lp_t* __
 
 // F.interpolate(low_res.float(), (h, w), "bilinear", align_corners=False) + clamp(min=0)  (VSM.py:534-537, visual_search.py:223-224)
 __global__ void resize_bilinear_kernel(const float* __restrict__ in, int hin, int win, float* __restrict__ out, int hout,
-                                       int wout, float rh, float rw) {
+                                       int wout, float rh, float rw, int clamp_min0) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)hout * wout) return;
   const int x = (int)(idx % wout), y = (int)(idx / wout);
@@ -128,7 +128,7 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, int hin, in
   const float ly = sy - y0, lx = sx - x0;
   const float t = (1.f - ly) * ((1.f - lx) * in[y0 * win + x0] + lx * in[y0 * win + x1]) +
                   ly * ((1.f - lx) * in[y1 * win + x0] + lx * in[y1 * win + x1]);
-  out[idx] = fmaxf(t, 0.f);
+  out[idx] = clamp_min0 ? fmaxf(t, 0.f) : t;
 }
 
 // Decision statistics of one heat map WITHOUT materialising it (visual_search.py:255-275,420-426):
@@ -232,9 +232,9 @@ hipError_t hyper_mask(const lp_t* hyper, const lp_t* up, float* out, int out_str
                      out_stride_crop, B, npix);
   return hipGetLastError();
 }
-hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s) {
+hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s, int clamp_min0) {
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nblk((int64_t)hout * wout)), dim3(256), 0, s, in, hin, win, out, hout,
-                     wout, (float)hin / (float)hout, (float)win / (float)wout);
+                     wout, (float)hin / (float)hout, (float)win / (float)wout, clamp_min0);
   return hipGetLastError();
 }
 

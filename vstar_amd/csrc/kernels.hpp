@@ -117,8 +117,8 @@ hipError_t upsample2x_im2col3x3(const lp_t* src, lp_t* A, int B, int h, int w, i
 // masks[b, pix] = sum_c hyper[b,c] * up[b,pix,c]  (bf16 in, fp32 accumulate, bf16-rounded like the reference matmul) -> fp32
 hipError_t hyper_mask(const lp_t* hyper, const lp_t* up, float* out, int out_stride_crop, int B, int npix, int C,
                       hipStream_t s);
-// bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0)
-hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s);
+// bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0) unless clamp_min0 == 0
+hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s, int clamp_min0 = 1);
 
 // min / max / total / rectangle sums of clamp(bilinear(lowres -> hout x wout), 0); out = double[3 + 8], mm_scratch = unsigned[2]
 hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,

@@ -186,12 +186,12 @@ class VstarEngine:
             "tf_argmax": rec[:, o2:o2 + MAX_VERIFY].view(np.int32)[:, :n_verify].copy(),
         }
 
-    def upsample_mask(self, low_res: np.ndarray, h: int, w: int) -> np.ndarray:
-        """F.interpolate(low_res.float(), (h, w), bilinear, align_corners=False) + clamp(min=0) on the GPU."""
+    def upsample_mask(self, low_res: np.ndarray, h: int, w: int, clamp: bool = True) -> np.ndarray:
+        """F.interpolate(low_res.float(), (h, w), bilinear, align_corners=False) [+ clamp(min=0)] on the GPU."""
         src = np.ascontiguousarray(low_res, dtype=np.float32).reshape(MASK_RES, MASK_RES)
         out = np.empty((h, w), dtype=np.float32)
-        _lib.check(self.lib.vstar_upsample_mask(self.handle, src.ctypes.data_as(ctypes.c_void_p), h, w,
-                                                out.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        _lib.check(self.lib.vstar_upsample_mask_ex(self.handle, src.ctypes.data_as(ctypes.c_void_p), h, w, 1 if clamp else 0,
+                                                   out.ctypes.data_as(ctypes.c_void_p)), self.handle)
         return out
 
     def heatmap_stats(self, low_res: np.ndarray, h: int, w: int, rects_xywh=None) -> np.ndarray:

@@ -2,7 +2,10 @@
 
 Same constructor argument (the `parse_args` namespace: version, vision_tower, conv_type, use_mm_start_end,
 model_max_length) and the same `inference(image, question, mode)` return conventions:
-  'detection'    -> (pred_boxes [2304,4] cpu, sigmoid scores [2304,1] cpu, heatmap [h,w] clamped >= 0)
+  'detection'    -> (pred_boxes [2304,4] cpu, sigmoid scores [2304,1] cpu in BFLOAT16, heatmap [h,w] clamped >= 0)
+                    (the reference returns det_result['pred_logits'][0].sigmoid().cpu() of a bf16 tensor, visual_search.py:225:
+                    the bf16 rounding of the sigmoid creates TIES among the top scores and the scheduler's argmax() / `>`
+                    thresholds act on those rounded values, so the scores keep that dtype here)
   'segmentation' -> heatmap [h,w]
   'vqa'          -> str            (greedy decode WITHOUT a KV cache, exactly like the reference: one full prefill per
                                     generated token, VSM.py:151 `use_cache=False`; used only by the contextual-cue branch)
@@ -31,6 +34,11 @@ from .engine import VstarEngine
 from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, SyntheticTokenizer, build_prompt, clip_preprocess,
                          owl_preprocess, tokenizer_image_token)
 from .weights import load_checkpoint_dir, random_state_dict
+
+
+def _scores(logits: np.ndarray) -> torch.Tensor:
+    """sigmoid of the (bf16-valued) class logits, evaluated and rounded in bfloat16 like the reference's tensor op."""
+    return torch.from_numpy(np.ascontiguousarray(logits)).to(torch.bfloat16).sigmoid()
 
 
 class TemplateMismatch(RuntimeError):
@@ -199,7 +207,7 @@ class VSM:
                 out.append(heat)
             else:
                 boxes = torch.from_numpy(res["pred_boxes"][b].copy())
-                scores = torch.from_numpy(res["pred_logits"][b].copy()).sigmoid()
+                scores = _scores(res["pred_logits"][b])
                 out.append((boxes, scores, heat))
         self.last_template_ok = np.concatenate(ok_all) if ok_all else np.zeros((0,), bool)
         self._handle_mismatches(out, lambda b: images[b], question, mode, upsample, defer_mismatch)
@@ -260,7 +268,7 @@ class VSM:
                 out.append(heat)
             else:
                 out.append((torch.from_numpy(res["pred_boxes"][b].copy()),
-                            torch.from_numpy(res["pred_logits"][b].copy()).sigmoid(), heat))
+                            _scores(res["pred_logits"][b]), heat))
         # the fallback decodes from the host-side crop (bit-identical pixels: test_gpu_preprocess_is_bit_identical...)
         self._handle_mismatches(out, lambda b: self._image.crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
                                 defer_mismatch)
@@ -331,7 +339,7 @@ class VSM:
         heat = torch.from_numpy(self.engine.upsample_mask(low, h, w)) if upsample else torch.from_numpy(low.copy())
         if mode == "segmentation":
             return heat
-        return (torch.from_numpy(res["pred_boxes"][0].copy()), torch.from_numpy(res["pred_logits"][0].copy()).sigmoid(), heat)
+        return (torch.from_numpy(res["pred_boxes"][0].copy()), _scores(res["pred_logits"][0]), heat)
 
     @torch.inference_mode()
     def generate_ids(self, image: Image.Image, question: str, max_new_tokens: int = 100, use_cache: bool = True) -> List[int]:
