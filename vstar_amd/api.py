@@ -184,6 +184,8 @@ class LlavaSearchModel:
     `.logits` / `.past_key_values`, `.config.vocab_size`.  fp16, KV cache in HBM; a continuation (`past_key_values=`) FORKS the
     question's slot (no copy, no re-prefill), which is what the option scoring of the evaluation needs."""
 
+    MAX_LOGIT_ROWS = 256          # logits rows one engine call returns (vstar_vqa_forward's n_want limit)
+
     def __init__(self, llm):
         self._llm = llm
         self.engine, self.cfg = llm.engine, llm.cfg
@@ -227,8 +229,15 @@ class LlavaSearchModel:
             self._next_fork = 1 + (self._next_fork % (self.cfg.max_slots - 1))
             seq = Seq(rows, kv_slot=slot, past_len=past_key_values.length, prefix_slot=past_key_values.slot)
             past = _PastKeyValues(slot, past_key_values.length + len(rows), forked=True)
-        logits, _ = self.engine.forward([seq], [(0, t) for t in range(len(rows))])
-        return SimpleNamespace(logits=torch.from_numpy(logits)[None], past_key_values=past if use_cache else None)
+        # lm_head runs only on requested rows (at most MAX_LOGIT_ROWS per call): `.logits` has the full [1, T, vocab] shape the
+        # reference returns, with the rows in front of the last MAX_LOGIT_ROWS left NaN (the evaluation reads logits[:, -1:] of
+        # the question and every row of the short option continuations)
+        T = len(rows)
+        first = max(0, T - self.MAX_LOGIT_ROWS)
+        got, _ = self.engine.forward([seq], [(0, t) for t in range(first, T)])
+        logits = torch.full((1, T, self.cfg.llm_vocab), float("nan"), dtype=torch.float16)
+        logits[0, first:] = torch.from_numpy(got)
+        return SimpleNamespace(logits=logits, past_key_values=past if use_cache else None)
 
     @torch.inference_mode()
     def generate(self, input_ids, images=None, object_features=None, images_long=None, objects_long=None, do_sample: bool = False,
