@@ -74,6 +74,49 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
                       f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
 
 
+def search_leg(eng, cfg, args, rank: int) -> dict:
+    """BASELINE config 2 LITERALLY (SURVEY §8d "searched crops/s"): one synthetic 3840x2160 image, `--search-targets` targets,
+    exhaustive depth-3 search tree (smallest_size = 540: 1 + 4 + 16 = 21 nodes per target), crops scored in 32-crop engine
+    batches, with EVERYTHING the search loop does inside the timed region: image upload, GPU-side crop / pad / Pillow-exact
+    resize / normalise (vstar_preprocess_crops), the engine pass, record D2H, template check, on-device heat-map statistics
+    (vstar_heatmap_stats) and the scheduler's decisions (visual_search.py:390-516 semantics, vstar_amd/search.py).  The confidence
+    thresholds are set so that no search stops early or enters the free-text cue branch: seeded random weights have no notion
+    of 'found', and the metric counts scored crops."""
+    import warnings
+    from vstar_amd.preprocess import SyntheticTokenizer
+    from vstar_amd.search import LazyExactPrioritize, smallest_size_for, visual_search_many
+    from vstar_amd.synthetic import synthetic_image
+    from vstar_amd.vsm import VSM
+    W, H = 3840, 2160
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+        vsm.shard_crops = False                  # each rank searches its own image (weak scaling, no collective in this leg)
+        smallest = smallest_size_for(W, H)
+        names = [f"object {i}" for i in range(args.search_targets)]
+        kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+        visual_search_many(vsm, synthetic_image(W, H, 1000 + rank), names[:2], None, smallest, **kw)       # warm-up (untimed)
+        for k in vsm.timers:
+            vsm.timers[k] = 0
+        LazyExactPrioritize.n_exact = 0
+        img = synthetic_image(W, H, rank)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = visual_search_many(vsm, img, names, None, smallest, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    crops = int(vsm.timers["crops"])
+    t = vsm.timers
+    return {"search_crops_per_s": round(crops / dt, 2), "wall_s": round(dt, 3), "crops_scored": crops, "targets": len(names),
+            "image": f"{W}x{H} synthetic", "tree": "depth 3 (1+4+16 nodes per target), exhaustive", "batch": cfg.max_batch,
+            "mode": "GPU preprocessing + on-device heat-map statistics (exact float32 fallback on near-ties: "
+                    f"{LazyExactPrioritize.n_exact} evaluations)",
+            "stage_s": {"engine_incl_gpu_preprocess_and_record_d2h": round(t["engine_s"], 3),
+                        "heatmap_statistics": round(t["post_s"], 3), "host_preprocess": round(t["preprocess_s"], 3),
+                        "decisions_prompting_and_other_host": round(dt - t["engine_s"] - t["post_s"] - t["preprocess_s"] - t["gather_s"], 3)},
+            "path_lengths": [int(r[1]) for r in res]}
+
+
 def fake_engine_run(args, world, rank, dist):
     """The multi-process skeleton of main() with a stub in place of the engine (CPU, gloo): same collectives, same timing
     protocol, same JSON keys.  Used by tests/test_host.py to cover the N>1 launch path without GPUs."""
@@ -132,6 +175,8 @@ def main():
     ap.add_argument("--skip-owl", action="store_true", help="core path only (diagnostic; NOT the headline metric)")
     ap.add_argument("--fake-engine", action="store_true", help="CPU plumbing check of the N-process path (gloo, stub step): "
                     "exercises rank/world handling, the per-step all-gather, the barrier and the max-over-ranks timing. NOT a bench")
+    ap.add_argument("--search-targets", type=int, default=16, help="targets of the config-2 search leg (>= 16 per BASELINE config 2)")
+    ap.add_argument("--no-search-leg", action="store_true", help="skip the end-to-end search leg (N = 1 only by default)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
@@ -216,23 +261,37 @@ def main():
     per_crop = fl["core"] if args.skip_owl else fl["full"]
     # HBM-side traffic of the GEMM family per launch, from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v7.json) — not re-measured live
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_v7.json")))
-        gem = [k for k in pmc if "gemm" in k["kernel"]]
-        traffic = round(sum(k["fetch_GB_corrected"] + k["write_GB"] for k in gem) * 1e9 / sum(k["launches"] for k in gem))
-    except Exception:
-        pass
+    traffic, traffic_src = None, None
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_v*.json")), reverse=True):
+        try:
+            pmc = json.load(open(cand))
+            gem = [k for k in pmc if "gemm" in k["kernel"]]
+            traffic = round(sum(k["fetch_GB_corrected"] + k["write_GB"] for k in gem) * 1e9 / sum(k["launches"] for k in gem))
+            traffic_src = os.path.relpath(cand, ROOT)
+            break
+        except Exception:
+            continue
     peak = 5000.0 if args.fp8 else PEAK_BF16_TFLOPS      # --fp8: 93 % of the GEMM FLOPs run on the fp8 MFMA (dense peak ~5 PF)
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None if args.fp8 else traffic,
-                "traffic_note": "bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE, PMC profile r01_pmc_v7; "
-                                "includes Infinity-Cache hits); algorithmic operand+output bytes per launch ~0.3 GB",
+                "traffic_note": f"bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE) from the committed rocprofv3 --pmc "
+                                f"passes of this command ({traffic_src}; counters cannot be read inside an un-profiled run); includes "
+                                "Infinity-Cache hits; algorithmic operand+output bytes per launch ~0.3 GB",
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
                 "end_to_end_tflops_per_gpu": round(crops_per_s / world * per_crop / 1e12, 1),
                 "end_to_end_frac": round(crops_per_s / world * per_crop / 1e12 / PEAK_BF16_TFLOPS, 4)}
+
+    # end-to-end search leg (config 2 literally) — single-GPU runs; at N > 1 the timed region above already carries the
+    # per-step record all-gather of the data-parallel search, and this leg stays off so that the scaling runs exercise one thing
+    search = None
+    if world == 1 and not args.no_search_leg and not args.skip_owl:
+        try:
+            search = search_leg(eng, cfg, args, rank)
+        except Exception as exc:            # the headline line must survive a failure of the auxiliary leg
+            search = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         cpu = None
@@ -251,7 +310,10 @@ def main():
                        ", records all-gathered per step",
                        "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
                        "flops_per_crop": per_crop, "weights_load_s": round(t_load, 1)},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "search": search,
+            "world_size": world, "collective": None if world == 1 else {
+                "backend": dist.get_backend() + " (RCCL over xGMI)", "op": "all_gather_into_tensor of the per-crop result records, once per step",
+                "bytes_per_rank_per_step": int(B * _lib.RESULT_FLOATS * 4), "ranks": dist.get_world_size()},
         }
         print(json.dumps(line))
     if world > 1:

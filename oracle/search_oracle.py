@@ -23,11 +23,21 @@ REF = os.environ.get("VSTAR_REFERENCE", "/root/reference")
 class FakeVSM:
     """inference(image, question, mode) -> same conventions as visual_search.py:208-225."""
 
-    def __init__(self, seed: int = 0, n_boxes: int = 64, gain: float = 9.0, conf_shift: float = -2.5, vqa_text=None):
+    def __init__(self, seed: int = 0, n_boxes: int = 64, gain: float = 9.0, conf_shift: float = -2.5, vqa_text=None,
+                 symmetric: bool = False):
         self.seed, self.n_boxes, self.gain, self.conf_shift = seed, n_boxes, gain, conf_shift
         self.vqa_text = vqa_text
+        # symmetric: the low-res map is mirrored left-right, so sibling sub-patches carry (mathematically) EQUAL heat mass and
+        # the reference's order among them is decided by float32 rounding — the near-tie regime of the scheduler
+        self.symmetric = symmetric
         self.calls = 0
         self.questions = []
+
+    def _low(self, g, scale):
+        low = torch.randn(1, 1, 12, 12, generator=g) * scale
+        if self.symmetric:
+            low[..., 6:] = torch.flip(low[..., :6], dims=[-1])
+        return low
 
     def _rng(self, image):
         w, h = image.size
@@ -43,7 +53,7 @@ class FakeVSM:
             if self.vqa_text is None:
                 raise NotImplementedError
             return self.vqa_text
-        low = torch.randn(1, 1, 12, 12, generator=g) * (self.gain if mode == "detection" else 9.0)
+        low = self._low(g, self.gain if mode == "detection" else 9.0)
         heat = torch.clamp(F.interpolate(low, (h, w), mode="bilinear", align_corners=False)[0, 0], min=0)
         if mode == "segmentation":
             return heat

@@ -98,6 +98,39 @@ class Prioritize:
         return self.priority < other.priority
 
 
+class LazyExactPrioritize(Prioritize):
+    """Queue entry of the device-reductions path.  `priority` is the negated child score from the fp64 rectangle-sum algebra,
+    which agrees with the reference's float32 numpy reductions to ~1e-5 relative — enough to order entries unless two of them
+    are nearly tied.  In that case (and only then) both entries compute their EXACT reference score — the float32 path on
+    materialised heat maps, `exact()` — and are ordered by it, so the pop order is the reference's in every case."""
+    REL_TOL = 1e-4          # >= 10 x the measured disagreement between the two arithmetic paths
+    n_exact = 0             # diagnostics: how often the exact path was needed
+
+    def __init__(self, priority, item, exact):
+        super().__init__(priority, item)
+        self._exact_fn, self._exact = exact, None
+
+    def exact(self):
+        if self._exact is None:
+            self._exact = -self._exact_fn()
+            LazyExactPrioritize.n_exact += 1
+        return self._exact
+
+    def _near(self, other):
+        a, b = float(self.priority), float(other.priority)
+        return abs(a - b) <= self.REL_TOL * max(abs(a), abs(b)) + 1e-12
+
+    def __eq__(self, other):
+        if isinstance(other, LazyExactPrioritize) and self._near(other):
+            return self.exact() == other.exact()
+        return self.priority == other.priority
+
+    def __lt__(self, other):
+        if isinstance(other, LazyExactPrioritize) and self._near(other):
+            return self.exact() < other.exact()
+        return self.priority < other.priority
+
+
 def smallest_size_for(image_width: int, image_height: int, minimum_size_scale: float = 4.0, minimum_size: int = 224) -> int:
     """visual_search.py:545."""
     return max(int(np.ceil(min(image_width, image_height) / minimum_size_scale)), minimum_size)
@@ -111,9 +144,11 @@ class _NodeScorer:
     """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
 
     def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool,
-                 gpu_preprocess: bool = True, device_reductions: bool = False):
+                 gpu_preprocess: bool = True, device_reductions: Optional[bool] = None):
         self.vsm, self.image, self.question = vsm, image, question
-        self.device_reductions = device_reductions and hasattr(vsm, "heatmap_stats") and hasattr(vsm, "inference_batch")
+        # on-device heat-map statistics (SURVEY §8f-4) whenever the VSM offers them; None = automatic, False = host reductions
+        can = hasattr(vsm, "heatmap_stats") and hasattr(vsm, "inference_batch")
+        self.device_reductions = can if device_reductions is None else (bool(device_reductions) and can)
         self.smallest_size = smallest_size
         self.batched = hasattr(vsm, "inference_batch")
         # device-side crop/resize when the VSM offers it: the full image is uploaded once, crops travel as boxes
@@ -196,7 +231,8 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                   target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
                   visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
                   noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
-                  gpu_preprocess: bool = True, device_reductions: bool = False, _scorer: Optional["_NodeScorer"] = None):
+                  gpu_preprocess: bool = True, device_reductions: Optional[bool] = None,
+                  _scorer: Optional["_NodeScorer"] = None):
     """Same contract as the reference's visual_search (visual_search.py:484-516): returns
     (final_step, path_length, search_successful, all_valid_boxes)."""
     if visualize:
@@ -284,10 +320,30 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                 tmp_patch = search_path[tmp_patch["parent_index"]]
                 tb = tmp_patch["bbox"]
                 tmp_stats = vsm.heatmap_stats(tmp_patch["heat_stats"]["low_res"], tb[3], tb[2], rel(tb))
-            for sub_patch, sub_score in zip(basic_sub_patches, basic_sub_scores):
+
+            def exact_scores(node=current_patch, subs=basic_sub_patches, memo={}):  # noqa: B006  (per-node memo on purpose)
+                """The reference's own float32 arithmetic for THIS node's children (visual_search.py:445-462): materialise the
+                normalised heat map of the node and of every ancestor and reduce with numpy.  Only evaluated on near-ties."""
+                if "v" not in memo:
+                    acc = [0] * len(subs)
+                    t = node
+                    while True:
+                        if "final_heatmap" not in t:
+                            tb2 = t["bbox"]
+                            hm = vsm.upsample_heatmap(t["heat_stats"]["low_res"], tb2[3], tb2[2]).view(tb2[3], tb2[2], 1)
+                            t["final_heatmap"] = normalize_score(hm).cpu().numpy()
+                        part = get_subpatch_scores(t["final_heatmap"], t["bbox"], subs)
+                        acc = [acc[i] + part[i] / (4 ** t["scale_level"]) for i in range(len(acc))]
+                        if t["parent_index"] == -1:
+                            break
+                        t = search_path[t["parent_index"]]
+                    memo["v"] = acc
+                return memo["v"]
+
+            for k, (sub_patch, sub_score) in enumerate(zip(basic_sub_patches, basic_sub_scores)):
                 info = {"bbox": sub_patch, "scale_level": level + 1, "score": np.float32(sub_score),
                         "parent_index": current_patch_index}
-                queue.put(Prioritize(-info["score"], info))
+                queue.put(LazyExactPrioritize(-info["score"], info, lambda k=k, f=exact_scores: f()[k]))
         elif expand:
             heat = target_cue_heatmap.view(bbox[3], bbox[2], 1)
             score_max = heat.max().item()
@@ -362,7 +418,7 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
     gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
     batch_size, speculate = kw.get("batch_size"), kw.get("speculate", True)
     scorers = [_NodeScorer(vsm, image, LOCATE_QUESTION.format(n), smallest_size, batch_size, speculate,
-                           kw.get("gpu_preprocess", True), kw.get("device_reductions", False)) for n in names]
+                           kw.get("gpu_preprocess", True), kw.get("device_reductions")) for n in names]
     if scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1:
         root = [0, 0, image.width, image.height]
         pairs = [(sc, b) for sc in scorers for b in sc.plan(root, PriorityQueue())]
