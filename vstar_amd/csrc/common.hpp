@@ -89,15 +89,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// activations, with the reference's bf16 rounding points (Appendix C of SURVEY.md)
+// activations, with the reference's bf16 rounding points (Appendix C of SURVEY.md).  sigmoid = v_exp_f32 + v_add + v_rcp_f32
+// (1 ulp, then rounded to 16 bits): an IEEE-exact fp32 divide costs ~10 VALU instructions per element, which made the SiLU /
+// quick-GELU epilogues of the gate|up and ViT fc1 GEMMs VALU-bound (6 % and 30 % of those kernels)
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_quick_gelu_bf16(float t) {  // t already bf16-rounded
   float u = rlp(1.702f * t);
-  float s = rlp(1.0f / (1.0f + __expf(-u)));
+  float s = rlp(fast_sigmoid(u));
   return t * s;
 }
 __device__ __forceinline__ float act_gelu_erf(float t) { return 0.5f * t * (1.0f + erff(t * 0.70710678118654752f)); }
 __device__ __forceinline__ float act_silu_bf16(float g) {  // g already bf16-rounded; torch silu on bf16 rounds once
-  return rlp(g / (1.0f + __expf(-g)));
+  return rlp(g * fast_sigmoid(g));
 }
 
 }  // namespace VS_NS

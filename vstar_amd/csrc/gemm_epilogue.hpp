@@ -41,7 +41,7 @@ __device__ __forceinline__ void gemm_epilogue_values(const GemmParams& p, int co
   }
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] / (1.0f + __expf(-1.702f * o[e])) : act_quick_gelu_bf16(o[e]);
+    for (int e = 0; e < 4; ++e) o[e] = OUT_F32 ? o[e] * fast_sigmoid(1.702f * o[e]) : act_quick_gelu_bf16(o[e]);
   } else if (EPI == VSTAR_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = act_gelu_erf(o[e]);
