@@ -146,18 +146,16 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const int nkt = (kend + 63) / 64;
   const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
 
+  // ONE barrier per 64-key tile: after it every wave has (a) seen its share of tile t land (vmcnt(0): only tile t is in flight at
+  // that point) and (b) finished computing tile t-1, so buffer (t+1)&1 may be overwritten — the next tile's DMA is issued right
+  // behind the barrier and has the whole compute of tile t to land.  (Two barriers per tile — one in front of the compute, one
+  // behind it — parked the waves 43 % of the time, rocprofv3 SQ_WAIT_ANY.)
   stage(0);
   for (int t = 0; t < nkt; ++t) {
-    if (t + 1 < nkt) {
-      stage(t + 1);
-      if (2 * K_INST == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nkt) stage(t + 1);
     const char* kb = smem + (t & 1) * 2 * KBYTES;
     const char* vb = kb + KBYTES;
     if (active) {
@@ -232,9 +230,6 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
   }
 
   if (active && query < S) {
