@@ -16,12 +16,18 @@ def short(name):
 
 acc = defaultdict(lambda: defaultdict(float))
 launches = defaultdict(int)
+have = set()                     # counters already taken from an earlier pass (a counter listed in two passes is not summed twice)
 for path in sys.argv[1:]:
     db = sqlite3.connect(path)
     seen = defaultdict(set)
+    this = set()
     for k, c, v, d in db.execute("select kernel_name, counter_name, value, dispatch_id from counters_collection"):
+        if c in have:
+            continue
+        this.add(c)
         acc[short(k)][c] += v
         seen[short(k)].add(d)
+    have |= this
     for k, s in seen.items():
         launches[k] = max(launches[k], len(s))
 out = []
