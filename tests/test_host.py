@@ -319,3 +319,18 @@ def test_bench_eval_vsm_factory_requires_a_local_vision_tower(tmp_path):
     args = types.SimpleNamespace(vsm_model_path=str(tmp_path / "vsm"), vision_tower=None)
     with pytest.raises(FileNotFoundError, match="--vision-tower"):
         make_vsm(args)
+
+
+def test_prompts_match_the_references_conversation_templates():
+    """build_prompt for both --conv_type values vs the strings the reference's Conversation.get_prompt() returns
+    (tests/golden/prompts.json, recorded from VisualSearch/model/llava/conversation.py by oracle/gen_prompt_golden.py)."""
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "prompts.json")))
+    assert {g["conv_type"] for g in gold} == {"llava_v1", "llava_llama_2"}
+    for g in gold:
+        got = pp.build_prompt(g["question"], g["use_mm_start_end"], g["answer"] or None, conv_type=g["conv_type"])
+        if g["answer"]:      # the reference closes a given answer with sep2; the teacher-forced prompt stops after the answer
+            got += " </s>" if g["conv_type"] == "llava_llama_2" else "</s>"
+        assert got == g["prompt"], (g["conv_type"], g["use_mm_start_end"], g["answer"])
+    with pytest.raises(ValueError):
+        pp.build_prompt("q", True, None, conv_type="mpt")

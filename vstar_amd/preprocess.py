@@ -75,11 +75,23 @@ def owl_preprocess(img: Image.Image, size: int = 768) -> np.ndarray:
     return _normalise(np.asarray(img))
 
 
-def build_prompt(question: str, use_mm_start_end: bool = True, answer: str | None = None) -> str:
-    """The llava_v1 prompt VSM.inference builds (visual_search.py:176-184); `answer` teacher-forces the reply."""
+# conv_templates["llava_llama_2"] (conversation.py:300-311), SeparatorStyle.LLAMA_2 (:72-93)
+LLAVA_LLAMA_2_SYSTEM = ("You are a helpful language and vision assistant. You are able to understand the visual content that the "
+                        "user provides, and assist the user with a variety of tasks using natural language.")
+
+
+def build_prompt(question: str, use_mm_start_end: bool = True, answer: str | None = None, conv_type: str = "llava_v1") -> str:
+    """The prompt VSM.inference builds (visual_search.py:176-184) for `--conv_type` llava_v1 (default) or llava_llama_2;
+    `answer` teacher-forces the reply (without the closing </s>).  Pinned to the reference's templates by
+    tests/golden/prompts.json (oracle/gen_prompt_golden.py)."""
     prompt = DEFAULT_IMAGE_TOKEN + "\n" + question
     if use_mm_start_end:
         prompt = prompt.replace(DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN)
+    if conv_type == "llava_llama_2":
+        ret = "[INST] <<SYS>>\n" + LLAVA_LLAMA_2_SYSTEM + "\n<</SYS>>\n\n" + prompt + " [/INST]"
+        return ret + (" " + answer if answer else "")
+    if conv_type != "llava_v1":
+        raise ValueError(f"unknown conv_type {conv_type!r} (visual_search.py:47 offers llava_v1 and llava_llama_2)")
     ret = LLAVA_V1_SYSTEM + LLAVA_V1_SEP
     ret += LLAVA_V1_ROLES[0] + ": " + prompt + LLAVA_V1_SEP
     if answer:

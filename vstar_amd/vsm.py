@@ -69,8 +69,8 @@ class VSM:
         `synthetic_seed` to run seeded random weights of the same architecture (benchmarks / tests)."""
         self.conv_type = getattr(args, "conv_type", "llava_v1")
         self.use_mm_start_end = getattr(args, "use_mm_start_end", True)
-        if self.conv_type != "llava_v1":
-            raise NotImplementedError("only the llava_v1 template (the reference default) is supported")
+        if self.conv_type not in ("llava_v1", "llava_llama_2"):
+            raise ValueError(f"unknown conv_type {self.conv_type!r} (visual_search.py:47: llava_v1 | llava_llama_2)")
         version = getattr(args, "version", None)
         real = version is not None and os.path.isdir(str(version))
         if engine is not None:
@@ -148,8 +148,8 @@ class VSM:
 
     # ---- prompt -> ids with the answer teacher-forced ----
     def _ids(self, question: str) -> Tuple[np.ndarray, int, List[int], List[int]]:
-        prompt = build_prompt(question, self.use_mm_start_end)
-        full = build_prompt(question, self.use_mm_start_end, answer=ANSWER_TEMPLATE)
+        prompt = build_prompt(question, self.use_mm_start_end, conv_type=self.conv_type)
+        full = build_prompt(question, self.use_mm_start_end, answer=ANSWER_TEMPLATE, conv_type=self.conv_type)
         ids_p = tokenizer_image_token(prompt, self.vsm_tokenizer)
         ids_f = tokenizer_image_token(full, self.vsm_tokenizer)
         if ids_f[: len(ids_p)] != ids_p:
@@ -311,7 +311,7 @@ class VSM:
         [LOC] equals the one of the reference's last decode step.  Like the reference, boxes/logits come from the FIRST [LOC]
         (`det_result[...][0]`) and the mask from the LAST (`pred_mask[-1]`); no [LOC] at all -> IndexError (`pred_mask[-1]` on
         an empty tensor)."""
-        prompt_ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end), self.vsm_tokenizer)
+        prompt_ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end, conv_type=self.conv_type), self.vsm_tokenizer)
         gen = self.generate_ids(image, question, max_new_tokens=100)
         locs = [i for i, t in enumerate(gen) if t == self.loc_token_idx]
         self.fallback_log.append({"question": question, "generated": list(gen), "loc_positions": locs})
@@ -347,7 +347,7 @@ class VSM:
         use_cache=True (default): prompt prefilled once, then one KV-cached decode step per token on the engine
         (vstar_vsm_generate).  use_cache=False: the reference's literal schedule (generate(use_cache=False)): every new token
         costs one full CLIP + LLaMA prefill over the sequence so far.  Both return the same arg-max tokens."""
-        ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end), self.vsm_tokenizer)
+        ids = tokenizer_image_token(build_prompt(question, self.use_mm_start_end, conv_type=self.conv_type), self.vsm_tokenizer)
         clip = torch.from_numpy(clip_preprocess(image, self.cfg.clip_image_size)).bfloat16()[None]
         P = self.cfg.n_img_tokens
         eos = getattr(self.vsm_tokenizer, "eos_token_id", 2)
