@@ -87,12 +87,14 @@ def search_leg(eng, cfg, args, rank: int) -> dict:
     from vstar_amd.search import LazyExactPrioritize, smallest_size_for, visual_search_many
     from vstar_amd.synthetic import synthetic_image
     from vstar_amd.vsm import VSM
-    W, H = 3840, 2160
+    # config 5 (--config5): 8K image, --minimum_size_scale 16 -> smallest_size 270 -> depth-5 tree (341 nodes per target)
+    W, H = (7680, 4320) if args.config5 else (3840, 2160)
+    scale = 16.0 if args.config5 else 4.0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
         vsm.shard_crops = False                  # each rank searches its own image (weak scaling, no collective in this leg)
-        smallest = smallest_size_for(W, H)
+        smallest = smallest_size_for(W, H, scale)
         names = [f"object {i}" for i in range(args.search_targets)]
         kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
         visual_search_many(vsm, synthetic_image(W, H, 1000 + rank), names[:2], None, smallest, **kw)       # warm-up (untimed)
@@ -107,8 +109,12 @@ def search_leg(eng, cfg, args, rank: int) -> dict:
         dt = time.perf_counter() - t0
     crops = int(vsm.timers["crops"])
     t = vsm.timers
+    depth, n, side = 1, 1, min(W, H)
+    while side > smallest:
+        side, depth, n = side // 2, depth + 1, n + 4 ** depth
     return {"search_crops_per_s": round(crops / dt, 2), "wall_s": round(dt, 3), "crops_scored": crops, "targets": len(names),
-            "image": f"{W}x{H} synthetic", "tree": "depth 3 (1+4+16 nodes per target), exhaustive", "batch": cfg.max_batch,
+            "image": f"{W}x{H} synthetic", "tree": f"depth {depth} ({n} nodes per target, smallest_size {smallest}), exhaustive",
+            "batch": cfg.max_batch,
             "mode": "GPU preprocessing + on-device heat-map statistics (exact float32 fallback on near-ties: "
                     f"{LazyExactPrioritize.n_exact} evaluations)",
             "stage_s": {"engine_incl_gpu_preprocess_and_record_d2h": round(t["engine_s"], 3),
@@ -177,10 +183,18 @@ def main():
                     "exercises rank/world handling, the per-step all-gather, the barrier and the max-over-ranks timing. NOT a bench")
     ap.add_argument("--search-targets", type=int, default=16, help="targets of the config-2 search leg (>= 16 per BASELINE config 2)")
     ap.add_argument("--no-search-leg", action="store_true", help="skip the end-to-end search leg (N = 1 only by default)")
+    ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as specified: W8A8 fp8 LLaMA linears, 64-crop batches, and the "
+                    "search leg on an 8K synthetic image with --minimum_size_scale 16 (depth-5 tree); separate line, not the headline")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
 
+    if args.config5:
+        args.fp8 = True
+        if args.batch == 32:
+            args.batch = 64
+        if args.search_targets == 16:
+            args.search_targets = 2            # 2 x 341 = 682 crops
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -305,7 +319,7 @@ def main():
             "dtype": "fp8 e4m3 W8A8 for the LLaMA linears (per-token / per-channel scales), bf16 elsewhere" if args.fp8 else "bf16",
             "data": "synthetic (seeded random weights of the real architecture, N(0,1) pixels, random ids)",
             "config": {"workload": ("TINY-plumbing " if args.tiny else "") + ("[config-5 precision] " if args.fp8 else "") +
-                       f"BASELINE config 2: {B}-crop batches/GPU, CLIP-ViT-L/14@{cfg.clip_image_size} (P={P}) + LLaMA-7B prefill "
+                       f"BASELINE config {5 if args.config5 else 2}: {B}-crop batches/GPU, CLIP-ViT-L/14@{cfg.clip_image_size} (P={P}) + LLaMA-7B prefill "
                        f"S={S} + " + ("(core only)" if args.skip_owl else "OWL-ViT-B/16@768 + det/SAM heads") +
                        ", records all-gathered per step",
                        "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
