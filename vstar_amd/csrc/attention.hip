@@ -16,6 +16,10 @@
 #include "kernels.hpp"
 #include <cstdlib>
 
+#ifndef ATTN_KT
+#define ATTN_KT 64          // keys per LDS tile: 64 (2-deep ring) or 32 (4-deep ring, same LDS bytes, DMA three tiles ahead)
+#endif
+
 namespace VS_NS {
 
 namespace {
@@ -62,10 +66,14 @@ template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ out, int S, int H,
                                                     float scale_log2e) {
   constexpr int KS = D / 16, DB = D / 32;
-  constexpr int KBYTES = 64 * D * 2;               // K tile = V tile bytes
+  constexpr int KT = ATTN_KT;                       // keys per tile
+  constexpr int NBUF = 128 / KT;                    // ring depth (the ring always holds 128 keys of K and of V)
+  constexpr int PD = NBUF - 1;                      // tiles requested ahead of the one being computed
+  constexpr int KBYTES = KT * D * 2;                // K tile = V tile bytes
   constexpr int KCH = D / 8;                        // 16-B chunks per K row
   constexpr int KROWS_PER_INST = 64 / KCH;          // K rows covered by one wave-wide DMA instruction
-  constexpr int K_INST = 64 / KROWS_PER_INST / 4;   // K DMA instructions per wave per tile (4 waves)
+  constexpr int K_INST = KT / KROWS_PER_INST / 4;   // K DMA instructions per wave per tile (4 waves)
+  static_assert(K_INST >= 1, "tile too small for 4 DMA waves");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -107,8 +115,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
     vsrc[i] = Vg + (ch ^ (gq << 2)) * 8;
   }
   auto stage = [&](int t) {
-    char* base = smem + (t & 1) * 2 * KBYTES;
-    const int kt0 = t * 64;
+    char* base = smem + (t % NBUF) * 2 * KBYTES;
+    const int kt0 = t * KT;
 #pragma unroll
     for (int i = 0; i < K_INST; ++i) {
       int kr = kt0 + krow_l[i];
@@ -143,25 +151,32 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   float m = -1e30f, l = 0.f;
 
   const int kend = CAUSAL ? min(S, q0b + 128) : S;
-  const int nkt = (kend + 63) / 64;
+  const int nkt = (kend + KT - 1) / KT;
   const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
 
-  // ONE barrier per 64-key tile: after it every wave has (a) seen its share of tile t land (vmcnt(0): only tile t is in flight at
-  // that point) and (b) finished computing tile t-1, so buffer (t+1)&1 may be overwritten — the next tile's DMA is issued right
-  // behind the barrier and has the whole compute of tile t to land.  (Two barriers per tile — one in front of the compute, one
-  // behind it — parked the waves 43 % of the time, rocprofv3 SQ_WAIT_ANY.)
-  stage(0);
+  // ONE barrier per tile: after it every wave has (a) seen its share of tile t land (counted vmcnt: only the PD-1 younger tiles
+  // may still be in flight) and (b) finished computing tile t-1, whose ring slot the tile requested next (t + PD) reuses.
+  // (Two barriers per tile parked the waves 43 % of the time, rocprofv3 SQ_WAIT_ANY.)
+#pragma unroll
+  for (int i = 0; i < PD; ++i)
+    if (i < nkt) stage(i);
   for (int t = 0; t < nkt; ++t) {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    {
+      const int younger = min(nkt - 1, t + PD - 1) - t;      // tiles requested after tile t so far (block-uniform)
+      constexpr int PER = 2 * K_INST;                         // DMA instructions per tile per wave (K + V)
+      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(2 * PER) : "memory");
+      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < nkt) stage(t + 1);
-    const char* kb = smem + (t & 1) * 2 * KBYTES;
+    if (t + PD < nkt) stage(t + PD);
+    const char* kb = smem + (t % NBUF) * 2 * KBYTES;
     const char* vb = kb + KBYTES;
     if (active) {
 #pragma unroll 1
-      for (int st = 0; st < 2; ++st) {
-        const int kt0 = t * 64 + st * 32;
+      for (int st = 0; st < KT / 32; ++st) {
+        const int kt0 = t * KT + st * 32;
         if (kt0 >= kend) continue;
         if (CAUSAL && kt0 > q0 + 31) continue;                  // wave-uniform: sub-tile entirely above the diagonal
         // ---- S^T = K . Q^T ----
