@@ -134,6 +134,25 @@ int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, cons
                           const int32_t* ids, int L, const int32_t* loc_pos,
                           const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
 
+/*
+ * Grouped scoring: G crops x T prompts per crop whose tokenised prompts share their first Lp ids (system prompt, the -200 image
+ * placeholder and the common start of the question — for the search loop everything up to the target's name), e.g. several
+ * search targets evaluated on the same crops (vstar_bench_eval.py:205-209 loops visual_search per missing object).  Under the
+ * causal mask the states of the shared positions do not depend on what follows them, so they are computed ONCE per crop
+ * (CLIP tower, projector, and Lp - 1 + P of the LLaMA rows), each prompt only adds its suffix rows (<= 32), and the OWL-ViT
+ * tower / box head run once per crop.  Record n = g * T + t equals what vstar_vsm_score_batch returns for (crop g, prompt t)
+ * up to bf16 rounding (the attention visits the keys in a different tiling).
+ *   prefix_ids [Lp]            shared ids, exactly one -200
+ *   suffix_ids [G*T*Ls]        per-record continuation, right-padded to Ls <= 32 with any valid id
+ *   loc_in_suffix [G*T]        index INSIDE the suffix of the token that precedes [LOC]
+ *   verify_in_suffix [G*T*nv]  indices inside the suffix whose next-token arg-max is returned in tf_argmax
+ * Requires G * T <= max_batch and G * (round_up(Lp - 1 + P, 128) + 32 T) <= max_batch * (max_text_len - 1 + P).
+ * Pixels are those of the G crops ([G,3,I,I] / [G,3,768,768]); flags as for vstar_vsm_score_batch (no VSTAR_F_SKIP_OWL).
+ */
+int vstar_vsm_score_grouped(vstar_handle* h, int G, int T, const uint16_t* clip_pix, const uint16_t* owl_pix,
+                            const int32_t* prefix_ids, int Lp, const int32_t* suffix_ids, int Ls, const int32_t* loc_in_suffix,
+                            const int32_t* verify_in_suffix, int n_verify, unsigned flags, vstar_result* out);
+
 /* GPU-side preprocessing.  vstar_image_set uploads the full RGB uint8 image [height,width,3] once;
  * vstar_preprocess_crops turns B crop boxes (x0,y0,x1,y1 exactly as passed to PIL `image.crop`, visual_search.py:394)
  * into the engine's CLIP and OWL-ViT input tensors: expand2square (top-left, CLIP-mean colour) + resize IxI, and resize to

@@ -19,7 +19,7 @@ EXPORTS = [
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_vsm_generate", "vstar_op_gemm_fp8",
-    "vstar_op_gemm_last_tile", "vstar_upsample_mask_ex",
+    "vstar_op_gemm_last_tile", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -79,6 +79,9 @@ def load() -> ctypes.CDLL:
     lib.vstar_vsm_score_batch.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_uint,
                                           c_void_p]
     lib.vstar_vsm_score_batch.restype = c_int
+    lib.vstar_vsm_score_grouped.argtypes = [H, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                            c_uint, c_void_p]
+    lib.vstar_vsm_score_grouped.restype = c_int
     lib.vstar_vsm_generate.argtypes = [H, c_void_p, c_void_p, c_int, c_int, c_int, c_uint, c_void_p, c_void_p]
     lib.vstar_vsm_generate.restype = c_int
     lib.vstar_image_set.argtypes = [H, c_void_p, c_int, c_int]

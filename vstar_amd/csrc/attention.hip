@@ -26,7 +26,8 @@ namespace {
 
 // ---------------- RoPE (in place on q and k of the fused qkv buffer) ----------------
 // HF rotate-half convention with the reference's bf16 rounding points: each product and the sum are bf16.
-__global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos_sin, int rows, int S, int H, int D) {
+__global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos_sin, int rows, int S, int H, int D, int grp_R0,
+                            int grp_Lc) {
   const int half = D >> 1;
   const int vec_per_head = half >> 3;                 // 8-element vectors in the first half
   const int per_row = 2 * H * vec_per_head;           // q and k
@@ -38,7 +39,8 @@ __global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos
   rem -= which * H * vec_per_head;
   const int h = rem / vec_per_head;
   const int d0 = (rem - h * vec_per_head) * 8;
-  const int pos = row % S;
+  int pos = row % S;
+  if (grp_R0 > 0 && pos >= grp_R0) pos = grp_Lc + ((pos - grp_R0) & 31);      // grouped sequences: 32-row suffix blocks restart at grp_Lc
   lp_t* base = qkv + (int64_t)row * (3 * H * D) + which * (H * D) + h * D;
   const lpx8 x1 = *(const lpx8*)(base + d0);
   const lpx8 x2 = *(const lpx8*)(base + d0 + half);
@@ -64,7 +66,12 @@ __global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos
 // V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ out, int S, int H,
-                                                    float scale_log2e) {
+                                                    float scale_log2e, int grp_R0, int grp_Lc) {
+  // Grouped sequences (causal only; grp_R0 > 0): rows [0, grp_Lc) are a SHARED prefix, rows [grp_R0, S) are independent 32-row
+  // suffix blocks (one per search target) that each attend to the shared prefix and, causally, to themselves — the prefill of
+  // T prompts that share their first grp_Lc tokens, with the prefix's K/V computed once (engine.hip::score_grouped).  A query
+  // block inside the suffix region walks the prefix's key tiles (keys >= grp_Lc masked) and then its own 128 rows, where wave w
+  // only looks at its own 32-row sub-tile.
   constexpr int KS = D / 16, DB = D / 32;
   constexpr int KT = ATTN_KT;                       // keys per tile
   constexpr int NBUF = 128 / KT;                    // ring depth (the ring always holds 128 keys of K and of V)
@@ -91,6 +98,10 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const lp_t* Kg = qkv + (int64_t)b * S * ld + (int64_t)H * D + h * D;
   const lp_t* Vg = qkv + (int64_t)b * S * ld + 2 * (int64_t)H * D + h * D;      // V rows of the fused qkv buffer
 
+  const bool sfx = CAUSAL && grp_R0 > 0 && q0b >= grp_R0;          // block-uniform: this query block lies in the suffix region
+  const int nsh = sfx ? (grp_Lc + KT - 1) / KT : 0;                   // key tiles of the shared prefix
+  auto key0 = [&](int t) { return sfx ? (t < nsh ? t * KT : q0b + (t - nsh) * KT) : t * KT; };
+
   // per-lane DMA sources
   const lp_t* ksrc[K_INST];
   int krow_l[K_INST];
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   }
   auto stage = [&](int t) {
     char* base = smem + (t % NBUF) * 2 * KBYTES;
-    const int kt0 = t * KT;
+    const int kt0 = key0(t);
 #pragma unroll
     for (int i = 0; i < K_INST; ++i) {
       int kr = kt0 + krow_l[i];
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   float m = -1e30f, l = 0.f;
 
   const int kend = CAUSAL ? min(S, q0b + 128) : S;
-  const int nkt = (kend + KT - 1) / KT;
+  const int nkt = sfx ? nsh + (kend - q0b + KT - 1) / KT : (kend + KT - 1) / KT;
   const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
 
   // ONE barrier per tile: after it every wave has (a) seen its share of tile t land (counted vmcnt: only the PD-1 younger tiles
@@ -176,9 +187,12 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
     if (active) {
 #pragma unroll 1
       for (int st = 0; st < KT / 32; ++st) {
-        const int kt0 = t * KT + st * 32;
-        if (kt0 >= kend) continue;
-        if (CAUSAL && kt0 > q0 + 31) continue;                  // wave-uniform: sub-tile entirely above the diagonal
+        const int kt0 = key0(t) + st * 32;
+        const bool shared_tile = sfx && t < nsh;                // prefix keys seen from a suffix block: no causal mask, limit grp_Lc
+        const int klimit = shared_tile ? grp_Lc : S;
+        if (kt0 >= (shared_tile ? grp_Lc : kend)) continue;
+        if (sfx && !shared_tile && kt0 != q0) continue;         // suffix block: of its own 128 rows a wave sees only its 32
+        if (CAUSAL && !shared_tile && kt0 > q0 + 31) continue;  // wave-uniform: sub-tile entirely above the diagonal
         // ---- S^T = K . Q^T ----
         f32x16 sacc;
 #pragma unroll
@@ -196,12 +210,13 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
         constexpr float RESCALE_THR = 6.0f;
         float p[16];
         float mx = -1e30f;
-        const bool need_mask = (kt0 + 32 > S) || (CAUSAL && kt0 + 31 > q0);
+        const bool causal_here = CAUSAL && !shared_tile;
+        const bool need_mask = (kt0 + 32 > klimit) || (causal_here && kt0 + 31 > q0);
         if (need_mask) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const bool masked = (key >= S) || (CAUSAL && key > query);
+            const bool masked = (key >= klimit) || (causal_here && key > query);
             sacc[r] = masked ? -1e30f : sacc[r];
           }
         }
@@ -403,17 +418,18 @@ __global__ __launch_bounds__(256) void small_attn_fewkeys_kernel(const lp_t* __r
 
 }  // namespace
 
-hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin, int B, int S, int H, int D, hipStream_t s) {
+hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin, int B, int S, int H, int D, hipStream_t s, int grp_R0, int grp_Lc) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
   if (cos_sin) {
     const int64_t n = (int64_t)B * S * 2 * H * (D / 16);
-    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_sin, B * S, S, H, D);
+    hipLaunchKernelGGL(rope_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_sin, B * S, S, H, D, grp_R0, grp_Lc);
   }
   return hipGetLastError();
 }
 
 template <int D, bool CAUSAL>
-static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, float sl, hipStream_t s) {
+static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, float sl, hipStream_t s, int grp_R0 = 0,
+                               int grp_Lc = 0) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
   auto kern = attn2_kernel<D, CAUSAL>;
@@ -423,15 +439,17 @@ static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, 
     attr_done = true;
   }
   dim3 grid((S + 127) / 128, H, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl, grp_R0, grp_Lc);
   return hipGetLastError();
 }
 
-hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s) {
+hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s, int grp_R0,
+                        int grp_Lc) {
   if (D != 64 && D != 128) return hipErrorInvalidValue;
+  if (grp_R0 > 0 && (!causal || D != 128 || grp_R0 % 128 || grp_Lc <= 0 || grp_Lc > grp_R0 || (S - grp_R0) % 32)) return hipErrorInvalidValue;
   const float sl = scale * 1.4426950408889634f;
   if (D == 64) return causal ? launch_attn2<64, true>(qkv, out, B, S, H, sl, s) : launch_attn2<64, false>(qkv, out, B, S, H, sl, s);
-  return causal ? launch_attn2<128, true>(qkv, out, B, S, H, sl, s) : launch_attn2<128, false>(qkv, out, B, S, H, sl, s);
+  return causal ? launch_attn2<128, true>(qkv, out, B, S, H, sl, s, grp_R0, grp_Lc) : launch_attn2<128, false>(qkv, out, B, S, H, sl, s);
 }
 
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,

@@ -81,6 +81,23 @@ __global__ void add_bcast_kernel(const lp_t* __restrict__ a, const lp_t* __restr
   *(lpx8*)(out + r * cols + v * 8) = o;
 }
 
+// grouped scoring: every crop's block of rows_per rows, plus the broadcast row b, repeated for the rep prompts of that crop
+__global__ void add_bcast_repeat_kernel(const lp_t* __restrict__ a, const lp_t* __restrict__ b, lp_t* __restrict__ out, int n_out,
+                                        int rep, int rows_per, int cols) {
+  const int cv = cols >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_out * rows_per * cv) return;
+  const int v = (int)(idx % cv);
+  const int64_t r = idx / cv;
+  const int n = (int)(r / rows_per), p = (int)(r % rows_per);
+  const lpx8 x = *(const lpx8*)(a + ((int64_t)(n / rep) * rows_per + p) * cols + v * 8);
+  const lpx8 y = *(const lpx8*)(b + v * 8);
+  lpx8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (short)f2lp(lp2f((lp_t)x[e]) + lp2f((lp_t)y[e]));
+  *(lpx8*)(out + r * cols + v * 8) = o;
+}
+
 // image_embeds[:, 1:, :] * image_embeds[:, :1, :]   (owlvit.py:131-137)
 __global__ void owl_cls_mul_kernel(const lp_t* __restrict__ x, lp_t* __restrict__ y, int B, int N, int C) {
   const int cv = C >> 3;
@@ -163,6 +180,12 @@ hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const l
 hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s) {
   if (cols % 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(add_bcast_kernel, dim3(nblk(rows * (cols / 8))), dim3(256), 0, s, a, b, out, rows, cols, b_rows);
+  return hipGetLastError();
+}
+hipError_t add_bcast_repeat(const lp_t* a, const lp_t* b, lp_t* out, int n_out, int rep, int rows_per, int cols, hipStream_t s) {
+  if (cols % 8 || rep < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(add_bcast_repeat_kernel, dim3(nblk((int64_t)n_out * rows_per * (cols / 8))), dim3(256), 0, s, a, b, out, n_out, rep,
+                     rows_per, cols);
   return hipGetLastError();
 }
 hipError_t owl_cls_mul(const lp_t* x, lp_t* y, int B, int N, int C, hipStream_t s) {

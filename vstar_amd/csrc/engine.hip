@@ -74,6 +74,20 @@ struct vstar_engine : EngineBase {
   int finalize();
   int score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* ids, int L, const int32_t* loc_pos,
             const int32_t* verify_pos, int n_verify, unsigned flags, vstar_result* out);
+  // grouped scoring: G crops x T prompts that share their first Lc spliced positions (see include/vstar_hip.h)
+  int score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* prefix_ids, int Lp,
+                    const int32_t* suffix_ids, int Ls, const int32_t* loc_in_suffix, const int32_t* verify_in_suffix, int n_verify,
+                    unsigned flags, vstar_result* out);
+  // shared stages of score / score_grouped
+  int grp_R0 = 0, grp_Lc = 0;       // grouped-sequence geometry of the LLaMA pass in flight (0 = plain sequences)
+  int llm_forward(int nseq, int S, int nsel);
+  int llm_heads(int nrec, int n_verify);
+  int owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_div);
+  int finish_records(int nrec, int n_verify, unsigned flags, vstar_result* out);
+  int stage_pixels(int B, const lp_t* clip_pix, const lp_t* owl_pix, unsigned flags, bool skip_owl, const lp_t** cpix, const lp_t** opix);
+  lp_t* grp_feats = nullptr;        // [max_batch * P, H] projected image features (grouped scoring)
+  int32_t* d_src = nullptr;         // [max_batch * Smax] embed_rows sources (grouped scoring)
+  std::vector<int32_t> h_src;
   int sam_attn(const SamAttn& a, const lp_t* q_in, int nq, const lp_t* k_in, const lp_t* v_in, int nk, int B,
                lp_t* pq, lp_t* pk, lp_t* pv, lp_t* att, lp_t* out, const lp_t* res);
   int make_sam_attn(const std::string& pre, SamAttn* a);
@@ -103,7 +117,7 @@ int vstar_engine::lin8(const uint8_t* Aq, const float* sa, const Lin& L, const L
   GemmParams p{};
   p.A = (const lp_t*)Aq; p.lda = L.K; p.W = (const lp_t*)L8.W; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
   p.M = M; p.N = L.N; p.K = L.K; p.a_scale = sa; p.w_scale = L8.s;
-  p.rope_cs = rope_cs; p.rope_S = rope_S; p.rope_cols = rope_cols;
+  p.rope_cs = rope_cs; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc;
   return gemm(p, epi, false);
 }
 
@@ -151,8 +165,9 @@ int vstar_engine::finalize() {
   RC(make_lin({"lm_head.weight"}, {}, &lm_head, H));
   Smax = c.max_text_len - 1 + clip.P;
   {  // rotate-half RoPE table, HF LlamaRotaryEmbedding: inv_freq = theta^(-2i/d), fp32, cast to bf16 before use
-    std::vector<lp_t> tab((size_t)Smax * 128);
-    for (int s = 0; s < Smax; ++s)
+    const int rope_rows = Smax + 160;     // grouped sequences index up to round_up(Lc, 128) and Lc + 32
+    std::vector<lp_t> tab((size_t)rope_rows * 128);
+    for (int s = 0; s < rope_rows; ++s)
       for (int i = 0; i < 64; ++i) {
         const float inv = 1.0f / powf(c.llm_rope_theta, (float)(2 * i) / 128.0f);
         const float f = (float)s * inv;
@@ -184,6 +199,8 @@ int vstar_engine::finalize() {
   RC(dalloc(&d_clip_pix, (size_t)maxB * 3 * c.clip_image_size * c.clip_image_size));
   RC(dalloc(&d_owl_pix, (size_t)maxB * 3 * c.owl_image_size * c.owl_image_size));
   RC(dalloc(&d_results, (size_t)maxB));
+  RC(dalloc(&grp_feats, (size_t)maxB * clip.P * H));
+  RC(dalloc(&d_src, lrows));
   HIPCHK(hipMemset(d_results, 0, sizeof(vstar_result) * maxB));
   // ---- text_hidden_fcs ----
   RC(make_lin({"model.text_hidden_fcs_det.0.0.weight"}, {"model.text_hidden_fcs_det.0.0.bias"}, &det0, H));
@@ -371,6 +388,196 @@ __global__ void sam_tokens_kernel(const lp_t* iou, const lp_t* mask_tokens, cons
 }
 }  // namespace
 
+// host/device pixel hand-over shared by score / score_grouped
+int vstar_engine::stage_pixels(int B, const lp_t* clip_pix, const lp_t* owl_pix, unsigned flags, bool skip_owl, const lp_t** cpix,
+                               const lp_t** opix) {
+  const vstar_config& c = cfg;
+  *cpix = clip_pix; *opix = owl_pix;
+  if (flags & VSTAR_F_INTERNAL_PIXELS) {
+    *cpix = d_clip_pix;   // filled by vstar_preprocess_crops on this stream
+    *opix = d_owl_pix;
+  } else if (!(flags & VSTAR_F_DEVICE_INPUTS)) {
+    const size_t cn = (size_t)B * 3 * c.clip_image_size * c.clip_image_size;
+    HIPCHK(hipMemcpyAsync(d_clip_pix, clip_pix, cn * 2, hipMemcpyHostToDevice, stream));
+    *cpix = d_clip_pix;
+    if (!skip_owl) {
+      const size_t on = (size_t)B * 3 * c.owl_image_size * c.owl_image_size;
+      HIPCHK(hipMemcpyAsync(d_owl_pix, owl_pix, on * 2, hipMemcpyHostToDevice, stream));
+      *opix = d_owl_pix;
+    }
+  }
+  return 0;
+}
+
+// ---- a5: LLaMA prefill (HF LlamaModel via llava_llama.py:93-102) over nseq sequences of S rows in lx; the last block runs on the
+// nsel rows listed in d_rowidx only and leaves them in sel_x.  grp_R0 / grp_Lc describe grouped sequences (shared prefix + 32-row
+// suffix blocks): they only change the RoPE positions and the attention mask — every other op is row-wise.
+int vstar_engine::llm_forward(int nseq, int S, int nsel) {
+  const vstar_config& c = cfg;
+  const int H = c.llm_hidden;
+  const int rows = nseq * S;
+  const float att_scale = 1.0f / sqrtf(128.0f);
+  // W8A8 (config 5): the four big linears of every block run on the fp8 MFMA when the call has enough rows for the 256^2
+  // kernel; activations are quantised per token right where they are produced (inside the RMSNorm for q|k|v and gate|up,
+  // by one pass over the attention output / the SiLU*up product for o_proj and down_proj)
+  const bool w8 = c.llm_w8a8 && rows >= 1024;
+  for (int i = 0; i < c.llm_layers; ++i) {
+    LlmBlock& b = llm[i];
+    if (w8) {
+      KCHK(rmsnorm_quant_fp8(lx, b.in_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
+      RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
+      if (!fused_rope) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
+    } else {
+      KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+      // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
+      GemmParams p{};
+      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = rows; p.N = b.qkv.N; p.K = b.qkv.K;
+      const bool fused = fused_rope && gemm256_eligible(p);
+      if (fused) { p.rope_cs = rope; p.rope_S = S; p.rope_cols = 2 * H; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc; }
+      RC(gemm(p, VSTAR_EPI_NONE, false));
+      if (!fused) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
+    }
+    KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream, grp_R0, grp_Lc));
+    if (i + 1 == c.llm_layers) {
+      // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
+      // attention is row-wise, so o_proj / MLP run on those gathered rows only (row-wise ops: bit-identical).
+      // (W8A8 mode: these few rows stay on the bf16 weights — the weight-bound regime gains nothing from fp8 MFMA.)
+      KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
+      KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
+      RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
+      KCHK(rmsnorm_lp(sel_x, b.post_norm, sel_h, nsel, H, c.llm_rms_eps, nullptr, stream));
+      RC(lin(sel_h, H, b.gate_up, sel_act, c.llm_mlp, nsel, VSTAR_EPI_SILU_MUL));
+      RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
+      break;
+    }
+    if (w8) {
+      KCHK(quantize_rows_fp8(latt, H, lq8, H, lsa, rows, H, stream));
+      RC(lin8(lq8, lsa, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+      KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
+      RC(lin8(lq8, lsa, b.gate_up, b.gate_up8, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0));
+      KCHK(quantize_rows_fp8(lact, c.llm_mlp, lq8, c.llm_mlp, lsa, rows, c.llm_mlp, stream));
+      RC(lin8(lq8, lsa, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    } else {
+      RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+      KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
+      RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+    }
+  }
+  return 0;
+}
+
+// ---- a6/a7/a8: final norm on the needed rows, lm_head argmax at the verify rows, text_hidden_fcs on the [LOC]-1 rows
+// (VSM.py:120-140,465-486).  sel_x rows: [0, nrec) the [LOC]-1 states, then nrec * n_verify verify rows.
+int vstar_engine::llm_heads(int nrec, int n_verify) {
+  const vstar_config& c = cfg;
+  const int H = c.llm_hidden;
+  const int nsel = nrec * (1 + n_verify);
+  KCHK(rmsnorm_lp(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));
+  if (n_verify > 0) {
+    RC(lin(hsel + (size_t)nrec * H, H, lm_head, vlogits, c.llm_vocab, nrec * n_verify, VSTAR_EPI_NONE, nullptr, 0, true));
+    KCHK(argmax_rows(vlogits, nrec * n_verify, c.llm_vocab, c.llm_vocab, d_argmax, 1, stream));
+  }
+  RC(lin(hsel, H, det0, fc_tmp, H, nrec, VSTAR_EPI_RELU));
+  RC(lin(fc_tmp, H, det1, emb_det, det1.N, nrec));
+  RC(lin(hsel, H, seg0, fc_tmp, H, nrec, VSTAR_EPI_RELU));
+  RC(lin(fc_tmp, H, seg1, emb_seg, 256, nrec));
+  return 0;
+}
+
+// ---- a9-a11: OWL-ViT tower on Bimg crops, class/box heads and the SAM-style mask head for nrec records; record n reads the image
+// features of crop n / img_div (grouped scoring: img_div prompts per crop; 1 otherwise)
+int vstar_engine::owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_div) {
+  const vstar_config& c = cfg;
+  const int B = nrec;
+  const int OH = c.owl_hidden, NP = owl.P, irow = Bimg * NP, prow = nrec * NP;
+  const int rstride = (int)(sizeof(vstar_result) / 4);
+  float* res_f = (float*)d_results;
+  // ---- a9: OWL-ViT tower + get_visual_embs (owlvit.py:121-148) ----
+  RC(run_tower(owl, opix, Bimg));
+  KCHK(layernorm_lp(owl.x, owl_post_g, owl_post_b, owl.h, Bimg * owl.N, OH, 1e-5f, nullptr, 0, stream));
+  KCHK(owl_cls_mul(owl.h, owl_feats_pre, Bimg, owl.N, OH, stream));
+  KCHK(layernorm_lp(owl_feats_pre, owl_ln_g, owl_ln_b, owl_feats, irow, OH, 1e-5f, nullptr, 0, stream));
+  // ---- a10: class + box heads (owlvit.py:150-170) ----
+  const int cld = cls_fused.N + 2;
+  RC(lin(owl_feats, OH, cls_fused, cls_emb, cld, irow, VSTAR_EPI_NONE, nullptr, 0, true));
+  KCHK(owl_class_logits(cls_emb, cld, c.owl_query_dim, emb_det, res_f + offsetof(vstar_result, pred_logits) / 4, rstride, nrec,
+                        NP, stream, img_div));
+  RC(lin(owl_feats, OH, box0, box_t0, OH, irow, VSTAR_EPI_GELU));
+  RC(lin(box_t0, OH, box1, box_t1, OH, irow, VSTAR_EPI_GELU));
+  RC(lin(box_t1, OH, box2, box_raw, 4, irow, VSTAR_EPI_NONE, nullptr, 0, true));
+  KCHK(owl_box_finish(box_raw, 4, res_f + offsetof(vstar_result, pred_boxes) / 4, rstride, nrec, owl.grid, stream, img_div));
+  // ---- a11: visual_projection + prompt encoder + two-way transformer + upscaling (VSM.py:515-533) ----
+  RC(lin(owl_feats, OH, vis_proj, s_src, 256, irow));
+  if (img_div <= 1) {
+    KCHK(add_bcast(s_src, no_mask, s_keys, prow, 256, 1, stream));              // src = image_embeddings + dense (no_mask_embed)
+  } else {
+    KCHK(add_bcast_repeat(s_src, no_mask, s_keys, nrec, img_div, NP, 256, stream));   // one private copy of the keys per prompt
+  }
+  hipLaunchKernelGGL(sam_tokens_kernel, dim3((B * 6 * 256 + 255) / 256), dim3(256), 0, stream, iou_token, mask_tokens,
+                     emb_seg, s_tok0, B);
+  KCHK(hipGetLastError());
+  const int T = 6, trow = B * T;
+  HIPCHK(hipMemcpyAsync(s_q, s_tok0, (size_t)trow * 256 * 2, hipMemcpyDeviceToDevice, stream));
+  for (int i = 0; i < 2; ++i) {
+    SamLayer& Ly = sam_layers[i];
+    // (1) token self attention
+    if (i == 0) {
+      RC(sam_attn(Ly.self_attn, s_q, T, s_q, s_q, T, B, s_ta, s_tb, s_tc, s_td, s_qpe, nullptr));
+    } else {
+      KCHK(add_bcast(s_q, s_tok0, s_mlp, trow, 256, trow, stream));           // q = queries + query_pe
+      RC(sam_attn(Ly.self_attn, s_mlp, T, s_mlp, s_q, T, B, s_ta, s_tb, s_tc, s_td, s_qpe, s_q));
+    }
+    KCHK(layernorm_lp(s_qpe, Ly.n1g, Ly.n1b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+    // (2) tokens -> image cross attention
+    KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));             // q = queries + query_pe
+    KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));          // k = keys + key_pe
+    RC(sam_attn(Ly.t2i, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
+    KCHK(layernorm_lp(s_tb, Ly.n2g, Ly.n2b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+    // (3) MLP on tokens
+    RC(lin(s_q, 256, Ly.lin1, s_mlp, Ly.lin1.N, trow, VSTAR_EPI_RELU));
+    RC(lin(s_mlp, Ly.lin1.N, Ly.lin2, s_tb, 256, trow, VSTAR_EPI_NONE, s_q, 256));
+    KCHK(layernorm_lp(s_tb, Ly.n3g, Ly.n3b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+    // (4) image -> tokens cross attention (q = keys + key_pe, k = queries + query_pe, v = queries)
+    KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
+    RC(sam_attn(Ly.i2t, s_kpe, NP, s_qpe, s_q, T, B, s_ia, s_ta, s_tb, s_ib, s_ic, s_keys));
+    KCHK(layernorm_lp(s_ic, Ly.n4g, Ly.n4b, s_keys, prow, 256, 1e-5f, nullptr, 0, stream));
+  }
+  KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
+  KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));
+  RC(sam_attn(sam_final, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
+  KCHK(layernorm_lp(s_tb, sam_nfg, sam_nfb, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
+  // hypernetwork MLP 0 on mask token 0 (= token row 1)
+  KCHK(gather_rows(s_q, d_tokidx, s_hyp_in, B, 256, stream));
+  RC(lin(s_hyp_in, 256, hyp0, s_hyp_a, 256, B, VSTAR_EPI_RELU));
+  RC(lin(s_hyp_a, 256, hyp1, s_hyp_b, 256, B, VSTAR_EPI_RELU));
+  RC(lin(s_hyp_b, 256, hyp2, s_hyper, 32, B));
+  // output_upscaling: Upsample(256->64) LN2d GELU Upsample(64->32) GELU (mask_decoder.py:78-84)
+  KCHK(upsample2x_im2col3x3(s_keys, s_col1, B, 48, 48, 256, stream));
+  RC(lin(s_col1, 2304, conv1, s_c1, 64, B * 96 * 96));
+  KCHK(layernorm_lp(s_c1, ln2d_g, ln2d_b, s_c1n, B * 96 * 96, 64, 1e-6f, nullptr, 1, stream));
+  KCHK(upsample2x_im2col3x3(s_c1n, s_col2, B, 96, 96, 64, stream));
+  RC(lin(s_col2, 576, conv2, s_c2, 32, B * 192 * 192, VSTAR_EPI_GELU));
+  KCHK(hyper_mask(s_hyper, s_c2, res_f + offsetof(vstar_result, lowres_mask) / 4, rstride, B, 192 * 192, 32, stream));
+  return 0;
+}
+
+int vstar_engine::finish_records(int nrec, int n_verify, unsigned flags, vstar_result* out) {
+  if (n_verify > 0) {   // verify argmax -> records
+    HIPCHK(hipMemcpy2DAsync((char*)d_results + offsetof(vstar_result, tf_argmax), sizeof(vstar_result), d_argmax,
+                            (size_t)n_verify * 4, (size_t)n_verify * 4, nrec, hipMemcpyDeviceToDevice, stream));
+  }
+  if (out) {
+    HIPCHK(hipMemcpyAsync(out, d_results, sizeof(vstar_result) * nrec,
+                          (flags & VSTAR_F_DEVICE_OUTPUT) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
+  }
+  if (!(flags & VSTAR_F_NO_SYNC)) {
+    HIPCHK(hipStreamSynchronize(stream));
+    collect_profile();
+  }
+  return 0;
+}
+
 int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* ids, int L,
                         const int32_t* loc_pos, const int32_t* verify_pos, int n_verify, unsigned flags,
                         vstar_result* out) {
@@ -408,21 +615,10 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   }
   HIPCHK(hipMemcpyAsync(d_ids, ids, (size_t)B * L * 4, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
-  const lp_t *cpix = clip_pix, *opix = owl_pix;
-  if (internal_pix) {
-    cpix = d_clip_pix;   // filled by vstar_preprocess_crops on this stream
-    opix = d_owl_pix;
-  } else if (!(flags & VSTAR_F_DEVICE_INPUTS)) {
-    const size_t cn = (size_t)B * 3 * c.clip_image_size * c.clip_image_size;
-    HIPCHK(hipMemcpyAsync(d_clip_pix, clip_pix, cn * 2, hipMemcpyHostToDevice, stream));
-    cpix = d_clip_pix;
-    if (!skip_owl) {
-      const size_t on = (size_t)B * 3 * c.owl_image_size * c.owl_image_size;
-      HIPCHK(hipMemcpyAsync(d_owl_pix, owl_pix, on * 2, hipMemcpyHostToDevice, stream));
-      opix = d_owl_pix;
-    }
-  }
+  const lp_t *cpix = nullptr, *opix = nullptr;
+  RC(stage_pixels(B, clip_pix, owl_pix, flags, skip_owl, &cpix, &opix));
   last_B = B; last_S = S;
+  grp_R0 = grp_Lc = 0;
 
   // ---- a2: CLIP tower (clip_encoder.py:31-60) ----
   RC(run_tower(clip, cpix, B));
@@ -436,153 +632,94 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
     RC(gemm(p, VSTAR_EPI_NONE, false));
   }
   KCHK(llm_embed_text(d_ids, L, img_col, P, embed, c.llm_vocab, lx, B, H, stream));
-  // ---- a5: LLaMA prefill (HF LlamaModel via llava_llama.py:93-102) ----
-  const int rows = B * S;
-  const float att_scale = 1.0f / sqrtf(128.0f);
-  const int nsel = B * (1 + n_verify);
-  // W8A8 (config 5): the four big linears of every block run on the fp8 MFMA when the call has enough rows for the 256^2
-  // kernel; activations are quantised per token right where they are produced (inside the RMSNorm for q|k|v and gate|up,
-  // by one pass over the attention output / the SiLU*up product for o_proj and down_proj)
-  const bool w8 = c.llm_w8a8 && rows >= 1024;
-  for (int i = 0; i < c.llm_layers; ++i) {
-    LlmBlock& b = llm[i];
-    if (w8) {
-      KCHK(rmsnorm_quant_fp8(lx, b.in_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
-      RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
-      if (!fused_rope) KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
-    } else {
-      KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-      // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
-      GemmParams p{};
-      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = rows; p.N = b.qkv.N; p.K = b.qkv.K;
-      const bool fused = fused_rope && gemm256_eligible(p);
-      if (fused) { p.rope_cs = rope; p.rope_S = S; p.rope_cols = 2 * H; }
-      RC(gemm(p, VSTAR_EPI_NONE, false));
-      if (!fused) KCHK(attn_prepare(lqkv, rope, B, S, c.llm_heads, 128, stream));
-    }
-    KCHK(attn_forward(lqkv, latt, B, S, c.llm_heads, 128, 1, att_scale, stream));
-    if (i + 1 == c.llm_layers) {
-      // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
-      // attention is row-wise, so o_proj / MLP run on those B*(1+V) gathered rows only (row-wise ops: bit-identical).
-      // (W8A8 mode: these few rows stay on the bf16 weights — the weight-bound regime gains nothing from fp8 MFMA.)
-      KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
-      KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
-      RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
-      KCHK(rmsnorm_lp(sel_x, b.post_norm, sel_h, nsel, H, c.llm_rms_eps, nullptr, stream));
-      RC(lin(sel_h, H, b.gate_up, sel_act, c.llm_mlp, nsel, VSTAR_EPI_SILU_MUL));
-      RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
-      break;
-    }
-    if (w8) {
-      KCHK(quantize_rows_fp8(latt, H, lq8, H, lsa, rows, H, stream));
-      RC(lin8(lq8, lsa, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-      KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
-      RC(lin8(lq8, lsa, b.gate_up, b.gate_up8, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0));
-      KCHK(quantize_rows_fp8(lact, c.llm_mlp, lq8, c.llm_mlp, lsa, rows, c.llm_mlp, stream));
-      RC(lin8(lq8, lsa, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-    } else {
-      RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-      KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
-      RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-    }
-  }
-  // ---- a6/a7: final norm on the needed rows only, lm_head argmax at the verify rows, [LOC]-1 gather ----
-  KCHK(rmsnorm_lp(sel_x, final_norm, hsel, nsel, H, c.llm_rms_eps, nullptr, stream));
-  if (n_verify > 0) {
-    RC(lin(hsel + (size_t)B * H, H, lm_head, vlogits, c.llm_vocab, B * n_verify, VSTAR_EPI_NONE, nullptr, 0, true));
-    KCHK(argmax_rows(vlogits, B * n_verify, c.llm_vocab, c.llm_vocab, d_argmax, 1, stream));
-  }
-  // ---- a8: text_hidden_fcs_{det,seg} on the [LOC]-1 row (VSM.py:120-140,478,486) ----
-  RC(lin(hsel, H, det0, fc_tmp, H, B, VSTAR_EPI_RELU));
-  RC(lin(fc_tmp, H, det1, emb_det, det1.N, B));
-  RC(lin(hsel, H, seg0, fc_tmp, H, B, VSTAR_EPI_RELU));
-  RC(lin(fc_tmp, H, seg1, emb_seg, 256, B));
+  RC(llm_forward(B, S, B * (1 + n_verify)));
+  RC(llm_heads(B, n_verify));
+  if (!skip_owl) RC(owl_heads_sam(opix, B, B, 1));
+  return finish_records(B, n_verify, flags, out);
+}
 
-  if (!skip_owl) {
-    const int OH = c.owl_hidden, NP = owl.P, prow = B * NP;
-    const int rstride = (int)(sizeof(vstar_result) / 4);
-    float* res_f = (float*)d_results;
-    // ---- a9: OWL-ViT tower + get_visual_embs (owlvit.py:121-148) ----
-    RC(run_tower(owl, opix, B));
-    KCHK(layernorm_lp(owl.x, owl_post_g, owl_post_b, owl.h, B * owl.N, OH, 1e-5f, nullptr, 0, stream));
-    KCHK(owl_cls_mul(owl.h, owl_feats_pre, B, owl.N, OH, stream));
-    KCHK(layernorm_lp(owl_feats_pre, owl_ln_g, owl_ln_b, owl_feats, prow, OH, 1e-5f, nullptr, 0, stream));
-    // ---- a10: class + box heads (owlvit.py:150-170) ----
-    const int cld = cls_fused.N + 2;
-    RC(lin(owl_feats, OH, cls_fused, cls_emb, cld, prow, VSTAR_EPI_NONE, nullptr, 0, true));
-    KCHK(owl_class_logits(cls_emb, cld, c.owl_query_dim, emb_det, res_f + offsetof(vstar_result, pred_logits) / 4, rstride, B,
-                          NP, stream));
-    RC(lin(owl_feats, OH, box0, box_t0, OH, prow, VSTAR_EPI_GELU));
-    RC(lin(box_t0, OH, box1, box_t1, OH, prow, VSTAR_EPI_GELU));
-    RC(lin(box_t1, OH, box2, box_raw, 4, prow, VSTAR_EPI_NONE, nullptr, 0, true));
-    KCHK(owl_box_finish(box_raw, 4, res_f + offsetof(vstar_result, pred_boxes) / 4, rstride, B, owl.grid, stream));
-    // ---- a11: visual_projection + prompt encoder + two-way transformer + upscaling (VSM.py:515-533) ----
-    RC(lin(owl_feats, OH, vis_proj, s_src, 256, prow));
-    KCHK(add_bcast(s_src, no_mask, s_keys, prow, 256, 1, stream));              // src = image_embeddings + dense (no_mask_embed)
-    hipLaunchKernelGGL(sam_tokens_kernel, dim3((B * 6 * 256 + 255) / 256), dim3(256), 0, stream, iou_token, mask_tokens,
-                       emb_seg, s_tok0, B);
-    KCHK(hipGetLastError());
-    const int T = 6, trow = B * T;
-    HIPCHK(hipMemcpyAsync(s_q, s_tok0, (size_t)trow * 256 * 2, hipMemcpyDeviceToDevice, stream));
-    for (int i = 0; i < 2; ++i) {
-      SamLayer& Ly = sam_layers[i];
-      // (1) token self attention
-      if (i == 0) {
-        RC(sam_attn(Ly.self_attn, s_q, T, s_q, s_q, T, B, s_ta, s_tb, s_tc, s_td, s_qpe, nullptr));
-      } else {
-        KCHK(add_bcast(s_q, s_tok0, s_mlp, trow, 256, trow, stream));           // q = queries + query_pe
-        RC(sam_attn(Ly.self_attn, s_mlp, T, s_mlp, s_q, T, B, s_ta, s_tb, s_tc, s_td, s_qpe, s_q));
+// Grouped scoring: G crops, each scored for T prompts whose first Lc spliced positions coincide (system prompt, image tokens and
+// the common start of the question).  The shared positions run through LLaMA ONCE per crop; each prompt adds one 32-row suffix
+// block that attends to them (under the causal mask the shared positions' states do not depend on what follows, so every
+// record equals the one vstar_vsm_score_batch computes for that (crop, prompt) pair up to the summation order of the attention).
+// Sequence layout per crop: rows [0, Lc) shared | [Lc, R0) zero padding, R0 = round_up(Lc, 128) | T blocks of 32 rows.
+int vstar_engine::score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* owl_pix, const int32_t* prefix_ids, int Lp,
+                                const int32_t* suffix_ids, int Ls, const int32_t* loc_in_suffix, const int32_t* verify_in_suffix,
+                                int n_verify, unsigned flags, vstar_result* out) {
+  if (!finalized) { set_error("vstar_finalize_weights has not been called"); return VSTAR_ERR_STATE; }
+  const vstar_config& c = cfg;
+  const int nrec = G * T;
+  if (G <= 0 || T <= 0 || nrec > c.max_batch) { set_error("G * T out of range (max_batch records per call)"); return VSTAR_ERR_INVALID; }
+  if (Ls < 1 || Ls > 32 || Lp < 2) { set_error("suffix length must be 1..32 tokens"); return VSTAR_ERR_INVALID; }
+  if (n_verify < 0 || n_verify > VSTAR_MAX_VERIFY) { set_error("n_verify out of range"); return VSTAR_ERR_INVALID; }
+  const bool internal_pix = flags & VSTAR_F_INTERNAL_PIXELS;
+  if (!prefix_ids || !suffix_ids || !loc_in_suffix || (!clip_pix && !internal_pix) || (!owl_pix && !internal_pix) ||
+      (n_verify && !verify_in_suffix)) { set_error("null input"); return VSTAR_ERR_INVALID; }
+  if (flags & VSTAR_F_SKIP_OWL) { set_error("grouped scoring always runs the heads"); return VSTAR_ERR_INVALID; }
+  HIPCHK(hipSetDevice(device));
+  int img_col = -1;
+  for (int j = 0; j < Lp; ++j)
+    if (prefix_ids[j] == -200) { if (img_col >= 0) { set_error("more than one -200 in the shared prefix"); return VSTAR_ERR_INVALID; } img_col = j; }
+  if (img_col < 0) { set_error("the shared prefix must contain the -200 image token"); return VSTAR_ERR_INVALID; }
+  const int P = clip.P, H = c.llm_hidden;
+  const int Lc = Lp - 1 + P, R0 = (Lc + 127) / 128 * 128, S = R0 + 32 * T;
+  if ((size_t)G * S > (size_t)c.max_batch * Smax || R0 > Smax + 128) {
+    set_error("grouped batch exceeds the LLaMA workspace (G * (round_up(Lc,128) + 32 T) rows)");
+    return VSTAR_ERR_INVALID;
+  }
+  // ---- embed_rows sources + the rows whose states are needed ----
+  h_src.assign((size_t)G * S, INT32_MIN);
+  std::vector<int32_t>& rowidx = h_rowidx;
+  rowidx.assign((size_t)nrec * (1 + n_verify), 0);
+  for (int g = 0; g < G; ++g) {
+    int32_t* row = h_src.data() + (size_t)g * S;
+    int r = 0;
+    for (int j = 0; j < Lp; ++j) {
+      if (j == img_col) { for (int q = 0; q < P; ++q) row[r++] = -(1 + g * P + q); }
+      else {
+        const int id = prefix_ids[j];
+        if (id < 0 || id >= c.llm_vocab) { set_error("token id out of range in the shared prefix"); return VSTAR_ERR_INVALID; }
+        row[r++] = id;
       }
-      KCHK(layernorm_lp(s_qpe, Ly.n1g, Ly.n1b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
-      // (2) tokens -> image cross attention
-      KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));             // q = queries + query_pe
-      KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));          // k = keys + key_pe
-      RC(sam_attn(Ly.t2i, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
-      KCHK(layernorm_lp(s_tb, Ly.n2g, Ly.n2b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
-      // (3) MLP on tokens
-      RC(lin(s_q, 256, Ly.lin1, s_mlp, Ly.lin1.N, trow, VSTAR_EPI_RELU));
-      RC(lin(s_mlp, Ly.lin1.N, Ly.lin2, s_tb, 256, trow, VSTAR_EPI_NONE, s_q, 256));
-      KCHK(layernorm_lp(s_tb, Ly.n3g, Ly.n3b, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
-      // (4) image -> tokens cross attention (q = keys + key_pe, k = queries + query_pe, v = queries)
-      KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
-      RC(sam_attn(Ly.i2t, s_kpe, NP, s_qpe, s_q, T, B, s_ia, s_ta, s_tb, s_ib, s_ic, s_keys));
-      KCHK(layernorm_lp(s_ic, Ly.n4g, Ly.n4b, s_keys, prow, 256, 1e-5f, nullptr, 0, stream));
     }
-    KCHK(add_bcast(s_q, s_tok0, s_qpe, trow, 256, trow, stream));
-    KCHK(add_bcast(s_keys, dense_pe, s_kpe, prow, 256, NP, stream));
-    RC(sam_attn(sam_final, s_qpe, T, s_kpe, s_keys, NP, B, s_ta, s_ia, s_ib, s_td, s_tb, s_q));
-    KCHK(layernorm_lp(s_tb, sam_nfg, sam_nfb, s_q, trow, 256, 1e-5f, nullptr, 0, stream));
-    // hypernetwork MLP 0 on mask token 0 (= token row 1)
-    KCHK(gather_rows(s_q, d_tokidx, s_hyp_in, B, 256, stream));
-    RC(lin(s_hyp_in, 256, hyp0, s_hyp_a, 256, B, VSTAR_EPI_RELU));
-    RC(lin(s_hyp_a, 256, hyp1, s_hyp_b, 256, B, VSTAR_EPI_RELU));
-    RC(lin(s_hyp_b, 256, hyp2, s_hyper, 32, B));
-    // output_upscaling: Upsample(256->64) LN2d GELU Upsample(64->32) GELU (mask_decoder.py:78-84)
-    KCHK(upsample2x_im2col3x3(s_keys, s_col1, B, 48, 48, 256, stream));
-    RC(lin(s_col1, 2304, conv1, s_c1, 64, B * 96 * 96));
-    KCHK(layernorm_lp(s_c1, ln2d_g, ln2d_b, s_c1n, B * 96 * 96, 64, 1e-6f, nullptr, 1, stream));
-    KCHK(upsample2x_im2col3x3(s_c1n, s_col2, B, 96, 96, 64, stream));
-    RC(lin(s_col2, 576, conv2, s_c2, 32, B * 192 * 192, VSTAR_EPI_GELU));
-    KCHK(hyper_mask(s_hyper, s_c2, res_f + offsetof(vstar_result, lowres_mask) / 4, rstride, B, 192 * 192, 32, stream));
-  }
-  // verify argmax -> records
-  if (n_verify > 0) {
-    HIPCHK(hipMemcpy2DAsync((char*)d_results + offsetof(vstar_result, tf_argmax), sizeof(vstar_result), d_argmax,
-                            (size_t)n_verify * 4, (size_t)n_verify * 4, B, hipMemcpyDeviceToDevice, stream));
-  }
-  if (out) {
-    if (flags & VSTAR_F_DEVICE_OUTPUT) {
-      HIPCHK(hipMemcpyAsync(out, d_results, sizeof(vstar_result) * B, hipMemcpyDeviceToDevice, stream));
-    } else {
-      HIPCHK(hipMemcpyAsync(out, d_results, sizeof(vstar_result) * B, hipMemcpyDeviceToHost, stream));
+    for (int t = 0; t < T; ++t) {
+      const int n = g * T + t;
+      for (int j = 0; j < Ls; ++j) {
+        const int id = suffix_ids[((size_t)n) * Ls + j];
+        if (id < 0 || id >= c.llm_vocab) { set_error("token id out of range in a suffix"); return VSTAR_ERR_INVALID; }
+        row[R0 + 32 * t + j] = id;
+      }
+      const int lp = loc_in_suffix[n];
+      if (lp < 0 || lp >= Ls) { set_error("loc_in_suffix out of range"); return VSTAR_ERR_INVALID; }
+      rowidx[n] = g * S + R0 + 32 * t + lp;
+      for (int v = 0; v < n_verify; ++v) {
+        const int pv = verify_in_suffix[(size_t)n * n_verify + v];
+        if (pv < 0 || pv >= Ls) { set_error("verify_in_suffix out of range"); return VSTAR_ERR_INVALID; }
+        rowidx[(size_t)nrec + (size_t)n * n_verify + v] = g * S + R0 + 32 * t + pv;
+      }
     }
   }
-  if (!(flags & VSTAR_F_NO_SYNC)) {
-    HIPCHK(hipStreamSynchronize(stream));
-    collect_profile();
+  HIPCHK(hipMemcpyAsync(d_src, h_src.data(), h_src.size() * 4, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
+  const lp_t *cpix = nullptr, *opix = nullptr;
+  RC(stage_pixels(G, clip_pix, owl_pix, flags, false, &cpix, &opix));
+  last_B = nrec; last_S = S;
+  // ---- a2 + a3: CLIP tower and projector for the G crops -> feature table; a4: splice by row sources ----
+  RC(run_tower(clip, cpix, G));
+  {
+    GemmParams p{};
+    p.A = clip.x; p.lda = clip.hidden; p.a_group = P; p.a_gstride = clip.N; p.a_off = 1;
+    p.W = projector.W; p.bias = projector.b; p.C = grp_feats; p.ldc = H; p.M = G * P; p.N = projector.N; p.K = projector.K;
+    RC(gemm(p, VSTAR_EPI_NONE, false));
   }
-  return 0;
+  KCHK(embed_rows(d_src, embed, c.llm_vocab, grp_feats, (int64_t)G * P, lx, G * S, H, stream));
+  grp_R0 = R0; grp_Lc = Lc;
+  const int rc = llm_forward(G, S, nrec * (1 + n_verify));
+  grp_R0 = grp_Lc = 0;
+  RC(rc);
+  RC(llm_heads(nrec, n_verify));
+  RC(owl_heads_sam(opix, G, nrec, T));
+  return finish_records(nrec, n_verify, flags, out);
 }
 
 // VSM.inference(mode='vqa'): greedy decode of one crop, KV-cached (see include/vstar_hip.h)
@@ -704,6 +841,13 @@ int vstar_vsm_score_batch(vstar_handle* h, int B, const uint16_t* clip_pix, cons
                           vstar_result* out) {
   if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->score(B, clip_pix, owl_pix, ids, L, loc_pos, verify_pos, n_verify, flags, out);
+}
+
+int vstar_vsm_score_grouped(vstar_handle* h, int G, int T, const uint16_t* clip_pix, const uint16_t* owl_pix,
+                            const int32_t* prefix_ids, int Lp, const int32_t* suffix_ids, int Ls, const int32_t* loc_in_suffix,
+                            const int32_t* verify_in_suffix, int n_verify, unsigned flags, vstar_result* out) {
+  if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
+  return h->score_grouped(G, T, clip_pix, owl_pix, prefix_ids, Lp, suffix_ids, Ls, loc_in_suffix, verify_in_suffix, n_verify, flags, out);
 }
 
 int vstar_vsm_generate(vstar_handle* h, const uint16_t* clip_pix, const int32_t* ids, int L, int max_new_tokens, int eos_id,

@@ -344,7 +344,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         if constexpr (EPI == VSTAR_EPI_NONE) {
           if (rope_tile) {
             const lpx8 vp = *(const lpx8*)(slab_partner + rl * RSTRIDE + ch * 16);
-            const int pos = (row < p.M ? row : p.M - 1) % p.rope_S;
+            int pos = (row < p.M ? row : p.M - 1) % p.rope_S;
+            if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);      // grouped sequences
             const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + ch * 8);
             const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + ch * 8);
             const float sgn = (wc & 1) ? 1.0f : -1.0f;      // first half of the head: x*cos - partner*sin

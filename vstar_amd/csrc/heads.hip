@@ -12,12 +12,12 @@ namespace {
 // bf16 reference.  One wave per image token.
 __global__ __launch_bounds__(256) void owl_class_kernel(const float* __restrict__ emb, int ld, int Q,
                                                         const lp_t* __restrict__ query, float* __restrict__ out,
-                                                        int out_stride_crop, int B, int rows_per_crop) {
+                                                        int out_stride_crop, int B, int rows_per_crop, int img_div) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (int64_t)B * rows_per_crop) return;
   const int b = (int)(row / rows_per_crop), p = (int)(row % rows_per_crop);
-  const float* er = emb + row * ld;
+  const float* er = emb + ((int64_t)(b / img_div) * rows_per_crop + p) * ld;
   const lp_t* qr = query + (int64_t)b * Q;
   float ee = 0.f, qq = 0.f;
   for (int d = lane; d < Q; d += 64) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void owl_class_kernel(const float* __restrict_
 
 // box_predictor: pred = sigmoid(box_head(x) + box_bias)  (owlvit.py:63-100)
 __global__ void owl_box_kernel(const float* __restrict__ raw, int ld, float* __restrict__ out, int out_stride_crop, int B,
-                               int grid) {
+                               int grid, int img_div) {
   const int npatch = grid * grid;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)B * npatch * 4) return;
@@ -55,7 +55,7 @@ __global__ void owl_box_kernel(const float* __restrict__ raw, int ld, float* __r
   else coord = 1.0f / (float)grid;
   coord = fminf(fmaxf(coord, 0.f), 1.f);
   const float bias = logf(coord + 1e-4f) - log1pf(-coord + 1e-4f);
-  const float v = rlp(rlp(raw[row * ld + c]) + bias);
+  const float v = rlp(rlp(raw[((int64_t)(b / img_div) * npatch + p) * ld + c]) + bias);
   out[(int64_t)b * out_stride_crop + p * 4 + c] = rlp(1.0f / (1.0f + __expf(-v)));
 }
 
@@ -208,15 +208,15 @@ hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout,
 }
 
 hipError_t owl_class_logits(const float* emb, int ld, int Q, const lp_t* query, float* out, int out_stride_crop, int B,
-                            int rows_per_crop, hipStream_t s) {
+                            int rows_per_crop, hipStream_t s, int img_div) {
   const int64_t rows = (int64_t)B * rows_per_crop;
   hipLaunchKernelGGL(owl_class_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, emb, ld, Q, query, out,
-                     out_stride_crop, B, rows_per_crop);
+                     out_stride_crop, B, rows_per_crop, img_div < 1 ? 1 : img_div);
   return hipGetLastError();
 }
-hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s) {
+hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s, int img_div) {
   hipLaunchKernelGGL(owl_box_kernel, dim3(nblk((int64_t)B * grid * grid * 4)), dim3(256), 0, s, raw, ld, out,
-                     out_stride_crop, B, grid);
+                     out_stride_crop, B, grid, img_div < 1 ? 1 : img_div);
   return hipGetLastError();
 }
 hipError_t upsample2x_im2col3x3(const lp_t* src, lp_t* A, int B, int h, int w, int C, hipStream_t s) {

@@ -25,6 +25,7 @@ struct GemmParams {
   // (col < rope_cols, heads of 128): out = rlp(x*cos) + rlp(-/+ partner*sin) with position = row % rope_S and the table
   // rope_cs [rope_S, 128] = cos(64)|sin(64) — the rounding points of rope_kernel, one pass over q,k less
   const lp_t* rope_cs; int rope_S; int rope_cols;
+  int rope_R0, rope_Lc;   // grouped sequences (see attn_forward): position of row r >= rope_R0 is rope_Lc + ((r - rope_R0) & 31); 0 = off
   // gemm256 only: W8A8 mode (BASELINE config 5).  a_scale != null => A and W point at OCP fp8 e4m3 bytes (lda / K count
   // fp8 elements, K % 256 == 0), a_scale [M] and w_scale [N] are the per-row / per-output-channel dequantisation factors:
   // C = epilogue((A_q · W_q^T) * a_scale[m] * w_scale[n]).  One v_mfma_scale_f32_16x16x128_f8f6f4 (scales 1.0) replaces two
@@ -80,9 +81,13 @@ hipError_t rmsnorm_lp(const lp_t* x, const lp_t* gamma, lp_t* y, int rows, int c
 
 // ---- attention (attention.hip) ----
 // qkv: [B*S, 3*H*D] (q | k | v).  attn_prepare: in-place rotate-half RoPE on q,k (no-op when cos_sin == null)
+// Grouped sequences (grp_R0 > 0; causal D = 128 only): rows [0, grp_Lc) of every sequence are a shared prefix, rows [grp_R0, S) are
+// independent 32-row suffix blocks that attend to the prefix and causally to themselves; RoPE positions of a suffix block restart
+// at grp_Lc.  grp_R0 % 128 == 0, (S - grp_R0) % 32 == 0.
 hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin /*[S, D] = cos(D/2)|sin(D/2), or null*/, int B, int S, int H, int D,
-                        hipStream_t s);
-hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s);
+                        hipStream_t s, int grp_R0 = 0, int grp_Lc = 0);
+hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s,
+                        int grp_R0 = 0, int grp_Lc = 0);
 // generic small attention for the SAM head: q[B,Nq,H*D] k[B,Nk,H*D] v[B,Nk,H*D] -> out[B,Nq,H*D]; D <= 32, fp32 math
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,
                            int D, hipStream_t s);
@@ -98,6 +103,8 @@ hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const l
                           int C, hipStream_t s);
 // out[r, :] = a[r, :] + b[(r % b_rows), :]   (bf16 add; b broadcast over groups of b_rows)
 hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s);
+// out[(n * rows_per + p), :] = a[((n / rep) * rows_per + p), :] + b[0, :]  for n < n_out : every block of rows_per rows repeated rep times
+hipError_t add_bcast_repeat(const lp_t* a, const lp_t* b, lp_t* out, int n_out, int rep, int rows_per, int cols, hipStream_t s);
 // OWL-ViT: y[b,p,:] = x[b,1+p,:] * x[b,0,:]  (x = post_layernorm output, [B,N,C]) -> [B,N-1,C]
 hipError_t owl_cls_mul(const lp_t* x, lp_t* y, int B, int N, int C, hipStream_t s);
 // gather rows: y[r,:] = x[idx[r],:]
@@ -107,10 +114,11 @@ hipError_t argmax_rows(const float* x, int rows, int cols, int ld, int32_t* out,
 
 // ---- heads (heads.hip) ----
 // class head: emb [R, ldc] fp32 = dense0(512) | shift | scale ; query [B, Q] bf16; rows_per_crop = 2304
+// img_div: record b reads the image rows of crop b / img_div (several queries per crop: grouped scoring); 1 = one query per crop
 hipError_t owl_class_logits(const float* emb, int ld, int Q, const lp_t* query, float* out, int out_stride_crop,
-                            int B, int rows_per_crop, hipStream_t s);
+                            int B, int rows_per_crop, hipStream_t s, int img_div = 1);
 // box head final: raw [R, 4] fp32 (dense2 out incl. bias) + grid bias -> sigmoid -> out[b*stride + p*4 ..]
-hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s);
+hipError_t owl_box_finish(const float* raw, int ld, float* out, int out_stride_crop, int B, int grid, hipStream_t s, int img_div = 1);
 // SAM upscaling: bilinear x2 (align_corners=False, fp32 -> bf16) fused with 3x3 im2col (zero pad):
 // src [B, h, w, C] channels-last -> A [B*(2h)*(2w), 9*C], k = (ky*3+kx)*C + c
 hipError_t upsample2x_im2col3x3(const lp_t* src, lp_t* A, int B, int h, int w, int C, hipStream_t s);

@@ -134,6 +134,38 @@ class VstarEngine:
         assert tuple(out_dev.shape) == (B, _lib.RESULT_FLOATS), out_dev.shape
         return out_dev, ctypes.c_void_p(out_dev.data_ptr())
 
+    # ---- grouped scoring: G crops x T prompts sharing their first Lp ids (include/vstar_hip.h: vstar_vsm_score_grouped) ----
+    def score_grouped(self, clip_pix, owl_pix, prefix_ids, suffix_ids, loc_in_suffix, verify_in_suffix=None, raw: bool = False,
+                      internal_pixels: bool = False, n_crops: Optional[int] = None):
+        """prefix_ids [Lp] (one -200); suffix_ids [G, T, Ls] (Ls <= 32, right-padded); loc_in_suffix [G, T]; verify_in_suffix
+        [G, T, V] or None.  Pixels of the G crops as for score_batch, or internal_pixels=True after preprocess (score_boxes path).
+        Returns G*T records in (crop-major, prompt-minor) order."""
+        suf = np.ascontiguousarray(np.asarray(suffix_ids, dtype=np.int32))
+        assert suf.ndim == 3
+        G, T, Ls = suf.shape
+        pre = np.ascontiguousarray(np.asarray(prefix_ids, dtype=np.int32).reshape(-1))
+        loc = np.ascontiguousarray(np.asarray(loc_in_suffix, dtype=np.int32).reshape(G * T))
+        nv, vptr = 0, None
+        if verify_in_suffix is not None:
+            vp = np.ascontiguousarray(np.asarray(verify_in_suffix, dtype=np.int32)).reshape(G * T, -1)
+            nv = vp.shape[1]
+            vptr = vp.ctypes.data_as(ctypes.c_void_p)
+        flags = 0
+        cptr = optr = None
+        if internal_pixels:
+            flags |= _lib.F_INTERNAL_PIXELS
+        else:
+            clip_pix, owl_pix = _as_bf16(clip_pix), _as_bf16(owl_pix)
+            assert clip_pix.shape[0] == G and owl_pix.shape[0] == G and clip_pix.device == owl_pix.device
+            if clip_pix.is_cuda:
+                flags |= _lib.F_DEVICE_INPUTS
+            cptr, optr = ctypes.c_void_p(clip_pix.data_ptr()), ctypes.c_void_p(owl_pix.data_ptr())
+        out = np.empty((G * T, _lib.RESULT_FLOATS), dtype=np.float32)
+        _lib.check(self.lib.vstar_vsm_score_grouped(
+            self.handle, G, T, cptr, optr, pre.ctypes.data_as(ctypes.c_void_p), pre.shape[0], suf.ctypes.data_as(ctypes.c_void_p), Ls,
+            loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        return out if raw else self.unpack(out, nv)
+
     # ---- GPU-side preprocessing (SURVEY.md §8f-3) ----
     def set_image(self, image) -> None:
         """Uploads the full RGB image (PIL.Image or uint8 [H,W,3]) once; crops are then just boxes."""
