@@ -74,7 +74,7 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
                       f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
 
 
-def search_leg(eng, cfg, args, rank: int) -> dict:
+def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
     """BASELINE config 2 LITERALLY (SURVEY §8d "searched crops/s"): one synthetic 3840x2160 image, `--search-targets` targets,
     exhaustive depth-3 search tree (smallest_size = 540: 1 + 4 + 16 = 21 nodes per target), crops scored in 32-crop engine
     batches, with EVERYTHING the search loop does inside the timed region: image upload, GPU-side crop / pad / Pillow-exact
@@ -94,6 +94,7 @@ def search_leg(eng, cfg, args, rank: int) -> dict:
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
         vsm.shard_crops = False                  # each rank searches its own image (weak scaling, no collective in this leg)
+        vsm.group_prompts = group                # False: every (crop, target) pair is a full pass, like the reference's loop
         smallest = smallest_size_for(W, H, scale)
         names = [f"object {i}" for i in range(args.search_targets)]
         kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
@@ -115,7 +116,8 @@ def search_leg(eng, cfg, args, rank: int) -> dict:
     return {"search_crops_per_s": round(crops / dt, 2), "wall_s": round(dt, 3), "crops_scored": crops, "targets": len(names),
             "image": f"{W}x{H} synthetic", "tree": f"depth {depth} ({n} nodes per target, smallest_size {smallest}), exhaustive",
             "batch": cfg.max_batch,
-            "mode": "GPU preprocessing + on-device heat-map statistics (exact float32 fallback on near-ties: "
+            "mode": ("shared-prefix grouping of the targets that visit the same crop (vstar_vsm_score_grouped) + " if group else "") +
+                    "GPU preprocessing + on-device heat-map statistics (exact float32 fallback on near-ties: "
                     f"{LazyExactPrioritize.n_exact} evaluations)",
             "stage_s": {"engine_incl_gpu_preprocess_and_record_d2h": round(t["engine_s"], 3),
                         "heatmap_statistics": round(t["post_s"], 3), "host_preprocess": round(t["preprocess_s"], 3),
@@ -300,12 +302,18 @@ def main():
 
     # end-to-end search leg (config 2 literally) — single-GPU runs; at N > 1 the timed region above already carries the
     # per-step record all-gather of the data-parallel search, and this leg stays off so that the scaling runs exercise one thing
-    search = None
+    search = search_grouped = None
     if world == 1 and not args.no_search_leg and not args.skip_owl:
         try:
-            search = search_leg(eng, cfg, args, rank)
+            search = search_leg(eng, cfg, args, rank, group=False)
         except Exception as exc:            # the headline line must survive a failure of the auxiliary leg
             search = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            # the same search with the targets' shared work done once per crop (results agree to bf16 rounding): what the
+            # drop-in classes do by default for multi-target searches
+            search_grouped = search_leg(eng, cfg, args, rank, group=True)
+        except Exception as exc:
+            search_grouped = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         cpu = None
@@ -324,7 +332,7 @@ def main():
                        ", records all-gathered per step",
                        "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
                        "flops_per_crop": per_crop, "weights_load_s": round(t_load, 1)},
-            "roofline": roofline, "cpu_baseline": cpu, "search": search,
+            "roofline": roofline, "cpu_baseline": cpu, "search": search, "search_grouped": search_grouped,
             "world_size": world, "collective": None if world == 1 else {
                 "backend": dist.get_backend() + " (RCCL over xGMI)", "op": "all_gather_into_tensor of the per-crop result records, once per step",
                 "bytes_per_rank_per_step": int(B * _lib.RESULT_FLOATS * 4), "ranks": dist.get_world_size()},

@@ -112,12 +112,58 @@ def test_multi_target_search_equals_per_target_loop(vsm):
             loop.append(visual_search(vsm, img, n, None, smallest, stats=st, **kw))
             st_loop.append(st)
         st_many = [{} for _ in names]
-        many = visual_search_many(vsm, img, names, None, smallest, **kw)
+        vsm.group_prompts = False          # plain batches (different prompts right-padded in one batch): bit-identical to the loop
+        try:
+            many = visual_search_many(vsm, img, names, None, smallest, **kw)
+        finally:
+            vsm.group_prompts = True
     assert len(many) == len(loop)
     for a, b in zip(loop, many):
         assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
         assert torch.equal(a[0]["detection_result"], b[0]["detection_result"])          # bit-identical scores
         assert float(a[0]["score"] if a[0]["score"] is not None else 0) == float(b[0]["score"] if b[0]["score"] is not None else 0)
+
+
+def test_multi_target_search_with_shared_prefix_grouping(vsm):
+    """visual_search_many with prompt grouping (default): the crops shared by the targets go through the towers and the shared
+    LLaMA positions once (vstar_vsm_score_grouped).  Records are a second bf16 evaluation of the same numbers (different attention
+    tiling), so they agree with the plain path to bf16 noise; on these fixtures every search still takes the same path."""
+    img = synthetic_image(1280, 720, 33)
+    smallest = smallest_size_for(1280, 720)
+    names = ["kite", "small red umbrella on the beach", "dog", "traffic light"]
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm.timers["grouped_records"] = 0
+        grouped = visual_search_many(vsm, img, names, None, smallest, **kw)
+        n_grouped = vsm.timers["grouped_records"]
+        vsm.group_prompts = False
+        try:
+            plain = visual_search_many(vsm, img, names, None, smallest, **kw)
+        finally:
+            vsm.group_prompts = True
+    # the first engine step of every target (root + speculative sub-tree, max_batch=8 nodes of the 21) went through the grouped
+    # entry point, each crop once for all four targets
+    assert n_grouped == 8 * len(names)
+    for a, b in zip(plain, grouped):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert torch.allclose(a[0]["detection_result"], b[0]["detection_result"], atol=1.0)      # pixels; bf16-level box differences
+    # per-record agreement on one crop: scores of the two paths within bf16 noise of each other
+    vsm.set_image(img)
+    qs = [pp.LOCATE_QUESTION.format(n) for n in names]
+    box = [[0, 0, 1280, 720]] * len(names)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        g = vsm.inference_boxes(box, qs, mode="detection", upsample=False)
+        vsm.group_prompts = False
+        try:
+            p_ = vsm.inference_boxes(box, qs, mode="detection", upsample=False)
+        finally:
+            vsm.group_prompts = True
+    for (bg, sg, hg), (bp, sp, hp) in zip(g, p_):
+        assert torch.equal(bg, bp) or (bg - bp).abs().max() < 8e-3     # box head: identical inputs, once per crop vs once per pair
+        assert (sg.float() - sp.float()).abs().max() < 2e-2
+        assert rel_l2(hg.numpy() - hg.numpy().mean(), hp.numpy() - hp.numpy().mean()) < 6e-2
 
 
 @pytest.mark.parametrize("use_cache", [True, False])

@@ -198,6 +198,12 @@ class VstarEngine:
             return None
         return out if raw else self.unpack(out, nv)
 
+    def preprocess_boxes(self, boxes_xyxy) -> None:
+        """Crop + pad + resize + normalise on the GPU into the engine's pixel buffers (consumed by a following call with
+        internal pixels: score_grouped(internal_pixels=True))."""
+        boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
+        _lib.check(self.lib.vstar_preprocess_crops(self.handle, boxes.shape[0], boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+
     def preprocess_only(self, boxes_xyxy):
         """(clip [B,3,I,I], owl [B,3,768,768]) float32 views of the device-side preprocessing result (tests)."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)

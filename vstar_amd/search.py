@@ -147,7 +147,7 @@ class _NodeScorer:
                  gpu_preprocess: bool = True, device_reductions: Optional[bool] = None):
         self.vsm, self.image, self.question = vsm, image, question
         # on-device heat-map statistics whenever the VSM offers them; None = automatic, False = host reductions
-        can = hasattr(vsm, "heatmap_stats") and hasattr(vsm, "inference_batch")
+        can = bool(getattr(vsm, "supports_device_reductions", hasattr(vsm, "heatmap_stats"))) and hasattr(vsm, "inference_batch")
         self.device_reductions = can if device_reductions is None else (bool(device_reductions) and can)
         self.smallest_size = smallest_size
         self.batched = hasattr(vsm, "inference_batch")
@@ -412,8 +412,9 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
 def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, **kw):
     """Several targets on ONE image (the reference loops `visual_search` per missing object, vstar_bench_eval.py:205-209):
     same per-target results as that loop — each entry is visual_search's 4-tuple — but the first engine step of every
-    target (root crop + its speculative sub-tree) is scored together, different prompts in the same 32-crop batches, so
-    small per-target steps still fill the GPU.  Later steps of a search run per target as usual."""
+    target (root crop + its speculative sub-tree) is scored together, all targets of a crop in the same engine call, so
+    small per-target steps still fill the GPU and a grouping VSM evaluates each crop's towers and shared prompt positions
+    once.  Later steps of a search run per target as usual."""
     names = list(target_object_names)
     gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
     batch_size, speculate = kw.get("batch_size"), kw.get("speculate", True)
@@ -421,8 +422,12 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
                            kw.get("gpu_preprocess", True), kw.get("device_reductions")) for n in names]
     if scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1:
         root = [0, 0, image.width, image.height]
-        pairs = [(sc, b) for sc in scorers for b in sc.plan(root, PriorityQueue())]
-        step = scorers[0].batch_size
+        # box-major order, chunks of WHOLE boxes: every target of a crop arrives in the same engine call, so the VSM can score
+        # the crop once with one suffix block per target (vsm._score_boxes_grouped); plain engines just see mixed-prompt batches
+        plans = [sc.plan(root, PriorityQueue()) for sc in scorers]
+        pairs = [(sc, b) for k in range(max(map(len, plans))) for sc, pl in zip(scorers, plans) if k < len(pl) for b in [pl[k]]]
+        T = len(scorers)
+        step = max(1, scorers[0].batch_size // T) * T
         for i0 in range(0, len(pairs), step):
             chunk = pairs[i0:i0 + step]
             boxes = [b for _, b in chunk]

@@ -217,6 +217,10 @@ class VSM:
     supports_deferred_mismatch = True
 
     @property
+    def supports_device_reductions(self) -> bool:
+        return hasattr(self.engine, "heatmap_stats")
+
+    @property
     def supports_gpu_preprocess(self) -> bool:
         return hasattr(self.engine, "score_boxes") and hasattr(self.engine, "set_image")
 
@@ -256,7 +260,9 @@ class VSM:
         def score_chunk(sel, out_dev):
             kw = {"out_dev": out_dev} if out_dev is not None else {}
             return self.engine.score_boxes(xyxy[sel], ids_rows[sel], loc_rows[sel], verify_pos=ver_rows[sel], raw=True, **kw)
-        records = self._score_sharded(n, score_chunk)
+        records = self._score_boxes_grouped(xyxy, qs, per_q, nv) if self.group_prompts else None
+        if records is None:
+            records = self._score_sharded(n, score_chunk)
         res = self.engine.unpack(records, nv)
         self.last_template_ok = (res["tf_argmax"] == tok_rows).all(axis=1)
         out: List = []
@@ -273,6 +279,89 @@ class VSM:
         self._handle_mismatches(out, lambda b: self._image.crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
                                 defer_mismatch)
         return out
+
+    group_prompts = True     # several prompts on the same crop share the LLaMA prefix (vstar_vsm_score_grouped); False = plain batches
+
+    def _score_boxes_grouped(self, xyxy: np.ndarray, qs: List[str], per_q: dict, nv: int) -> Optional[np.ndarray]:
+        """Multi-target batches (visual_search_many scores the same crops for several targets): every crop that appears with
+        T >= 2 distinct prompts is scored ONCE through the vision towers and the shared positions of the LLaMA sequence — system
+        prompt, image tokens and the common start of the question — plus one 32-row suffix block per prompt
+        (engine.score_grouped).  Returns the records in the caller's order, or None when the batch does not qualify (single
+        prompt, suffix longer than 32 tokens, a process group that shards crops, an engine without the entry point)."""
+        if not hasattr(self.engine, "score_grouped") or self._dist()[0] > 1:
+            return None
+        uq = list(per_q)
+        if len(uq) < 2:
+            return None
+        seqs = [list(map(int, per_q[q][0])) for q in uq]
+        lcp = 0
+        while all(lcp < len(sq) for sq in seqs) and len({sq[lcp] for sq in seqs}) == 1:
+            lcp += 1
+        if IMAGE_TOKEN_INDEX not in seqs[0][:lcp]:
+            return None
+        P = self.cfg.n_img_tokens
+        Lc = lcp - 1 + P                                            # shared spliced positions
+        Ls = max(len(sq) - lcp for sq in seqs)
+        info = {}
+        for q, sq in zip(uq, seqs):
+            _, loc_pos, ver_pos, _ = per_q[q]
+            loc_in, ver_in = loc_pos - Lc, [v - Lc for v in ver_pos[-nv:]]
+            if Ls > 32 or loc_in < 0 or min(ver_in, default=0) < 0:
+                return None
+            info[q] = (sq[lcp:] + [0] * (Ls - (len(sq) - lcp)), loc_in, ver_in)
+        # crops -> the prompts they are scored for (in first-seen order); group crops with the same prompt tuple
+        by_box: dict = {}
+        for i, (b, q) in enumerate(zip(map(tuple, xyxy.tolist()), qs)):
+            by_box.setdefault(b, {}).setdefault(q, []).append(i)
+        by_tuple: dict = {}
+        for b, d in by_box.items():
+            by_tuple.setdefault(tuple(d), []).append(b)
+        if all(len(t) < 2 for t in by_tuple):
+            return None
+        records = np.zeros((len(qs), RESULT_FLOATS), np.float32)
+        prefix = np.asarray(seqs[0][:lcp], np.int32)
+        mb = self.cfg.max_batch
+        single: List[int] = []
+        for qt, boxes in by_tuple.items():
+            T = len(qt)
+            if T < 2 or T > mb:
+                single += [i for b in boxes for q in qt for i in by_box[b][q]]
+                continue
+            per_call = max(1, mb // T)
+            suf = np.asarray([info[q][0] for q in qt], np.int32)
+            loc_in = np.asarray([info[q][1] for q in qt], np.int32)
+            ver_in = np.asarray([info[q][2] for q in qt], np.int32).reshape(T, nv)
+            for c0 in range(0, len(boxes), per_call):
+                chunk = boxes[c0:c0 + per_call]
+                G = len(chunk)
+                t1 = time.perf_counter()
+                _lib_boxes = np.asarray(chunk, np.int32)
+                self.engine.preprocess_boxes(_lib_boxes)
+                rec = self.engine.score_grouped(None, None, prefix, np.tile(suf[None], (G, 1, 1)), np.tile(loc_in[None], (G, 1)),
+                                                np.tile(ver_in[None], (G, 1, 1)) if nv else None, raw=True, internal_pixels=True)
+                self.timers["engine_s"] += time.perf_counter() - t1
+                self.timers["crops"] += G * T
+                self.timers["grouped_records"] = self.timers.get("grouped_records", 0) + G * T
+                for gi, b in enumerate(chunk):
+                    for t, q in enumerate(qt):
+                        for i in by_box[b][q]:
+                            records[i] = rec[gi * T + t]
+        if single:
+            single = sorted(single)
+            sel_all = np.asarray(single)
+            ids_rows = np.zeros((len(single), max(len(per_q[qs[i]][0]) for i in single)), np.int32)
+            for k, i in enumerate(single):
+                ids = per_q[qs[i]][0]
+                ids_rows[k, :len(ids)] = ids
+            for s0 in range(0, len(single), mb):
+                sl = slice(s0, s0 + mb)
+                idx = sel_all[sl]
+                t1 = time.perf_counter()
+                records[idx] = self.engine.score_boxes(xyxy[idx], ids_rows[sl], np.asarray([per_q[qs[i]][1] for i in idx], np.int32),
+                                                       verify_pos=np.asarray([per_q[qs[i]][2][-nv:] for i in idx], np.int32), raw=True)
+                self.timers["engine_s"] += time.perf_counter() - t1
+                self.timers["crops"] += len(idx)
+        return records
 
     def heatmap_stats(self, low_res, h: int, w: int, rects_xywh=None) -> np.ndarray:
         """On-device decision statistics of a heat map (no full-resolution materialisation)."""
