@@ -93,7 +93,9 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
-        vsm.shard_crops = False                  # each rank searches its own image (weak scaling, no collective in this leg)
+        # each rank searches its own image (weak scaling, no collective in this leg); --rccl-selfcheck turns the product's
+        # device-record all-gather on (VSM._score_sharded over the one-rank nccl group)
+        vsm.shard_crops = bool(getattr(args, "rccl_selfcheck", False))
         vsm.group_prompts = group                # False: every (crop, target) pair is a full pass, like the reference's loop
         smallest = smallest_size_for(W, H, scale)
         names = [f"object {i}" for i in range(args.search_targets)]
@@ -187,6 +189,8 @@ def main():
     ap.add_argument("--no-search-leg", action="store_true", help="skip the end-to-end search leg (N = 1 only by default)")
     ap.add_argument("--config5", action="store_true", help="BASELINE config 5 as specified: W8A8 fp8 LLaMA linears, 64-crop batches, and the "
                     "search leg on an 8K synthetic image with --minimum_size_scale 16 (depth-5 tree); separate line, not the headline")
+    ap.add_argument("--rccl-selfcheck", action="store_true", help="N = 1 only: join a ONE-rank nccl (= RCCL) process group and run the N > 1 "
+                    "code path — per-step all_gather_into_tensor of the device records, barrier, max-over-ranks — on the single GPU")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
@@ -207,8 +211,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_group = world > 1 or args.rccl_selfcheck
+    if use_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
 
@@ -240,14 +246,14 @@ def main():
         _lib.check(eng.lib.vstar_vsm_score_batch(
             eng.handle, B, vp(clip.data_ptr()), vp(owl.data_ptr()), ids.ctypes.data_as(vp), L, loc.ctypes.data_as(vp),
             verify.ctypes.data_as(vp), nv, flags, vp(rec_dev.data_ptr())), eng.handle)   # synchronises the engine stream
-        if world > 1:
+        if use_group:
             out = torch.empty((world * B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(out, rec_dev)
             return out
         return rec_dev
 
     def fence():
-        if world > 1:
+        if use_group:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -259,7 +265,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_group:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -333,12 +339,12 @@ def main():
                        "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
                        "flops_per_crop": per_crop, "weights_load_s": round(t_load, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "search": search, "search_grouped": search_grouped,
-            "world_size": world, "collective": None if world == 1 else {
+            "world_size": world, "collective": None if not use_group else {
                 "backend": dist.get_backend() + " (RCCL over xGMI)", "op": "all_gather_into_tensor of the per-crop result records, once per step",
                 "bytes_per_rank_per_step": int(B * _lib.RESULT_FLOATS * 4), "ranks": dist.get_world_size()},
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_group:
         dist.destroy_process_group()
 
 

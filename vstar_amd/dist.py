@@ -25,9 +25,9 @@ def pad_count(n_items: int, world: int) -> int:
 def allgather_records(local: torch.Tensor, n_items: int, group=None) -> torch.Tensor:
     """local: [pad_count, R] records of this rank's shard (rows beyond the shard are padding).  Returns [n_items, R]
     in the ORIGINAL item order on every rank."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local[:n_items]
+    world = dist.get_world_size(group)          # a one-rank group still runs the collective (RCCL self-check on one GPU)
     per = local.shape[0]
     gathered = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)
@@ -51,8 +51,9 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("VSTAR_FORCE_PROCESS_GROUP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}

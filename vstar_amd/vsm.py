@@ -122,7 +122,9 @@ class VSM:
         mine = shard_indices(n, rank, world)
         per = pad_count(n, world)
         mb = self.cfg.max_batch
-        on_device = world > 1 and dist.get_backend() == "nccl"
+        # a group of ONE nccl rank (bench.py --rccl-selfcheck, tests) still takes the device path: same code as N > 1
+        grouped = self.shard_crops and dist.is_available() and dist.is_initialized()
+        on_device = grouped and dist.get_backend() == "nccl"
         if on_device:
             local = torch.zeros((per, RESULT_FLOATS), dtype=torch.float32, device=f"cuda:{self.engine.device}")
         else:
@@ -137,10 +139,10 @@ class VSM:
             self.timers["engine_s"] += time.perf_counter() - t1
             self.timers["crops"] += len(sel)
         t2 = time.perf_counter()
-        if world == 1:
-            records = local[:n]
-        elif on_device:
+        if on_device:
             records = allgather_records(local, n).cpu().numpy()
+        elif world == 1:
+            records = local[:n]
         else:
             records = allgather_numpy(local, n, device="cpu")
         self.timers["gather_s"] += time.perf_counter() - t2
