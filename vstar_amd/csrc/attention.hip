@@ -15,9 +15,10 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include <cstdlib>
+#include <type_traits>
 
-#ifndef ATTN_KT
-#define ATTN_KT 64          // keys per LDS tile: 64 (2-deep ring) or 32 (4-deep ring, same LDS bytes, DMA three tiles ahead)
+#ifndef ATTN_EARLY_V
+#define ATTN_EARLY_V(D) ((D) == 128)
 #endif
 
 namespace VS_NS {
@@ -66,16 +67,15 @@ __global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos
 // V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
 template <int D, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ out, int S, int H,
-                                                    float scale_log2e, int grp_R0, int grp_Lc) {
+                                                    float scale_log2e, int grp_R0, int grp_Lc, int nqb) {
   // Grouped sequences (causal only; grp_R0 > 0): rows [0, grp_Lc) are a SHARED prefix, rows [grp_R0, S) are independent 32-row
   // suffix blocks (one per search target) that each attend to the shared prefix and, causally, to themselves — the prefill of
   // T prompts that share their first grp_Lc tokens, with the prefix's K/V computed once (engine.hip::score_grouped).  A query
   // block inside the suffix region walks the prefix's key tiles (keys >= grp_Lc masked) and then its own 128 rows, where wave w
   // only looks at its own 32-row sub-tile.
   constexpr int KS = D / 16, DB = D / 32;
-  constexpr int KT = ATTN_KT;                       // keys per tile
+  constexpr int KT = 64;                            // keys per tile (32 with a 4-deep ring of the same bytes measured no better)
   constexpr int NBUF = 128 / KT;                    // ring depth (the ring always holds 128 keys of K and of V)
-  constexpr int PD = NBUF - 1;                      // tiles requested ahead of the one being computed
   constexpr int KBYTES = KT * D * 2;                // K tile = V tile bytes
   constexpr int KCH = D / 8;                        // 16-B chunks per K row
   constexpr int KROWS_PER_INST = 64 / KCH;          // K rows covered by one wave-wide DMA instruction
@@ -86,9 +86,21 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware block order (1-D grid; the hardware deals workgroup L to XCD L % 8): each XCD gets a CONTIGUOUS range of
+  // (sequence, head, query-block) triples with the query block fastest, so the query blocks of one head — which all walk the
+  // same K/V rows — run next to each other on ONE XCD and share its L2 instead of fetching K/V into up to eight L2s.
+  int h, b, qblk;
+  {
+    const int total = (int)gridDim.x, L = (int)blockIdx.x;
+    const int per = total >> 3, rem = total & 7, x = L & 7;
+    const int v = (x < rem ? x * (per + 1) : rem * (per + 1) + (x - rem) * per) + (L >> 3);
+    qblk = v % nqb;
+    const int hb = v / nqb;
+    h = hb % H;
+    b = hb / H;
+  }
   // causal: the last query block has the most key tiles — launch the heavy blocks first so the tail of the grid is light
-  const int q0b = (CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * 128;
+  const int q0b = (CAUSAL ? nqb - 1 - qblk : qblk) * 128;
   const int q0 = q0b + wave * 32;
   const bool active = q0 < S;
   const int qi = lane & 31, h2 = lane >> 5;
@@ -150,117 +162,156 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const int tr_gq = (D == 64) ? ((t16 >> 3) & 1) : (t16 >> 2);      // g(key) of this lane's key row (key0 % 4 == 0)
   const int tr_off = ((t16 >> 2) + 4 * h2) * (D * 2) + (2 * g16 + ((t16 & 3) >> 1)) * 16 + (t16 & 1) * 8;
 
+  // Q fragments, PRE-SCALED by scale*log2(e) (rounded to the storage type once): the QK^T accumulator then already holds the
+  // scores in exp2 units, and with the running reference max handed to the MFMA as its C operand (negm, 16 registers all equal
+  // to -m) the accumulator comes out as s - m — no per-score multiply/subtract on the VALU.
   const lp_t* Qp = qkv + ((int64_t)b * S + qrow) * ld + h * D + h2 * 8;
   lpx8 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const lpx8*)(Qp + ks * 16);
+  for (int ks = 0; ks < KS; ++ks) {
+    const lpx8 raw = *(const lpx8*)(Qp + ks * 16);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[ks][e] = (short)f2lp(lp2f((lp_t)raw[e]) * scale_log2e);
+  }
   f32x16 oacc[DB];
 #pragma unroll
   for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m = -1e30f, l = 0.f;
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+  float m = 0.f, l = 0.f;          // l: this lane's partial row sum (its 16 of every 32 keys); the lane^32 halves are added at the end
+  bool first = true;               // wave-uniform: the first sub-tile a wave computes fixes m to a TRUE row maximum
 
   const int kend = CAUSAL ? min(S, q0b + 128) : S;
   const int nkt = sfx ? nsh + (kend - q0b + KT - 1) / KT : (kend + KT - 1) / KT;
   const int kswz = (D == 64) ? ((qi >> 1) & 7) : (qi & 15);   // key row = st*32 + qi: the st*32 term leaves both swizzles unchanged
+  // per-lane LDS byte offsets inside a ring slot (everything else of an address is a compile-time immediate: the key loop is
+  // unrolled over the ring slots and the two 32-key sub-tiles of a tile)
+  int koff[KS], voff[DB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) koff[ks] = qi * (D * 2) + (((ks * 2 + h2) ^ kswz) * 16);
+#pragma unroll
+  for (int db = 0; db < DB; ++db) voff[db] = (int)(uintptr_t)(lptr_t)smem + KBYTES + tr_off + ((db ^ tr_gq) * 64);
 
-  // ONE barrier per tile: after it every wave has (a) seen its share of tile t land (counted vmcnt: only the PD-1 younger tiles
-  // may still be in flight) and (b) finished computing tile t-1, whose ring slot the tile requested next (t + PD) reuses.
-  // (Two barriers per tile parked the waves 43 % of the time, rocprofv3 SQ_WAIT_ANY.)
+  auto subtile = [&](auto SLOT_, auto ST_, int t) {
+    constexpr int SLOT = decltype(SLOT_)::value, st = decltype(ST_)::value;
+    constexpr int SBASE = SLOT * 2 * KBYTES + st * 32 * (D * 2);
+    const int kt0 = key0(t) + st * 32;
+    const bool shared_tile = sfx && t < nsh;                // prefix keys seen from a suffix block: no causal mask, limit grp_Lc
+    const int klimit = shared_tile ? grp_Lc : S;
+    if (kt0 >= (shared_tile ? grp_Lc : kend)) return;
+    if (sfx && !shared_tile && kt0 != q0) return;           // suffix block: of its own 128 rows a wave sees only its 32
+    if (CAUSAL && !shared_tile && kt0 > q0 + 31) return;    // wave-uniform: sub-tile entirely above the diagonal
+    // ---- S^T - m = K . Q'^T + (-m) ----
+    f32x16 sacc = negm;
 #pragma unroll
-  for (int i = 0; i < PD; ++i)
-    if (i < nkt) stage(i);
-  for (int t = 0; t < nkt; ++t) {
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int younger = min(nkt - 1, t + PD - 1) - t;      // tiles requested after tile t so far (block-uniform)
-      constexpr int PER = 2 * K_INST;                         // DMA instructions per tile per wave (K + V)
-      if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(2 * PER) : "memory");
-      else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int ks = 0; ks < KS; ++ks) {
+      const lpx8 kf = *(const lpx8*)(smem + koff[ks] + SBASE);
+      sacc = mfma_32x32x16(kf, qf[ks], sacc);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + PD < nkt) stage(t + PD);
-    const char* kb = smem + (t % NBUF) * 2 * KBYTES;
-    const char* vb = kb + KBYTES;
-    if (active) {
-#pragma unroll 1
-      for (int st = 0; st < KT / 32; ++st) {
-        const int kt0 = key0(t) + st * 32;
-        const bool shared_tile = sfx && t < nsh;                // prefix keys seen from a suffix block: no causal mask, limit grp_Lc
-        const int klimit = shared_tile ? grp_Lc : S;
-        if (kt0 >= (shared_tile ? grp_Lc : kend)) continue;
-        if (sfx && !shared_tile && kt0 != q0) continue;         // suffix block: of its own 128 rows a wave sees only its 32
-        if (CAUSAL && !shared_tile && kt0 > q0 + 31) continue;  // wave-uniform: sub-tile entirely above the diagonal
-        // ---- S^T = K . Q^T ----
-        f32x16 sacc;
+    // V operand fragments of this sub-tile: keys 16j + 4*h2 + {0..3} (lo) and 16j + 8 + 4*h2 + {0..3} (hi) — the keys whose
+    // probabilities this lane will hold in pb — by ds_read_b64_tr_b16 as INLINE ASM: the compiler guards its own builtin for
+    // that instruction with `s_waitcnt vmcnt(0)` (it cannot tell the ring slot being read from the slot the in-flight LDS-DMA
+    // of the NEXT tile writes), which made every tile wait for its successor's prefetch.  EARLY_V issues the reads before the
+    // softmax so that they fly under it (8 * DB more live registers).
+    s4_t vlo[2][DB], vhi[2][DB];
+#define ATTN_V_READS()                                                                                                         \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int db = 0; db < DB; ++db) {                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[j][db]) : "v"(voff[db]), "i"(SBASE + 16 * j * (D * 2)));       \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[j][db]) : "v"(voff[db]), "i"(SBASE + (16 * j + 8) * (D * 2))); \
+  }
+    constexpr bool EARLY_V = ATTN_EARLY_V(D);
+    if constexpr (EARLY_V) { ATTN_V_READS() }
+    // this lane: query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2
+    const bool causal_here = CAUSAL && !shared_tile;
+    const bool need_mask = (kt0 + 32 > klimit) || (causal_here && kt0 + 31 > q0);
+    if (need_mask) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        const char* krow = kb + (st * 32 + qi) * (D * 2);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const lpx8 kf = *(const lpx8*)(krow + (((ks * 2 + h2) ^ kswz) * 16));
-          sacc = mfma_32x32x16(kf, qf[ks], sacc);
-        }
-        // ---- online softmax (this lane: query column `query`, keys kt0 + (r&3) + 8*(r>>2) + 4*h2) ----
-        // The running reference max m is only raised when some row's tile max exceeds it by more than RESCALE_THR
-        // (log2 units): exp2(s - m) then stays <= 2^THR, harmless for the fp32 row sum and for bf16 P (relative
-        // precision), and the O/l rescale (the widest VALU block) becomes rare instead of per-tile.
-        constexpr float RESCALE_THR = 6.0f;
-        float p[16];
-        float mx = -1e30f;
-        const bool causal_here = CAUSAL && !shared_tile;
-        const bool need_mask = (kt0 + 32 > klimit) || (causal_here && kt0 + 31 > q0);
-        if (need_mask) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
-            const bool masked = (key >= klimit) || (causal_here && key > query);
-            sacc[r] = masked ? -1e30f : sacc[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2e;       // scale > 0: max commutes with the scaling
-        if (__any(mx > m + RESCALE_THR)) {                            // wave-uniform
-          const float m_new = fmaxf(m, mx);
-          const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-          l *= alpha;
-          m = m_new;
-#pragma unroll
-          for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-        }
-        float rs = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          p[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], scale_log2e, -m));               // masked: exp2(-1e30*c - m) = 0
-          rs += p[r];
-        }
-        rs += __shfl_xor(rs, 32, 64);
-        l += rs;
-        // ---- O^T += V^T . P^T ----
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          lpx8 pb;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) pb[i] = (short)f2lp(p[8 * j + i]);
-#pragma unroll
-          for (int db = 0; db < DB; ++db) {
-            // keys 16j + 4*h2 + {0..3} and 16j + 8 + 4*h2 + {0..3} of sub-tile st (the keys whose probabilities this lane
-            // holds in pb): two transpose reads
-            const char* a0 = vb + (st * 32 + 16 * j) * (D * 2) + tr_off + ((db ^ tr_gq) * 64);
-            const s4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)a0);
-            const s4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t)(a0 + 8 * (D * 2)));
-            const lpx8 vf = (lpx8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            oacc[db] = mfma_32x32x16(vf, pb, oacc[db]);
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + (r & 3) + 8 * (r >> 2) + 4 * h2;
+        const bool masked = (key >= klimit) || (causal_here && key > query);
+        sacc[r] = masked ? -1e30f : sacc[r];
       }
     }
+    // ---- online softmax against the STALE reference m: p = exp2(s - m) straight from the accumulator.  m is only touched on
+    // the slow path: the wave's first sub-tile (m := true row max, so the final row sum is >= 1) and whenever some row's
+    // probabilities outgrow 2^16 (m := new row max, history rescaled).  exp2 stays finite below that, P is bf16 (relative
+    // precision) and l / O are fp32, so nothing else depends on how stale m is.
+    constexpr float BIG = 65536.0f;
+    float p[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(sacc[r]);
+      rs += p[r];
+    }
+    if (first || __any(!(rs <= BIG))) {                               // wave-uniform
+      float mx = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                         // row max relative to the current m
+      const float delta = first ? fmaxf(mx, -1e4f) : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);             // first: l = O = 0, the factor is irrelevant (and finite)
+      l *= alpha;
+#pragma unroll
+      for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      m += delta;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -m;
+      rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        p[r] = __builtin_amdgcn_exp2f(sacc[r] - delta);               // masked: exp2(-1e30 - delta) = 0
+        rs += p[r];
+      }
+      first = false;
+    }
+    l += rs;
+    if constexpr (!EARLY_V) { ATTN_V_READS() }
+#undef ATTN_V_READS
+    // the transpose reads are invisible to the compiler's lgkmcnt bookkeeping: wait for them here (in-order counter)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int db = 0; db < DB; ++db) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[j][db]), "+v"(vhi[j][db]));
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      lpx8 pb;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pb[i] = (short)f2lp(p[8 * j + i]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const lpx8 vf = (lpx8){vlo[j][db][0], vlo[j][db][1], vlo[j][db][2], vlo[j][db][3],
+                               vhi[j][db][0], vhi[j][db][1], vhi[j][db][2], vhi[j][db][3]};
+        oacc[db] = mfma_32x32x16(vf, pb, oacc[db]);
+      }
+    }
+  };
+
+  // ONE barrier per tile: after it every wave has (a) seen its share of tile t land (vmcnt(0): tile t's DMA is the youngest
+  // request) and (b) finished computing tile t-1, whose ring slot the tile requested next (t + 1) reuses.
+  // (Two barriers per tile parked the waves 43 % of the time, rocprofv3 SQ_WAIT_ANY.)
+  auto tile = [&](auto SLOT_, int t) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < nkt) stage(t + 1);
+    if (active) {
+      subtile(SLOT_, std::integral_constant<int, 0>{}, t);
+      subtile(SLOT_, std::integral_constant<int, 1>{}, t);
+    }
+  };
+  stage(0);
+  for (int t = 0; t < nkt; t += 2) {
+    tile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nkt) tile(std::integral_constant<int, 1>{}, t + 1);
   }
+  l += __shfl_xor(l, 32, 64);
 
   if (active && query < S) {
     const float inv = 1.0f / l;
@@ -438,8 +489,9 @@ static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, 
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  dim3 grid((S + 127) / 128, H, B);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl, grp_R0, grp_Lc);
+  const int nqb = (S + 127) / 128;
+  dim3 grid((unsigned)(nqb * H * B));
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl, grp_R0, grp_Lc, nqb);
   return hipGetLastError();
 }
 
