@@ -216,8 +216,9 @@ enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_E
 int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
                   const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,
                   int M, int N, int K, int epilogue);
-/* Which GEMM kernel the calling thread's last vstar_op_gemm / vstar_op_gemm_fp8 launched: 128, 256, or 0 (nothing launched).
- * Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */
+/* Which GEMM kernel the calling thread's last vstar_op_gemm / vstar_op_gemm_fp8 launched: 128, 256, 384 (= 256 + 128: whole
+ * rounds of 256x256 tiles over the leading rows and the ragged last round's rows as 128x128 tiles — bit-identical to either
+ * kernel alone), or 0 (nothing launched).  Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */
 int vstar_op_gemm_last_tile(void);
 /* W8A8 GEMM (BASELINE config 5: fp8 weights on the CDNA4 fp8 MFMA), op level, all pointers DEVICE pointers: quantises the
  * rows of A [M,K] (per token) and of W [ceil(N/256)*256, K] (per output channel) to OCP fp8 e4m3 with scale = absmax/448,

@@ -34,7 +34,7 @@ def _gemm(lib, a, w, bias=None, res=None, epi=0, f32=False, n=None, tile=0):
                            1 if f32 else 0, M, N, K, epi | flag)
     assert rc == 0, lib.vstar_last_error(None)
     ran = lib.vstar_op_gemm_last_tile()
-    assert ran in (128, 256)
+    assert ran in (128, 256, 384)
     if tile:
         assert ran == tile, f"asked for the {tile}^2 kernel, the {ran}^2 kernel ran"
     torch.cuda.synchronize()
@@ -273,6 +273,28 @@ def test_gemm_tile_override_contract(lib, cuda):
     assert lib.vstar_op_gemm_last_tile() == 256
     _gemm(lib, big_a[:1200], big_w[:384])
     assert lib.vstar_op_gemm_last_tile() == 128
+
+
+@pytest.mark.parametrize("M,N,K,epi,use_bias,use_res,f32,split", [
+    (18464, 1024, 256, 0, True, True, False, True),      # CLIP out-proj / fc2 form: 292 tiles = 1 round + 36 on 256 CUs -> split
+    (73760, 2304, 128, 1, True, False, False, True),     # OWL qkv width with QUICK_GELU: 10 rounds + 41 tiles -> split
+    (18464, 3072, 128, 0, False, True, False, False),    # CLIP qkv width: the tail would need two rounds of 128^2 tiles -> no split
+    (18464, 1024, 256, 0, True, False, True, True),      # fp32 output through the split
+])
+def test_gemm_ragged_round_split_is_bit_identical(lib, cuda, M, N, K, epi, use_bias, use_res, f32, split):
+    """Dispatcher default on a 256-CU device: a thin last round of 256^2 tiles is replaced by 128^2 tiles over the trailing
+    rows (vstar_op_gemm_last_tile() == 384).  Same K order in both kernels: the result equals the forced single-kernel one."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(cuda)
+    bias = torch.randn(N, generator=g).bfloat16().to(cuda) if use_bias else None
+    res = torch.randn(M, N, generator=g).bfloat16().to(cuda) if use_res else None
+    c = _gemm(lib, a, w, bias, res, epi=epi, f32=f32)
+    ran = lib.vstar_op_gemm_last_tile()
+    c256 = _gemm(lib, a, w, bias, res, epi=epi, f32=f32, tile=256)
+    assert torch.equal(c, c256)
+    if torch.cuda.get_device_properties(0).multi_processor_count == 256:
+        assert ran == (384 if split else 256), ran
 
 
 @pytest.mark.parametrize("M,N,K,epi,use_bias,use_res,f32", [

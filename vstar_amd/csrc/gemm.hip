@@ -202,7 +202,39 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
     const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const bool prefer128 = force != 256 && !p.rope_cs && !p.a_scale && t256 < cus &&
                            0.36 * (double)((t128 + cus - 1) / cus) < (double)((t256 + cus - 1) / cus);
-    if (!prefer128) { t_last_tile = 256; return gemm256_lp(p, epilogue, out_f32, s); }
+    if (!prefer128) {
+      // Ragged last round (e.g. CLIP out-proj / fc2: 18464 x 1024 = 292 tiles = one full round + 36 tiles on 256 CUs): when the
+      // 256^2 grid ends with a thinly filled round, the rows of that round go to the 128^2 kernel instead — whole rounds of
+      // 256^2 tiles over the leading rows, then the trailing rows as ONE round of 128^2 tiles (CLIP fc2 172 -> 155 us, out-proj
+      // 65 -> 60 us; with two or more 128^2 rounds the split measured no better than the ragged round).  Bit-identical
+      // to the unsplit launch (same K order in both kernels).  Only for identity row maps (the tail is addressed by pointer
+      // offset) and without fused RoPE / W8A8 (row-indexed side inputs).
+      const int64_t rt = (p.M + 255) / 256, ct = (p.N + 255) / 256;
+      const int64_t full = t256 / cus, rem = t256 - full * cus;
+      static const bool env_split = [] { const char* e = getenv("VSTAR_GEMM_SPLIT"); return !e || atoi(e) != 0; }();   // A/B runs
+      const bool split_ok = env_split && force == 0 && p.a_group <= 0 && p.c_group <= 0 && !p.rope_cs && !p.a_scale && !p.debug_flags;
+      if (split_ok && full >= 1 && rem > 0) {
+        const int64_t rt1 = full * cus / ct;                       // leading row tiles: at most `full` rounds of 256^2 tiles
+        const int64_t M1 = rt1 * 256, M2 = p.M - M1;
+        const int64_t t128b = ((M2 + 127) / 128) * ((p.N + 127) / 128);
+        if (rt1 >= 4 && rt1 < rt && M2 > 0 && t128b <= cus) {      // ONE round of 128^2 tiles (measured: two rounds no longer pay)
+          GemmParams a = p, b = p;
+          a.M = (int)M1;
+          b.M = (int)M2;
+          b.A = p.A + M1 * p.lda;
+          b.C = out_f32 ? (void*)((float*)p.C + M1 * p.ldc) : (void*)((lp_t*)p.C + M1 * p.ldc);
+          if (p.res) b.res = p.res + M1 * p.ldr;
+          b.tile_force = 128;
+          hipError_t e = gemm256_lp(a, epilogue, out_f32, s);
+          if (e != hipSuccess) return e;
+          e = gemm_lp(b, epilogue, out_f32, s);
+          t_last_tile = 256 + 128;                                 // observable: split launch
+          return e;
+        }
+      }
+      t_last_tile = 256;
+      return gemm256_lp(p, epilogue, out_f32, s);
+    }
   }
   if (p.rope_cs || p.a_scale) return hipErrorInvalidValue;   // fused RoPE / W8A8 exist only in the 256^2 kernel: callers check gemm256_eligible
   t_last_tile = 128;
