@@ -172,6 +172,36 @@ def test_attention(lib, cuda, B, S, H, D, causal, theta):
         assert (out.float().cpu() - ref2).abs().max().item() < 3e-2
 
 
+@pytest.mark.parametrize("S,H,D,causal", [(577, 2, 64, 0), (640, 2, 128, 1), (200, 1, 128, 1)])
+@pytest.mark.parametrize("profile", ["ascending", "descending", "all_very_negative", "sawtooth"])
+def test_attention_softmax_dynamic_range(lib, cuda, S, H, D, causal, profile):
+    """The kernel subtracts a STALE running maximum (handed to the QK^T MFMA as its C operand) and only re-centres on a slow
+    path: a wave's first sub-tile, and whenever a probability outgrows 2^16.  These score profiles drive that path hard:
+    scores that climb by e^90 along the keys (re-centring in every tile), that fall by as much (later tiles underflow),
+    that sit at -300 everywhere (the first sub-tile must anchor m to a true maximum or the row sum underflows), and a sawtooth."""
+    g = torch.Generator().manual_seed(S + D + len(profile))
+    x = (0.1 * torch.randn(1, S, 3, H, D, generator=g))
+    j = torch.arange(S, dtype=torch.float32)
+    ramp = {"ascending": 90.0 * j / S, "descending": 90.0 * (1 - j / S), "all_very_negative": torch.full((S,), -300.0),
+            "sawtooth": 40.0 * ((j % 97) / 97.0) + 30.0 * (j // 97 % 2)}[profile]
+    x[0, :, 0, :, 0] = math.sqrt(D)                        # q[:, 0] = sqrt(D): score(i, j) = k[j, 0] + small noise
+    x[0, :, 1, :, 0] = ramp[:, None]
+    x[0, :, 2] = torch.randn(S, H, D, generator=g)         # V unit variance
+    qkv = x.view(S, -1).bfloat16()
+    ref = _attn_ref(qkv, 1, S, H, D, causal, 0.0)
+    out = torch.full((S, H * D), float("nan"), dtype=torch.bfloat16, device=cuda)
+    ws_bytes = lib.vstar_op_attention_workspace(1, S, H, D)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    rc = lib.vstar_op_attention(None, P(qkv.to(cuda)), P(out), P(ws), ws_bytes, 1, S, H, D, causal, 0.0)
+    assert rc == 0, lib.vstar_last_error(None)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    # the pre-scaled q (bf16) moves a score of magnitude 90 by ~0.15; a CPU emulation of the kernel's rounding points lands at
+    # 5e-3 relative on these profiles — gate at the plain test's tolerance
+    assert (o - ref).abs().max().item() < 6e-2
+    assert _rel(o, ref) < 3e-2
+
+
 # ---- the 256x256 8-phase kernel (M >= 1024, N >= 256, K % 128 == 0): tails, long K, epilogues, race screen ----
 @pytest.mark.parametrize("M,N,K", [(1024, 256, 128), (1500, 768, 256), (1030, 300, 384), (2048, 512, 11008),
                                    (20480, 1024, 4096), (1300, 4096, 1024)])

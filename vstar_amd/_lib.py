@@ -31,7 +31,7 @@ EXPORTS_VQA = [
 F32, F16, BF16 = 0, 1, 2
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
 EPI_NOSYNC, EPI_TILE128, EPI_TILE256 = 0x100, 0x200, 0x400
-F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS = 1, 2, 4, 8, 16
+F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS, F_SHARE_PREFIX = 1, 2, 4, 8, 16, 32
 
 
 class VstarResult(ctypes.Structure):

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
       for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                         // row max relative to the current m
       const float delta = first ? fmaxf(mx, -1e4f) : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);             // first: l = O = 0, the factor is irrelevant (and finite)
+      const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);   // first: l = O = 0 (and exp2(-delta) may overflow: 0 * inf)
       l *= alpha;
 #pragma unroll
       for (int db = 0; db < DB; ++db)

@@ -82,6 +82,17 @@ __global__ void add_bcast_kernel(const lp_t* __restrict__ a, const lp_t* __restr
 }
 
 // grouped scoring: every crop's block of rows_per rows, plus the broadcast row b, repeated for the rep prompts of that crop
+__global__ void bcast_rows_kernel(const lp_t* __restrict__ src, lp_t* __restrict__ dst, int nrep, int64_t rep_stride, int nrows, int cv,
+                                  int64_t ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)nrows * cv;
+  if (idx >= per * nrep) return;
+  const int r = (int)(idx / per);
+  const int64_t rem = idx - (int64_t)r * per;
+  const int i = (int)(rem / cv), c = (int)(rem - (int64_t)i * cv);
+  *(lpx8*)(dst + ((int64_t)r * rep_stride + i) * ld + c * 8) = *(const lpx8*)(src + (int64_t)i * ld + c * 8);
+}
+
 __global__ void add_bcast_repeat_kernel(const lp_t* __restrict__ a, const lp_t* __restrict__ b, lp_t* __restrict__ out, int n_out,
                                         int rep, int rows_per, int cols) {
   const int cv = cols >> 3;
@@ -182,6 +193,13 @@ hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int 
   hipLaunchKernelGGL(add_bcast_kernel, dim3(nblk(rows * (cols / 8))), dim3(256), 0, s, a, b, out, rows, cols, b_rows);
   return hipGetLastError();
 }
+hipError_t bcast_rows(const lp_t* src, lp_t* dst, int nrep, int64_t rep_stride, int nrows, int cols, int64_t ld, hipStream_t s) {
+  if (cols % 8 || nrep <= 0 || nrows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3(nblk((int64_t)nrep * nrows * (cols / 8))), dim3(256), 0, s, src, dst, nrep, rep_stride, nrows,
+                     cols / 8, ld);
+  return hipGetLastError();
+}
+
 hipError_t add_bcast_repeat(const lp_t* a, const lp_t* b, lp_t* out, int n_out, int rep, int rows_per, int cols, hipStream_t s) {
   if (cols % 8 || rep < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(add_bcast_repeat_kernel, dim3(nblk((int64_t)n_out * rows_per * (cols / 8))), dim3(256), 0, s, a, b, out, n_out, rep,

@@ -3,6 +3,7 @@
 // (VisualSearch/model/VSM.py:201-364, 438-553) with the generate() loop collapsed into one teacher-forced prefill
 // (SURVEY.md §7 "hard parts"; the lm_head argmax at the verify positions lets the caller prove the collapse is exact).
 #include "llm_cached.hpp"
+#include <cstring>
 
 namespace {
 struct SamAttn { Lin q, k, v, out; int internal; };
@@ -80,6 +81,7 @@ struct vstar_engine : EngineBase {
                     unsigned flags, vstar_result* out);
   // shared stages of score / score_grouped
   int grp_R0 = 0, grp_Lc = 0;       // grouped-sequence geometry of the LLaMA pass in flight (0 = plain sequences)
+  int psh_Lp = 0;                   // shared-prefix length of the LLaMA pass in flight (VSTAR_F_SHARE_PREFIX; 0 = off)
   int llm_forward(int nseq, int S, int nsel);
   int llm_heads(int nrec, int n_verify);
   int owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_div);
@@ -177,8 +179,9 @@ int vstar_engine::finalize() {
     RC(dalloc(&rope, tab.size()));
     HIPCHK(hipMemcpy(rope, tab.data(), tab.size() * 2, hipMemcpyHostToDevice));
   }
-  const size_t lrows = (size_t)maxB * Smax;
+  const size_t lrows = (size_t)(maxB + 1) * Smax;      // + 1: the shared-prefix sequence (VSTAR_F_SHARE_PREFIX)
   RC(dalloc(&lx, lrows * H));
+  HIPCHK(hipMemset(lx, 0, lrows * H * sizeof(lp_t)));     // rows no call has written yet are still read by the row-wise kernels (shared-prefix slot)
   RC(dalloc(&lh, lrows * H));
   RC(dalloc(&lqkv, lrows * 3 * H));
   RC(dalloc(&latt, lrows * H));
@@ -421,27 +424,60 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
   // kernel; activations are quantised per token right where they are produced (inside the RMSNorm for q|k|v and gate|up,
   // by one pass over the attention output / the SiLU*up product for o_proj and down_proj)
   const bool w8 = c.llm_w8a8 && rows >= 1024;
+  // Shared prefix (VSTAR_F_SHARE_PREFIX, psh_Lp > 0): the first Lp positions of every sequence are the same tokens, so they run
+  // ONCE, as a sequence of their own in the rows [Lp, 2 Lp) of slot `nseq` of the activation buffers.  The linears see the
+  // compact row set {rows [Lp, S) of every sequence} + {the prefix rows} through a periodic row map (group S - Lp, stride S,
+  // offset Lp: the partial last group lands exactly on the prefix rows); row-wise kernels simply run over all buffer rows;
+  // the attention runs unchanged over the full sequences after the prefix's q|k|v rows were copied to the head of each, plus
+  // one small launch for the prefix sequence itself.
+  const int Lp = w8 ? 0 : psh_Lp;
+  const int Sr = S - Lp;
+  const int M = Lp ? nseq * Sr + Lp : rows;             // rows of the linears
+  const int nrows = Lp ? rows + 2 * Lp : rows;          // rows of the row-wise kernels (slot nseq: [0, 2 Lp))
+  const size_t pre = (size_t)rows + Lp;                 // first buffer row of the prefix sequence
+  struct MapGuard {                                      // the row map never outlives this call (early error returns included)
+    vstar_engine* e;
+    ~MapGuard() { e->map_group = 0; }
+  } guard{this};
+  auto set_map = [&](bool on) {
+    map_group = (on && Lp) ? Sr : 0;
+    map_gstride = S;
+    map_off = Lp;
+  };
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
+    set_map(true);
     if (w8) {
       KCHK(rmsnorm_quant_fp8(lx, b.in_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
       RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
       if (!fused_rope) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
     } else {
-      KCHK(rmsnorm_lp(lx, b.in_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
+      KCHK(rmsnorm_lp(lx, b.in_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
       // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
       GemmParams p{};
-      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = rows; p.N = b.qkv.N; p.K = b.qkv.K;
+      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = M; p.N = b.qkv.N; p.K = b.qkv.K;
+      if (Lp) { p.a_group = p.c_group = Sr; p.a_gstride = p.c_gstride = S; p.a_off = p.c_off = Lp; }
       const bool fused = fused_rope && gemm256_eligible(p);
-      if (fused) { p.rope_cs = rope; p.rope_S = S; p.rope_cols = 2 * H; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc; }
+      if (fused) {
+        p.rope_cs = rope; p.rope_S = Lp ? Sr : S; p.rope_cols = 2 * H; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc;
+        if (Lp) { p.rope_pos0 = Lp; p.rope_tail = nseq * Sr; }
+      }
       RC(gemm(p, VSTAR_EPI_NONE, false));
-      if (!fused) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
+      if (!fused) {
+        KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));     // (prefix rows of the sequences: overwritten below)
+        if (Lp) KCHK(attn_prepare(lqkv + pre * 3 * H, rope, 1, Lp, c.llm_heads, 128, stream, 0, 0));
+      }
+    }
+    if (Lp) {
+      KCHK(bcast_rows(lqkv + pre * 3 * H, lqkv, nseq, S, Lp, 3 * H, 3 * H, stream));
+      KCHK(attn_forward(lqkv + pre * 3 * H, latt + pre * H, 1, Lp, c.llm_heads, 128, 1, att_scale, stream, 0, 0));
     }
     KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream, grp_R0, grp_Lc));
     if (i + 1 == c.llm_layers) {
       // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
       // attention is row-wise, so o_proj / MLP run on those gathered rows only (row-wise ops: bit-identical).
       // (W8A8 mode: these few rows stay on the bf16 weights — the weight-bound regime gains nothing from fp8 MFMA.)
+      set_map(false);
       KCHK(gather_rows(latt, d_rowidx, sel_att, nsel, H, stream));
       KCHK(gather_rows(lx, d_rowidx, sel_x, nsel, H, stream));
       RC(lin(sel_att, H, b.o, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
@@ -458,10 +494,10 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       KCHK(quantize_rows_fp8(lact, c.llm_mlp, lq8, c.llm_mlp, lsa, rows, c.llm_mlp, stream));
       RC(lin8(lq8, lsa, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
     } else {
-      RC(lin(latt, H, b.o, lx, H, rows, VSTAR_EPI_NONE, lx, H));
-      KCHK(rmsnorm_lp(lx, b.post_norm, lh, rows, H, c.llm_rms_eps, nullptr, stream));
-      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL));
-      RC(lin(lact, c.llm_mlp, b.down, lx, H, rows, VSTAR_EPI_NONE, lx, H));
+      RC(lin(latt, H, b.o, lx, H, M, VSTAR_EPI_NONE, lx, H));
+      KCHK(rmsnorm_lp(lx, b.post_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
+      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, M, VSTAR_EPI_SILU_MUL));
+      RC(lin(lact, c.llm_mlp, b.down, lx, H, M, VSTAR_EPI_NONE, lx, H));
     }
   }
   return 0;
@@ -632,7 +668,20 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
     RC(gemm(p, VSTAR_EPI_NONE, false));
   }
   KCHK(llm_embed_text(d_ids, L, img_col, P, embed, c.llm_vocab, lx, B, H, stream));
-  RC(llm_forward(B, S, B * (1 + n_verify)));
+  // VSTAR_F_SHARE_PREFIX: the text before <image> (>= 16 tokens, identical in every row, and short enough for the prefix
+  // sequence to sit in [Lp, 2 Lp) of one sequence slot) is computed once; its embeddings are those of sequence 0
+  psh_Lp = 0;
+  if ((flags & VSTAR_F_SHARE_PREFIX) && !c.llm_w8a8 && img_col >= 16 && 2 * img_col <= S) {
+    bool same = true;
+    for (int b = 1; b < B && same; ++b) same = memcmp(ids, ids + (size_t)b * L, (size_t)img_col * 4) == 0;
+    if (same) {
+      psh_Lp = img_col;
+      HIPCHK(hipMemcpyAsync(lx + ((size_t)B * S + psh_Lp) * H, lx, (size_t)psh_Lp * H * sizeof(lp_t), hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  const int frc = llm_forward(B, S, B * (1 + n_verify));
+  psh_Lp = 0;
+  RC(frc);
   RC(llm_heads(B, n_verify));
   if (!skip_owl) RC(owl_heads_sam(opix, B, B, 1));
   return finish_records(B, n_verify, flags, out);

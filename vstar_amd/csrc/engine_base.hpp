@@ -205,8 +205,14 @@ struct EngineBase {
     p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr;
     p.C = C; p.ldc = ldc; p.c_group = 0;
     p.M = M; p.N = L.N; p.K = L.K;
+    if (map_group > 0) {      // row map in force (shared-prefix LLaMA pass): compact row r -> (r / group) * gstride + off + r % group
+      p.a_group = p.c_group = map_group;
+      p.a_gstride = p.c_gstride = map_gstride;
+      p.a_off = p.c_off = map_off;
+    }
     return gemm(p, epi, f32);
   }
+  int map_group = 0; int64_t map_gstride = 0, map_off = 0;
   void collect_profile() {
     if (!profile) return;
     for (size_t i = 0; i + 1 < ev_used; i += 2) {

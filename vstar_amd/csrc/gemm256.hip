@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
             const lpx8 vp = *(const lpx8*)(slab_partner + rl * RSTRIDE + ch * 16);
             int pos = (row < p.M ? row : p.M - 1) % p.rope_S;
             if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);      // grouped sequences
+            if (p.rope_tail > 0) pos = row >= p.rope_tail ? (row < p.M ? row : p.M - 1) - p.rope_tail : pos + p.rope_pos0;   // shared prefix
             const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + ch * 8);
             const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + ch * 8);
             const float sgn = (wc & 1) ? 1.0f : -1.0f;      // first half of the head: x*cos - partner*sin

@@ -26,6 +26,9 @@ struct GemmParams {
   // rope_cs [rope_S, 128] = cos(64)|sin(64) — the rounding points of rope_kernel, one pass over q,k less
   const lp_t* rope_cs; int rope_S; int rope_cols;
   int rope_R0, rope_Lc;   // grouped sequences (see attn_forward): position of row r >= rope_R0 is rope_Lc + ((r - rope_R0) & 31); 0 = off
+  // shared system-prompt prefix (engine.hip::llm_forward): rows [0, rope_tail) are sequences of rope_S rows that START at position
+  // rope_pos0 (their first rope_pos0 positions live once, in the rows from rope_tail on: position = row - rope_tail); 0 = off
+  int rope_pos0, rope_tail;
   // gemm256 only: W8A8 mode (BASELINE config 5).  a_scale != null => A and W point at OCP fp8 e4m3 bytes (lda / K count
   // fp8 elements, K % 256 == 0), a_scale [M] and w_scale [N] are the per-row / per-output-channel dequantisation factors:
   // C = epilogue((A_q · W_q^T) * a_scale[m] * w_scale[n]).  One v_mfma_scale_f32_16x16x128_f8f6f4 (scales 1.0) replaces two
@@ -105,6 +108,9 @@ hipError_t llm_embed_text(const int32_t* ids, int L, int img_col, int P, const l
 hipError_t add_bcast(const lp_t* a, const lp_t* b, lp_t* out, int64_t rows, int cols, int64_t b_rows, hipStream_t s);
 // out[(n * rows_per + p), :] = a[((n / rep) * rows_per + p), :] + b[0, :]  for n < n_out : every block of rows_per rows repeated rep times
 hipError_t add_bcast_repeat(const lp_t* a, const lp_t* b, lp_t* out, int n_out, int rep, int rows_per, int cols, hipStream_t s);
+// dst[(r * rep_stride + i) * ld + 0..cols) = src[i * ld + 0..cols) for r < nrep, i < nrows (one block of rows copied to the head of
+// every sequence); cols % 8 == 0
+hipError_t bcast_rows(const lp_t* src, lp_t* dst, int nrep, int64_t rep_stride, int nrows, int cols, int64_t ld, hipStream_t s);
 // OWL-ViT: y[b,p,:] = x[b,1+p,:] * x[b,0,:]  (x = post_layernorm output, [B,N,C]) -> [B,N-1,C]
 hipError_t owl_cls_mul(const lp_t* x, lp_t* y, int B, int N, int C, hipStream_t s);
 // gather rows: y[r,:] = x[idx[r],:]

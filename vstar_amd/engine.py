@@ -36,6 +36,11 @@ class VstarEngine:
         _lib.check(self.lib.vstar_create(ctypes.byref(c), device, ctypes.byref(self.handle)))
         self.device = device
         self.finalized = False
+        # VSTAR_F_SHARE_PREFIX on score_batch / score_boxes calls (the system prompt shared by the crops of a call is computed
+        # once).  Off by default: at 32 crops on 256 CUs the 5 % fewer GEMM rows (76 instead of 80 row tiles) fill the same number of
+        # whole rounds of 256^2 tiles, so the call is no faster (tools/prefix_bench.py: 233.6 vs 233.5 ms); it pays when the saved
+        # rows cross a round boundary (e.g. 33 crops then cost what 32 do)
+        self.share_prefix = False
 
     # ---- weights (replaces VSMForCausalLM.from_pretrained + get_vision_tower(), visual_search.py:157-161) ----
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
@@ -81,17 +86,19 @@ class VstarEngine:
 
     # ---- the hot path ----
     def score_batch(self, clip_pix, owl_pix, input_ids, loc_pos, verify_pos=None, skip_owl: bool = False,
-                    sync: bool = True, raw: bool = False, out_dev: Optional[torch.Tensor] = None):
+                    sync: bool = True, raw: bool = False, out_dev: Optional[torch.Tensor] = None, share_prefix: Optional[bool] = None):
         """clip_pix [B,3,I,I], owl_pix [B,3,768,768] (bf16-castable; CPU or cuda tensors), input_ids [B,L] with one -200,
         loc_pos [B] spliced-sequence index of the hidden state that predicts [LOC]; verify_pos [B,V] optional.
         out_dev: a contiguous float32 cuda tensor [B, RESULT_FLOATS] — the records stay in HBM (VSTAR_F_DEVICE_OUTPUT: what the
-        multi-GPU path all-gathers over RCCL without a host bounce); the call then returns None."""
+        multi-GPU path all-gathers over RCCL without a host bounce); the call then returns None.
+        share_prefix (default: the engine's `share_prefix` attribute, False): VSTAR_F_SHARE_PREFIX — the text before <image>, when it
+        is the same >= 16 tokens in every row (the system prompt), goes through LLaMA once instead of B times."""
         cfg = self.cfg
         clip_pix = _as_bf16(clip_pix)
         B = clip_pix.shape[0]
         I = cfg.clip_image_size
         assert tuple(clip_pix.shape) == (B, 3, I, I), clip_pix.shape
-        flags = 0
+        flags = _lib.F_SHARE_PREFIX if (self.share_prefix if share_prefix is None else share_prefix) else 0
         if skip_owl:
             flags |= _lib.F_SKIP_OWL
             owl_ptr = None
@@ -176,7 +183,7 @@ class VstarEngine:
                    self.handle)
 
     def score_boxes(self, boxes_xyxy, input_ids, loc_pos, verify_pos=None, raw: bool = False,
-                    out_dev: Optional[torch.Tensor] = None):
+                    out_dev: Optional[torch.Tensor] = None, share_prefix: Optional[bool] = None):
         """Crop + pad + PIL-exact resize + normalise on the GPU for `boxes_xyxy` [B,4] (ints, as passed to image.crop),
         then the same scoring pass as `score_batch` (out_dev: see there)."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
@@ -191,6 +198,8 @@ class VstarEngine:
             vptr = vp.ctypes.data_as(ctypes.c_void_p)
         out, out_ptr = self._out_buffer(B, out_dev)
         flags = _lib.F_INTERNAL_PIXELS | (_lib.F_DEVICE_OUTPUT if out_dev is not None else 0)
+        if self.share_prefix if share_prefix is None else share_prefix:
+            flags |= _lib.F_SHARE_PREFIX
         _lib.check(self.lib.vstar_vsm_score_batch(
             self.handle, B, None, None, ids.ctypes.data_as(ctypes.c_void_p), ids.shape[1],
             loc.ctypes.data_as(ctypes.c_void_p), vptr, nv, flags, out_ptr), self.handle)
