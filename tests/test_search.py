@@ -202,3 +202,76 @@ def test_speculative_template_mismatch_only_raises_when_visited():
     with pytest.raises(IndexError):
         search.visual_search(vsm, img, "object", [0, 0, 10, 10], gold["smallest_size"])
     assert vsm.resolved == 1
+
+
+# ---------------- lock-step multi-target search (visual_search_many): thread machinery on a CPU stand-in ----------------
+class _BoxVSM:
+    """On-device-style VSM stand-in: crops travel as boxes (`inference_boxes`), results are a deterministic function of
+    (box, question); low-res heat maps are upsampled on demand.  Records every engine call."""
+    supports_gpu_preprocess = True
+    supports_deferred_mismatch = False
+
+    def __init__(self, max_batch=6, fail_on=None):
+        from types import SimpleNamespace
+        self.cfg = SimpleNamespace(max_batch=max_batch)
+        self.calls, self.fail_on = [], fail_on
+        self.image = None
+
+    def set_image(self, image):
+        self.image = image
+
+    def _one(self, b, q):
+        import zlib
+        g = torch.Generator().manual_seed(zlib.crc32(repr((tuple(int(v) for v in b), q)).encode()) % (2 ** 31))
+        low = torch.randn(12, 12, generator=g) * 9
+        boxes = torch.rand(32, 4, generator=g)
+        scores = torch.sigmoid(torch.randn(32, 1, generator=g) * 1.5 - 2.5)
+        return boxes, scores, low
+
+    def inference_boxes(self, boxes, question, mode="detection", upsample=False, **kw):
+        qs = [question] * len(boxes) if isinstance(question, str) else list(question)
+        self.calls.append([(tuple(int(v) for v in b), q) for b, q in zip(boxes, qs)])
+        if self.fail_on is not None and any(self.fail_on in q for q in qs):
+            raise RuntimeError("engine failure")
+        return [self._one(b, q) for b, q in zip(boxes, qs)]
+
+    def inference_batch(self, *a, **k):            # presence marks the VSM as batched
+        raise AssertionError("boxes path expected")
+
+    def upsample_heatmap(self, low, h, w):
+        return torch.clamp(torch.nn.functional.interpolate(low[None, None], (h, w), mode="bilinear", align_corners=False)[0, 0], min=0)
+
+
+def test_lock_step_many_equals_the_per_target_loop():
+    from vstar_amd.search import smallest_size_for, visual_search, visual_search_many
+    from vstar_amd.synthetic import synthetic_image
+    img = synthetic_image(960, 640, 3)
+    smallest = smallest_size_for(960, 640, 4.0)
+    names = ["kite", "red umbrella", "dog", "traffic light", "boat"]
+    kw = dict(confidence_high=0.97, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0, batch_size=3)
+    solo_vsm = _BoxVSM()
+    loop = [visual_search(solo_vsm, img, n, None, smallest, **kw) for n in names]
+    many_vsm = _BoxVSM()
+    many = visual_search_many(many_vsm, img, names, None, smallest, **kw)
+    assert len(many) == len(loop)
+    for a, b in zip(loop, many):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert float(a[0]["score"] or 0) == float(b[0]["score"] or 0)
+    # lock step: fewer, fuller engine calls than the loop, and every call holds the requests of several targets while they last
+    assert len(many_vsm.calls) < len(solo_vsm.calls)
+    assert len({q for _, q in many_vsm.calls[0]}) == len(names)
+    # the same (box, question) pairs were scored in total
+    flat = lambda calls: sorted(p for c in calls for p in c)  # noqa: E731
+    assert flat(many_vsm.calls) == flat(solo_vsm.calls)
+    # target i's result does not depend on the company: a different set of co-searched targets gives the same tuple
+    other = visual_search_many(_BoxVSM(), img, [names[2], "zebra"], None, smallest, **kw)
+    assert other[0][1] == loop[2][1] and other[0][0]["bbox"] == loop[2][0]["bbox"]
+
+
+def test_lock_step_engine_failure_reaches_the_caller():
+    from vstar_amd.search import smallest_size_for, visual_search_many
+    from vstar_amd.synthetic import synthetic_image
+    img = synthetic_image(640, 480, 1)
+    with pytest.raises(RuntimeError, match="engine failure"):
+        visual_search_many(_BoxVSM(fail_on="dog"), img, ["kite", "dog", "boat"], None, smallest_size_for(640, 480, 4.0),
+                           confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)

@@ -98,8 +98,8 @@ def test_batched_search_equals_sequential(vsm):
 
 
 def test_multi_target_search_equals_per_target_loop(vsm):
-    """visual_search_many (first engine step of all targets batched together, prompts of different lengths right-padded in
-    the same batch) returns exactly what the reference's per-object loop returns."""
+    """visual_search_many (the targets' searches advance in lock step; prompts of different lengths right-padded in the same
+    batch) returns exactly what the reference's per-object loop returns."""
     img = synthetic_image(1280, 720, 33)
     smallest = smallest_size_for(1280, 720)
     names = ["kite", "small red umbrella on the beach", "dog"]          # different prompt lengths
@@ -142,9 +142,15 @@ def test_multi_target_search_with_shared_prefix_grouping(vsm):
             plain = visual_search_many(vsm, img, names, None, smallest, **kw)
         finally:
             vsm.group_prompts = True
-    # the first engine step of every target (root + speculative sub-tree, max_batch=8 nodes of the 21) went through the grouped
-    # entry point, each crop once for all four targets
-    assert n_grouped == 8 * len(names)
+    # lock step: EVERY record of every target went through the grouped entry point (group_prompts = "always" during the call)
+    assert n_grouped == 21 * len(names)
+    # a target's result does not depend on its company: searched with other partners it takes the same path to the same numbers
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        other = visual_search_many(vsm, img, [names[2], "zebra crossing", names[0]], None, smallest, **kw)
+    for got, want in ((other[0], grouped[2]), (other[2], grouped[0])):
+        assert got[1] == want[1] and got[2] == want[2] and got[0]["bbox"] == want[0]["bbox"]
+        assert torch.equal(got[0]["detection_result"], want[0]["detection_result"])          # bit-identical records
     for a, b in zip(plain, grouped):
         assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
         assert torch.allclose(a[0]["detection_result"], b[0]["detection_result"], atol=1.0)      # pixels; bf16-level box differences

@@ -144,7 +144,7 @@ class _NodeScorer:
     """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
 
     def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool,
-                 gpu_preprocess: bool = True, device_reductions: Optional[bool] = None):
+                 gpu_preprocess: bool = True, device_reductions: Optional[bool] = None, upload_image: bool = True):
         self.vsm, self.image, self.question = vsm, image, question
         # on-device heat-map statistics (SURVEY §8f-4) whenever the VSM offers them; None = automatic, False = host reductions
         can = bool(getattr(vsm, "supports_device_reductions", hasattr(vsm, "heatmap_stats"))) and hasattr(vsm, "inference_batch")
@@ -153,7 +153,7 @@ class _NodeScorer:
         self.batched = hasattr(vsm, "inference_batch")
         # device-side crop/resize when the VSM offers it: the full image is uploaded once, crops travel as boxes
         self.on_device = gpu_preprocess and bool(getattr(vsm, "supports_gpu_preprocess", False))
-        if self.on_device:
+        if self.on_device and upload_image:       # (visual_search_many: the targets of one image share ONE upload)
             vsm.set_image(image)
         world = vsm._dist()[0] if hasattr(vsm, "_dist") else 1    # one engine batch per rank and step
         self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) * world if self.batched else 1)
@@ -196,26 +196,34 @@ class _NodeScorer:
             self.cache[tuple(b)] = [r, sz, not self.batched]     # [result, (w, h), heatmap already full-res?]
         self.n_scored += len(todo)
 
-    def get(self, bbox, queue: PriorityQueue):
+    def missing(self, bbox, queue: PriorityQueue) -> Optional[List[list]]:
+        """None when `bbox` is cached, else the crops one engine step should score now (`plan`)."""
+        return None if tuple(bbox) in self.cache else self.plan(bbox, queue)
+
+    def score(self, todo: List[list]) -> List:
+        """One engine step for the crops `todo` (this scorer's question)."""
+        # defer_mismatch: a crop whose template check fails is only re-decoded (and can only raise the reference's
+        # IndexError) when the best-first order really visits it — speculative crops the reference never evaluates cannot
+        # abort a search the reference would complete
+        kw = {"defer_mismatch": True} if getattr(self.vsm, "supports_deferred_mismatch", False) else {}
+        if self.on_device:
+            return self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False, **kw)
+        crops = [_crop(self.image, b) for b in todo]
+        if self.batched:
+            return self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False, **kw)
+        return [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
+
+    def accept(self, todo: List[list], res: List) -> None:
+        """Results of one engine step for `todo` (from `score`, or from a multi-target step of visual_search_many)."""
+        if self.on_device:
+            sizes = [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1])) for b in todo]
+        else:
+            sizes = [_crop(self.image, b).size for b in todo]
+        self.store(todo, res, sizes)
+        self.n_batches += 1
+
+    def take(self, bbox):
         key = tuple(bbox)
-        if key not in self.cache:
-            todo = self.plan(bbox, queue)
-            # defer_mismatch: a crop whose template check fails is only re-decoded (and can only raise the reference's
-            # IndexError) when the best-first order really visits it — speculative crops the reference never evaluates cannot
-            # abort a search the reference would complete
-            kw = {"defer_mismatch": True} if getattr(self.vsm, "supports_deferred_mismatch", False) else {}
-            if self.on_device:
-                res = self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False, **kw)
-                sizes = [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1])) for b in todo]
-            else:
-                crops = [_crop(self.image, b) for b in todo]
-                sizes = [c.size for c in crops]
-                if self.batched:
-                    res = self.vsm.inference_batch(crops, self.question, mode="detection", upsample=False, **kw)
-                else:
-                    res = [self.vsm.inference(copy.deepcopy(c), self.question, mode="detection") for c in crops]
-            self.store(todo, res, sizes)
-            self.n_batches += 1
         if hasattr(self.cache[key][0], "resolve"):              # DeferredMismatch: the node is being consumed NOW
             self.cache[key][0] = self.cache[key][0].resolve()
         (boxes, scores, heat), (w, h), full = self.cache[key]
@@ -226,6 +234,12 @@ class _NodeScorer:
             self.cache[key] = [(boxes, scores, heat), (w, h), True]
         return boxes, scores, heat
 
+    def get(self, bbox, queue: PriorityQueue):
+        todo = self.missing(bbox, queue)
+        if todo is not None:
+            self.accept(todo, self.score(todo))
+        return self.take(bbox)
+
 
 def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high=0.5, confidence_low=0.3,
                   target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
@@ -235,6 +249,27 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                   _scorer: Optional["_NodeScorer"] = None):
     """Same contract as the reference's visual_search (visual_search.py:484-516): returns
     (final_step, path_length, search_successful, all_valid_boxes)."""
+    steps = _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high, confidence_low,
+                                 target_cue_threshold, target_cue_threshold_decay, target_cue_threshold_minimum, visualize,
+                                 save_path, batch_size=batch_size, speculate=speculate, noun_chunker=noun_chunker, stats=stats,
+                                 gpu_preprocess=gpu_preprocess, device_reductions=device_reductions, _scorer=_scorer)
+    try:
+        scorer, todo = next(steps)
+        while True:
+            scorer, todo = steps.send(scorer.score(todo))
+    except StopIteration as done:
+        return done.value
+
+
+def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high=0.5, confidence_low=0.3,
+                         target_cue_threshold=6.0, target_cue_threshold_decay=0.7, target_cue_threshold_minimum=3.0,
+                         visualize=False, save_path=None, *, batch_size: Optional[int] = None, speculate: bool = True,
+                         noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
+                         gpu_preprocess: bool = True, device_reductions: Optional[bool] = None,
+                         _scorer: Optional["_NodeScorer"] = None):
+    """The search as a generator: whenever it needs crops scored it yields (scorer, crops) and is sent the engine's results for
+    them; its return value is visual_search's.  `visual_search` drives one such generator, `visual_search_many` several in lock
+    step.  Everything else — the decision math of visual_search.py:390-516 — is unchanged."""
     if visualize:
         raise NotImplementedError("search-path visualisation (cv2/matplotlib, visual_search.py:285-376) is out of scope")
     init_patch = {"bbox": [0, 0, image.width, image.height], "scale_level": 1, "score": None, "parent_index": -1}
@@ -251,7 +286,10 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
         bbox = current_patch["bbox"]
         level = current_patch["scale_level"]
         pw, ph = int(bbox[0] + bbox[2]) - int(bbox[0]), int(bbox[1] + bbox[3]) - int(bbox[1])
-        pred_bboxes, pred_logits, target_cue_heatmap = scorer.get(bbox, queue)
+        todo = scorer.missing(bbox, queue)
+        if todo is not None:
+            scorer.accept(todo, (yield scorer, todo))
+        pred_bboxes, pred_logits, target_cue_heatmap = scorer.take(bbox)
         expand = True
         if len(pred_logits) > 0:
             top_index = pred_logits.view(-1).argmax()
@@ -411,31 +449,67 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
 
 def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, **kw):
     """Several targets on ONE image (the reference loops `visual_search` per missing object, vstar_bench_eval.py:205-209):
-    same per-target results as that loop — each entry is visual_search's 4-tuple — but the first engine step of every
-    target (root crop + its speculative sub-tree) is scored together, all targets of a crop in the same engine call, so
-    small per-target steps still fill the GPU and a grouping VSM evaluates each crop's towers and shared prompt positions
-    once.  Later steps of a search run per target as usual."""
+    same per-target results as that loop — each entry is visual_search's 4-tuple — but the searches advance in LOCK STEP: each
+    is a generator (`_visual_search_steps`) that yields the crops it needs scored; one engine step scores what ALL live searches
+    ask for, all targets of a crop in the same call, so small per-target steps still fill the GPU and a grouping VSM
+    (`vsm.group_prompts`) evaluates each crop's towers and shared prompt positions once for every target that wants it.  With
+    grouping the VSM is switched to group_prompts = "always" for the call: a (crop, prompt) record then never depends on which
+    other targets asked for the crop, so target i's result is a function of (image, target i) alone.  One target, or a VSM
+    without on-device crops, is the plain loop."""
     names = list(target_object_names)
     gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
     batch_size, speculate = kw.get("batch_size"), kw.get("speculate", True)
     scorers = [_NodeScorer(vsm, image, LOCATE_QUESTION.format(n), smallest_size, batch_size, speculate,
-                           kw.get("gpu_preprocess", True), kw.get("device_reductions")) for n in names]
-    if scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1:
-        root = [0, 0, image.width, image.height]
-        # box-major order, chunks of WHOLE boxes: every target of a crop arrives in the same engine call, so the VSM can score
-        # the crop once with one suffix block per target (vsm._score_boxes_grouped); plain engines just see mixed-prompt batches
-        plans = [sc.plan(root, PriorityQueue()) for sc in scorers]
-        pairs = [(sc, b) for k in range(max(map(len, plans))) for sc, pl in zip(scorers, plans) if k < len(pl) for b in [pl[k]]]
-        T = len(scorers)
-        step = max(1, scorers[0].batch_size // T) * T
-        for i0 in range(0, len(pairs), step):
-            chunk = pairs[i0:i0 + step]
-            boxes = [b for _, b in chunk]
-            dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
-            res = vsm.inference_boxes(boxes, [sc.question for sc, _ in chunk], mode="detection", upsample=False, **dkw)
-            for (sc, b), r in zip(chunk, res):
-                sc.store([b], [r], [(int(b[0] + b[2]) - int(b[0]), int(b[1] + b[3]) - int(b[1]))])
-            for sc in {id(sc): sc for sc, _ in chunk}.values():
-                sc.n_batches += 1
+                           kw.get("gpu_preprocess", True), kw.get("device_reductions"), upload_image=(k == 0))
+               for k, n in enumerate(names)]
     kw = {k: v for k, v in kw.items()}
-    return [visual_search(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]
+    if not (scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1):
+        return [visual_search(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]
+    gens = [_visual_search_steps(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]
+    results: List = [None] * len(names)
+    waiting: Dict[int, List[list]] = {}            # target index -> the crops its search is waiting for
+
+    def advance(i, value=None, first=False):
+        try:
+            _, todo = next(gens[i]) if first else gens[i].send(value)
+            waiting[i] = todo
+        except StopIteration as done:
+            results[i] = done.value
+
+    grouping = getattr(vsm, "group_prompts", False)
+    if grouping:
+        vsm.group_prompts = "always"
+    try:
+        for i in range(len(names)):
+            advance(i, first=True)
+        dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
+        while waiting:
+            reqs, waiting = waiting, {}
+            # box-major order: the requests of all targets for the same crop next to each other
+            order: Dict[Tuple, List] = {}
+            for i, boxes in reqs.items():
+                for j, b in enumerate(boxes):
+                    order.setdefault(tuple(b), []).append((i, j))
+            flat = [(i, j, list(b)) for b, lst in order.items() for i, j in lst]
+            # engine calls of about one batch of records (whole crops each): the per-call result arrays stay cache-sized
+            cap = max(int(getattr(getattr(vsm, "cfg", None), "max_batch", 32)), 1)
+            out: List = []
+            c0 = 0
+            while c0 < len(flat):
+                c1 = min(c0 + cap, len(flat))
+                while c1 < len(flat) and flat[c1][2] == flat[c1 - 1][2]:      # do not split the requests for one crop
+                    c1 += 1
+                out += vsm.inference_boxes([f[2] for f in flat[c0:c1]], [scorers[f[0]].question for f in flat[c0:c1]],
+                                           mode="detection", upsample=False, **dkw)
+                c0 = c1
+            per = {i: [None] * len(boxes) for i, boxes in reqs.items()}
+            for (i, j, _), r in zip(flat, out):
+                per[i][j] = r
+            for i in reqs:                         # in target order: host decisions of search i, up to its next request
+                advance(i, per[i])
+    finally:
+        if grouping:
+            vsm.group_prompts = grouping
+        for g in gens:
+            g.close()
+    return results

@@ -31,7 +31,7 @@ from ._lib import RESULT_FLOATS
 from .config import VSMConfig
 from .dist import allgather_numpy, allgather_records, pad_count, shard_indices
 from .engine import VstarEngine
-from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, SyntheticTokenizer, build_prompt, clip_preprocess,
+from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, LOCATE_QUESTION, SyntheticTokenizer, build_prompt, clip_preprocess,
                          owl_preprocess, tokenizer_image_token)
 from .weights import load_checkpoint_dir, random_state_dict
 
@@ -282,54 +282,79 @@ class VSM:
                                 defer_mismatch)
         return out
 
-    group_prompts = True     # several prompts on the same crop share the LLaMA prefix (vstar_vsm_score_grouped); False = plain batches
+    # several prompts on the same crop share the LLaMA prefix (vstar_vsm_score_grouped).  False = plain batches; True = group the
+    # crops that appear with >= 2 prompts in a call; "always" = every locate-template prompt goes through the grouped entry point,
+    # also alone, so that a (crop, prompt) record never depends on what else was in the call (visual_search_many's lock-step mode)
+    group_prompts = True
+
+    def _template_lcp(self) -> List[int]:
+        """Token ids shared by ALL locate prompts (system prompt, image token, "Please locate the"): the common start of the
+        prompts of two object names that differ from their first token on.  The grouped layout always splits a prompt HERE, never
+        at the longest common prefix of whatever prompts happen to share a call, so a record does not depend on its company."""
+        if getattr(self, "_tpl", None) is None:
+            a = list(map(int, self._ids(LOCATE_QUESTION.format("zebra"))[0]))
+            b = list(map(int, self._ids(LOCATE_QUESTION.format("anchor"))[0]))
+            n = 0
+            while n < min(len(a), len(b)) and a[n] == b[n]:
+                n += 1
+            self._tpl = a[:n]
+        return self._tpl
 
     def _score_boxes_grouped(self, xyxy: np.ndarray, qs: List[str], per_q: dict, nv: int) -> Optional[np.ndarray]:
         """Multi-target batches (visual_search_many scores the same crops for several targets): every crop that appears with
         T >= 2 distinct prompts is scored ONCE through the vision towers and the shared positions of the LLaMA sequence — system
-        prompt, image tokens and the common start of the question — plus one 32-row suffix block per prompt
+        prompt, image tokens and the template's "Please locate the" — plus one 32-row suffix block per prompt
         (engine.score_grouped).  Returns the records in the caller's order, or None when the batch does not qualify (single
-        prompt, suffix longer than 32 tokens, a process group that shards crops, an engine without the entry point)."""
+        prompt unless group_prompts == "always", a process group that shards crops, an engine without the entry point).
+        Prompts that do not start with the locate template, or whose remainder exceeds 32 tokens, take the plain path."""
         if not hasattr(self.engine, "score_grouped") or self._dist()[0] > 1:
             return None
+        always = self.group_prompts == "always"
         uq = list(per_q)
-        if len(uq) < 2:
+        if len(uq) < 2 and not always:
             return None
-        seqs = [list(map(int, per_q[q][0])) for q in uq]
-        lcp = 0
-        while all(lcp < len(sq) for sq in seqs) and len({sq[lcp] for sq in seqs}) == 1:
-            lcp += 1
-        if IMAGE_TOKEN_INDEX not in seqs[0][:lcp]:
+        tpl = self._template_lcp()
+        lcp = len(tpl)
+        if IMAGE_TOKEN_INDEX not in tpl:
             return None
         P = self.cfg.n_img_tokens
         Lc = lcp - 1 + P                                            # shared spliced positions
-        Ls = max(len(sq) - lcp for sq in seqs)
+        seqs = {q: list(map(int, per_q[q][0])) for q in uq}
+        ok = {q: sq[:lcp] == tpl and 1 <= len(sq) - lcp <= 32 and per_q[q][1] >= Lc and min(per_q[q][2][-nv:], default=Lc) >= Lc
+              for q, sq in seqs.items()}
+        if not any(ok.values()):
+            return None
+        Ls = max(len(seqs[q]) - lcp for q in uq if ok[q])
         info = {}
-        for q, sq in zip(uq, seqs):
-            _, loc_pos, ver_pos, _ = per_q[q]
-            loc_in, ver_in = loc_pos - Lc, [v - Lc for v in ver_pos[-nv:]]
-            if Ls > 32 or loc_in < 0 or min(ver_in, default=0) < 0:
-                return None
-            info[q] = (sq[lcp:] + [0] * (Ls - (len(sq) - lcp)), loc_in, ver_in)
+        for q in uq:
+            if ok[q]:
+                sq = seqs[q]
+                _, loc_pos, ver_pos, _ = per_q[q]
+                info[q] = (sq[lcp:] + [0] * (Ls - (len(sq) - lcp)), loc_pos - Lc, [v - Lc for v in ver_pos[-nv:]])
         # crops -> the prompts they are scored for (in first-seen order); group crops with the same prompt tuple
         by_box: dict = {}
+        single: List[int] = []
         for i, (b, q) in enumerate(zip(map(tuple, xyxy.tolist()), qs)):
-            by_box.setdefault(b, {}).setdefault(q, []).append(i)
+            if ok[q]:
+                by_box.setdefault(b, {}).setdefault(q, []).append(i)
+            else:
+                single.append(i)
         by_tuple: dict = {}
         for b, d in by_box.items():
             by_tuple.setdefault(tuple(d), []).append(b)
-        if all(len(t) < 2 for t in by_tuple):
+        if not always and all(len(t) < 2 for t in by_tuple):
             return None
         records = np.zeros((len(qs), RESULT_FLOATS), np.float32)
-        prefix = np.asarray(seqs[0][:lcp], np.int32)
+        prefix = np.asarray(tpl, np.int32)
         mb = self.cfg.max_batch
-        single: List[int] = []
+        rows_cap = mb * (self.cfg.max_text_len - 1 + P)             # activation rows the engine holds
+        R0 = (Lc + 127) // 128 * 128
         for qt, boxes in by_tuple.items():
             T = len(qt)
-            if T < 2 or T > mb:
+            if (T < 2 and not always) or T > mb or R0 + 32 * T > rows_cap:
                 single += [i for b in boxes for q in qt for i in by_box[b][q]]
                 continue
-            per_call = max(1, mb // T)
+            per_call = max(1, min(mb // T, rows_cap // (R0 + 32 * T)))
             suf = np.asarray([info[q][0] for q in qt], np.int32)
             loc_in = np.asarray([info[q][1] for q in qt], np.int32)
             ver_in = np.asarray([info[q][2] for q in qt], np.int32).reshape(T, nv)
