@@ -15,7 +15,7 @@ import torch
 from PIL import Image
 
 from .config import VSMConfig
-from .search import smallest_size_for, visual_search
+from .search import smallest_size_for, visual_search, visual_search_many
 from .vsm import VSM
 
 MISSING_MSG = ("Sorry, I can not answer the question. Some visual information about the following objects is missing or "
@@ -45,11 +45,18 @@ def parse_missing_objects(prediction: str):
 
 
 def search_objects(vsm, image_path, names, args):
+    """vstar_bench_eval.py:205-209 (one visual_search per missing object); several missing objects of an image are searched in lock
+    step (`visual_search_many`: same per-object tuples, the crops the objects share are scored together)."""
     found = []
-    for name in names:
-        image = Image.open(image_path).convert("RGB")
-        smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
-        step, _, _, all_valid = visual_search(vsm, image, name, target_bbox=None, smallest_size=smallest)
+    if not names:
+        return found
+    image = Image.open(image_path).convert("RGB")
+    smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
+    if len(names) > 1:
+        out = visual_search_many(vsm, image, names, None, smallest)
+    else:
+        out = [visual_search(vsm, image, names[0], target_bbox=None, smallest_size=smallest)]
+    for name, (step, _, _, all_valid) in zip(names, out):
         boxes = all_valid if all_valid is not None else [step["detection_result"]]
         for b in boxes:
             b[0] += step["bbox"][0]
