@@ -275,3 +275,27 @@ def test_lock_step_engine_failure_reaches_the_caller():
     with pytest.raises(RuntimeError, match="engine failure"):
         visual_search_many(_BoxVSM(fail_on="dog"), img, ["kite", "dog", "boat"], None, smallest_size_for(640, 480, 4.0),
                            confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lock_step_many_equals_loop_on_random_settings(seed):
+    """Image sizes, batch sizes, target counts and thresholds drawn at random: lock-step results == the per-target loop, and the
+    engine scored the same (crop, question) pairs at most once each."""
+    from vstar_amd.search import smallest_size_for, visual_search, visual_search_many
+    rng = np.random.default_rng(100 + seed)
+    w, h = int(rng.integers(500, 1400)), int(rng.integers(400, 1000))
+    img = synthetic_image(w, h, seed)
+    smallest = smallest_size_for(w, h, float(rng.choice([2.0, 4.0, 8.0])), 64)
+    names = [f"thing {k}" for k in range(int(rng.integers(2, 6)))]
+    kw = dict(confidence_high=float(rng.choice([0.6, 0.9, 2.0])), confidence_low=float(rng.choice([0.0, 0.3])),
+              target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0, batch_size=int(rng.integers(1, 9)),
+              speculate=bool(rng.integers(0, 2)))
+    solo, many_vsm = _BoxVSM(max_batch=4), _BoxVSM(max_batch=4)
+    loop = [visual_search(solo, img, n, None, smallest, **kw) for n in names]
+    many = visual_search_many(many_vsm, img, names, None, smallest, **kw)
+    for a, b in zip(loop, many):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert torch.equal(a[0]["detection_result"], b[0]["detection_result"])
+    pairs = [p for c in many_vsm.calls for p in c]
+    assert len(pairs) == len(set(pairs))
+    assert sorted(pairs) == sorted(p for c in solo.calls for p in c)
