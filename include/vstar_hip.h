@@ -194,6 +194,13 @@ int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int 
  * visual_search.py:420-426 (max, min-max normalisation) and :255-266 (get_subpatch_scores) consume. Host in, host out. */
 int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_out, int n_rects, const int32_t* rects_xywh,
                         double* out);
+/* n heat maps in one call (one upload, n kernel passes, one download, one synchronisation): item i is lowres[i] (192x192),
+ * out_hw[2i], out_hw[2i+1] = (h_out, w_out), n_rects[i] <= 8 rectangles at rects_xywh[32 i ...]; writes out[11 i ...] laid out like
+ * vstar_heatmap_stats' `out` (unused rectangle slots are 0).  The scheduler asks for a node's own statistics and its
+ * ancestors' (visual_search.py:445-462 accumulates over all ancestors) — and, in a lock-step multi-target search, every
+ * target's — together. */
+int vstar_heatmap_stats_batch(vstar_handle* h, int n, const float* lowres, const int32_t* out_hw, const int32_t* n_rects,
+                              const int32_t* rects_xywh, double* out);
 
 /* Debug/parity taps: copy an internal activation of the LAST score_batch call to host as fp32.
  * name in {"clip_features","projector","llm_hidden_loc","embed_det","embed_seg","owl_feats"}.

@@ -260,6 +260,24 @@ def test_heatmap_stats_kernel_matches_host_reductions(vsm):
             assert abs(st[3 + k] - H[y:y + rh, x:x + rw].sum()) <= 1e-9 * max(H.sum(), 1.0)
 
 
+def test_heatmap_stats_batch_equals_single_calls(vsm):
+    """vstar_heatmap_stats_batch: n maps of different output sizes / rectangle counts in one engine call == n single calls (the
+    same kernels; fp64 sums agree to the order of the atomics)."""
+    g = torch.Generator().manual_seed(8)
+    items = []
+    for k, (h, w) in enumerate([(540, 960), (2160, 3840), (224, 301), (97, 1200), (700, 700)]):
+        low = (torch.randn(192, 192, generator=g) * (2 + k)).numpy()
+        rects = [[0, 0, w // 2, h // 2], [w // 2, 0, w - w // 2, h // 2], [0, h // 2, w // 2, h - h // 2], [w // 3, h // 5, 17, 9]][:k]
+        items.append((low, h, w, rects or None))
+    got = vsm.heatmap_stats_batch(items)
+    assert len(got) == len(items)
+    for (low, h, w, rects), st in zip(items, got):
+        one = vsm.heatmap_stats(low, h, w, rects)
+        assert st.shape == one.shape and st[0] == one[0] and st[1] == one[1]
+        assert np.allclose(st[2:], one[2:], rtol=1e-12, atol=0)
+    assert vsm.heatmap_stats_batch([]) == []
+
+
 def test_heatmap_stats_survives_image_regrow(vsm):
     """Regression (round-1 advisor finding): vstar_image_set used to hipFree the heat-map statistics scratch when a LARGER image
     forced a regrow and kept the dangling pointer — the next vstar_heatmap_stats then DMA'd into freed memory that the new image

@@ -18,7 +18,7 @@ EXPORTS = [
     "vstar_create", "vstar_destroy", "vstar_last_error", "vstar_load_tensor", "vstar_finalize_weights",
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
-    "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_vsm_generate", "vstar_op_gemm_fp8",
+    "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
 ]
 
@@ -90,6 +90,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_preprocess_crops.restype = c_int
     lib.vstar_heatmap_stats.argtypes = [H, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.vstar_heatmap_stats.restype = c_int
+    lib.vstar_heatmap_stats_batch.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.vstar_heatmap_stats_batch.restype = c_int
     lib.vstar_upsample_mask.argtypes = [H, c_void_p, c_int, c_int, c_void_p]
     lib.vstar_upsample_mask.restype = c_int
     lib.vstar_upsample_mask_ex.argtypes = [H, c_void_p, c_int, c_int, c_int, c_void_p]

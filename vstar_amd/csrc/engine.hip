@@ -56,6 +56,7 @@ struct vstar_engine : EngineBase {
   vstar_result* d_results = nullptr;
   int last_B = 0, last_S = 0;
   void* d_stats = nullptr;
+  void* d_stats_batch = nullptr; size_t stats_batch_cap = 0;      // vstar_heatmap_stats_batch scratch
   // GPU-side preprocessing state
   uint8_t* d_image = nullptr; size_t image_cap = 0; int img_H = 0, img_W = 0;
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
@@ -865,6 +866,7 @@ void vstar_destroy(vstar_handle* h) {
   h->gen.release();
   h->release_base();
   if (h->d_stats) hipFree(h->d_stats);
+  if (h->d_stats_batch) hipFree(h->d_stats_batch);
   if (h->d_image) hipFree(h->d_image);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
@@ -947,6 +949,39 @@ int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_o
   ok = ok && hipMemcpyAsync(out, sc->out, sizeof(double) * (3 + n_rects), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
   ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
   if (!ok) { h->set_error("vstar_heatmap_stats: HIP failure"); return VSTAR_ERR_HIP; }
+  return VSTAR_OK;
+}
+
+int vstar_heatmap_stats_batch(vstar_handle* h, int n, const float* lowres, const int32_t* out_hw, const int32_t* n_rects,
+                              const int32_t* rects_xywh, double* out) {
+  if (!h || n < 0 || (n && (!lowres || !out_hw || !n_rects || !rects_xywh || !out))) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  if (n == 0) return VSTAR_OK;
+  for (int i = 0; i < n; ++i)
+    if (out_hw[2 * i] <= 0 || out_hw[2 * i + 1] <= 0 || n_rects[i] < 0 || n_rects[i] > 8) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  hipSetDevice(h->device);
+  constexpr size_t MAPF = (size_t)VSTAR_MASK_RES * VSTAR_MASK_RES;
+  // device scratch per item: [low MAPF f32][out 11 f64][rects 32 i32][mm 2 u32]; grown on demand
+  const size_t per = MAPF * 4 + 11 * 8 + 32 * 4 + 2 * 4;
+  const size_t need = per * (size_t)n;
+  if (need > h->stats_batch_cap) {
+    if (h->d_stats_batch) hipFree(h->d_stats_batch);
+    h->d_stats_batch = nullptr; h->stats_batch_cap = 0;
+    if (hipMalloc(&h->d_stats_batch, need) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats_batch"); return VSTAR_ERR_NOMEM; }
+    h->stats_batch_cap = need;
+  }
+  char* base = (char*)h->d_stats_batch;
+  float* d_low = (float*)base;
+  double* d_out = (double*)(base + MAPF * 4 * n);
+  int* d_rects = (int*)(base + (MAPF * 4 + 11 * 8) * n);
+  unsigned* d_mm = (unsigned*)(base + (MAPF * 4 + 11 * 8 + 32 * 4) * n);
+  bool ok = hipMemcpyAsync(d_low, lowres, MAPF * 4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  ok = ok && hipMemcpyAsync(d_rects, rects_xywh, (size_t)32 * 4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  for (int i = 0; ok && i < n; ++i)
+    ok = heat_stats(d_low + MAPF * i, VSTAR_MASK_RES, VSTAR_MASK_RES, out_hw[2 * i], out_hw[2 * i + 1], d_rects + 32 * i, n_rects[i],
+                    d_out + 11 * i, d_mm + 2 * i, h->stream) == hipSuccess;
+  ok = ok && hipMemcpyAsync(out, d_out, sizeof(double) * 11 * n, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+  ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+  if (!ok) { h->set_error("vstar_heatmap_stats_batch: HIP failure"); return VSTAR_ERR_HIP; }
   return VSTAR_OK;
 }
 

@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict
     for (int k = 0; k < n_rects; ++k) atomicAdd(&out[3 + k], rs[k]);
   }
 }
+__global__ void heat_stats_init(double* out, unsigned* mm) {
+  if (threadIdx.x < 3 + MAX_RECTS) out[threadIdx.x] = 0.0;
+  if (threadIdx.x == 0) { mm[0] = 0x7f800000u; mm[1] = 0u; }
+}
 __global__ void heat_stats_finish(double* out, const unsigned* mm) {
   out[0] = (double)__uint_as_float(mm[0]);
   out[1] = (double)__uint_as_float(mm[1]);
@@ -193,11 +197,7 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,
                       unsigned* mm_scratch, hipStream_t s) {
   if (n_rects < 0 || n_rects > MAX_RECTS) return hipErrorInvalidValue;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * (3 + MAX_RECTS), s);
-  if (e != hipSuccess) return e;
-  static const unsigned init[2] = {0x7f800000u, 0u};
-  e = hipMemcpyAsync(mm_scratch, init, sizeof(init), hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(heat_stats_init, dim3(1), dim3(64), 0, s, out, mm_scratch);     // zero the sums, min := +inf, max := 0
   const int64_t total = (int64_t)hout * wout;
   unsigned blocks = (unsigned)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;

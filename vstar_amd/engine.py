@@ -7,7 +7,7 @@ libvstar_hip.so; torch is used here only to hold host/device buffers.
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, Optional
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -250,6 +250,27 @@ class VstarEngine:
                                                 rects.ctypes.data_as(ctypes.c_void_p) if len(rects) else None,
                                                 out.ctypes.data_as(ctypes.c_void_p)), self.handle)
         return out
+
+    def heatmap_stats_batch(self, items) -> List[np.ndarray]:
+        """items: [(low_res [192,192], h, w, rects_xywh or None), ...] -> heatmap_stats of each, in ONE engine call."""
+        n = len(items)
+        if n == 0:
+            return []
+        low = np.empty((n, MASK_RES, MASK_RES), np.float32)
+        hw = np.empty((n, 2), np.int32)
+        nr = np.zeros((n,), np.int32)
+        rects = np.zeros((n, 8, 4), np.int32)
+        for i, (m, h, w, r) in enumerate(items):
+            low[i] = np.asarray(m, np.float32).reshape(MASK_RES, MASK_RES)
+            hw[i] = (h, w)
+            if r is not None and len(r):
+                rr = np.asarray(r, np.int32).reshape(-1, 4)
+                nr[i] = len(rr)
+                rects[i, :len(rr)] = rr
+        out = np.zeros((n, 11), np.float64)
+        p = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+        _lib.check(self.lib.vstar_heatmap_stats_batch(self.handle, n, p(low), p(hw), p(nr), p(rects), p(out)), self.handle)
+        return [out[i, :3 + nr[i]].copy() for i in range(n)]
 
     def debug_read(self, name: str, count: int) -> np.ndarray:
         out = np.empty((count,), dtype=np.float32)

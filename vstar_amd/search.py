@@ -254,11 +254,18 @@ def visual_search(vsm, image, target_object_name, target_bbox, smallest_size, co
                                  save_path, batch_size=batch_size, speculate=speculate, noun_chunker=noun_chunker, stats=stats,
                                  gpu_preprocess=gpu_preprocess, device_reductions=device_reductions, _scorer=_scorer)
     try:
-        scorer, todo = next(steps)
+        req = next(steps)
         while True:
-            scorer, todo = steps.send(scorer.score(todo))
+            req = steps.send(req[1].score(req[2]) if req[0] == "score" else _serve_stats(vsm, req[1]))
     except StopIteration as done:
         return done.value
+
+
+def _serve_stats(vsm, reqs):
+    """Heat-map statistics for [(low_res, h, w, rects), ...]: one engine call when the VSM offers the batched form."""
+    if hasattr(vsm, "heatmap_stats_batch"):
+        return vsm.heatmap_stats_batch(reqs)
+    return [vsm.heatmap_stats(m, h, w, r) for m, h, w, r in reqs]
 
 
 def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_size, confidence_high=0.5, confidence_low=0.3,
@@ -267,8 +274,9 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
                          noun_chunker: Optional[Callable[[str], List[str]]] = None, stats: Optional[dict] = None,
                          gpu_preprocess: bool = True, device_reductions: Optional[bool] = None,
                          _scorer: Optional["_NodeScorer"] = None):
-    """The search as a generator: whenever it needs crops scored it yields (scorer, crops) and is sent the engine's results for
-    them; its return value is visual_search's.  `visual_search` drives one such generator, `visual_search_many` several in lock
+    """The search as a generator: whenever it needs crops scored it yields ("score", scorer, crops) and is sent the engine's
+    results for them; whenever it needs heat-map statistics (device reductions) it yields ("stats", [(low_res, h, w, rects), ...])
+    and is sent one statistics vector per item; its return value is visual_search's.  `visual_search` drives one such generator, `visual_search_many` several in lock
     step.  Everything else — the decision math of visual_search.py:390-516 — is unchanged."""
     if visualize:
         raise NotImplementedError("search-path visualisation (cv2/matplotlib, visual_search.py:285-376) is out of scope")
@@ -288,7 +296,7 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
         pw, ph = int(bbox[0] + bbox[2]) - int(bbox[0]), int(bbox[1] + bbox[3]) - int(bbox[1])
         todo = scorer.missing(bbox, queue)
         if todo is not None:
-            scorer.accept(todo, (yield scorer, todo))
+            scorer.accept(todo, (yield "score", scorer, todo))
         pred_bboxes, pred_logits, target_cue_heatmap = scorer.take(bbox)
         expand = True
         if len(pred_logits) > 0:
@@ -318,7 +326,15 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
             current_patch_index = len(search_path) - 1
             threshold = max(target_cue_threshold_minimum, target_cue_threshold * target_cue_threshold_decay ** (level - 1))
             rel = lambda owner: [[sp[0] - owner[0], sp[1] - owner[1], sp[2], sp[3]] for sp in basic_sub_patches]  # noqa: E731
-            st = vsm.heatmap_stats(target_cue_heatmap, bbox[3], bbox[2], rel(bbox))
+            # this node's statistics and every ancestor's (over THIS node's child rectangles) in one request
+            stat_reqs = [(target_cue_heatmap, bbox[3], bbox[2], rel(bbox))]
+            anc = current_patch
+            while anc["parent_index"] != -1:
+                anc = search_path[anc["parent_index"]]
+                tb = anc["bbox"]
+                stat_reqs.append((anc["heat_stats"]["low_res"], tb[3], tb[2], rel(tb)))
+            stat_res = yield "stats", stat_reqs
+            st, anc_stats = stat_res[0], list(stat_res[1:])
             low = target_cue_heatmap
             if not st[1] > threshold:
                 patch = _crop(image, bbox)
@@ -333,7 +349,7 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
                 noun_chunks = noun_chunker(phrase)
                 phrase = noun_chunks[0] if len(noun_chunks) == 1 else "region {}".format(phrase)
                 low = vsm.inference_batch([patch], LOCATE_QUESTION.format(phrase), mode="segmentation", upsample=False)[0]
-                st = vsm.heatmap_stats(low, bbox[3], bbox[2], rel(bbox))
+                st = (yield "stats", [(low, bbox[3], bbox[2], rel(bbox))])[0]
                 search_path[current_patch_index]["context_cue"] = vqa_results + "#" + phrase
             current_patch["heat_stats"] = {"low_res": low, "min": st[0], "max": st[1], "sum": st[2]}
 
@@ -356,8 +372,7 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
                 if tmp_patch["parent_index"] == -1:
                     break
                 tmp_patch = search_path[tmp_patch["parent_index"]]
-                tb = tmp_patch["bbox"]
-                tmp_stats = vsm.heatmap_stats(tmp_patch["heat_stats"]["low_res"], tb[3], tb[2], rel(tb))
+                tmp_stats = anc_stats.pop(0)
 
             def exact_scores(node=current_patch, subs=basic_sub_patches, memo={}):  # noqa: B006  (per-node memo on purpose)
                 """The reference's own float32 arithmetic for THIS node's children (visual_search.py:445-462): materialise the
@@ -469,12 +484,30 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
     results: List = [None] * len(names)
     waiting: Dict[int, List[list]] = {}            # target index -> the crops its search is waiting for
 
+    want_stats: Dict[int, List] = {}               # target index -> heat-map statistics requests
+
     def advance(i, value=None, first=False):
         try:
-            _, todo = next(gens[i]) if first else gens[i].send(value)
-            waiting[i] = todo
+            req = next(gens[i]) if first else gens[i].send(value)
+            if req[0] == "score":
+                waiting[i] = req[2]
+            else:
+                want_stats[i] = req[1]
         except StopIteration as done:
             results[i] = done.value
+
+    def drain_stats():
+        """Serve statistics requests — all targets' in ONE engine call per pass — until every live search waits for crops."""
+        nonlocal want_stats
+        while want_stats:
+            cur, want_stats = want_stats, {}
+            flat_reqs = [r for i in cur for r in cur[i]]
+            res = _serve_stats(vsm, flat_reqs)
+            k = 0
+            for i in cur:
+                n_i = len(cur[i])
+                advance(i, res[k:k + n_i])
+                k += n_i
 
     grouping = getattr(vsm, "group_prompts", False)
     if grouping:
@@ -482,6 +515,7 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
     try:
         for i in range(len(names)):
             advance(i, first=True)
+        drain_stats()
         dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
         while waiting:
             reqs, waiting = waiting, {}
@@ -507,6 +541,7 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
                 per[i][j] = r
             for i in reqs:                         # in target order: host decisions of search i, up to its next request
                 advance(i, per[i])
+            drain_stats()
     finally:
         if grouping:
             vsm.group_prompts = grouping

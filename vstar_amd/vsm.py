@@ -398,6 +398,15 @@ class VSM:
         self.timers["post_s"] += time.perf_counter() - t0
         return out
 
+    def heatmap_stats_batch(self, items) -> List[np.ndarray]:
+        """Several heatmap_stats in one engine call: items = [(low_res, h, w, rects_xywh), ...]."""
+        t0 = time.perf_counter()
+        conv = [(m.numpy() if isinstance(m, torch.Tensor) else np.asarray(m), h, w, r) for m, h, w, r in items]
+        out = self.engine.heatmap_stats_batch(conv) if hasattr(self.engine, "heatmap_stats_batch") else \
+            [self.engine.heatmap_stats(m, h, w, r) for m, h, w, r in conv]
+        self.timers["post_s"] += time.perf_counter() - t0
+        return out
+
     def _handle_mismatches(self, out: List, crop_of, question, mode: str, upsample: bool, defer: bool) -> None:
         """Per-crop consequence of the teacher-forced template check (`last_template_ok`).
 
