@@ -163,13 +163,15 @@ def fake_engine_run(args, world, rank, dist):
         dt = float(tt.item())
         assert [float(out[r * B, 0]) for r in range(world)] == [float(r) for r in range(world)]     # rank order of the gather
     if rank == 0:
-        print(json.dumps({"metric": "FAKE-ENGINE plumbing check (not a measurement)", "value": round(world * B * args.steps / dt, 3),
+        fake_line = json.dumps({"metric": "FAKE-ENGINE plumbing check (not a measurement)", "value": round(world * B * args.steps / dt, 3),
                           "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "stub", "config": {"workload": "stub", "parallelism": f"dp{world}"},
-                          "roofline": None, "cpu_baseline": None}))
+                          "roofline": None, "cpu_baseline": None})
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0:
+        _print_last(fake_line)
 
 
 def main():
@@ -343,9 +345,28 @@ def main():
                 "backend": dist.get_backend() + " (RCCL over xGMI)", "op": "all_gather_into_tensor of the per-crop result records, once per step",
                 "bytes_per_rank_per_step": int(B * _lib.RESULT_FLOATS * 4), "ranks": dist.get_world_size()},
         }
-        print(json.dumps(line))
     if use_group:
+        _flush_c_stdio()                 # every rank: whatever RCCL buffered through C stdio goes out BEFORE rank 0's JSON line
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        _print_last(json.dumps(line))
+
+
+def _print_last(text: str) -> None:
+    """The JSON line must be the LAST line of stdout: RCCL writes its start-up banner through C stdio, which (on a pipe) stays
+    buffered until exit and would otherwise land after it.  Flush the C buffers first, then print and flush."""
+    _flush_c_stdio()
+    print(text, flush=True)
+
+
+def _flush_c_stdio() -> None:
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
