@@ -22,7 +22,9 @@ def test_bench_under_torchrun_one_rank_nccl(cuda):
            "--batch", "4", "--search-targets", "3", "--no-cpu-baseline", "--rccl-selfcheck"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith("{"), lines[-3:]       # the JSON line is the LAST line (RCCL's banner must not trail it)
+    line = json.loads(lines[-1])
     assert line["n_gpus"] == 1 and line["collective"]["backend"].startswith("nccl") and line["collective"]["ranks"] == 1
     assert line["value"] > 0
     for leg in ("search", "search_grouped"):
