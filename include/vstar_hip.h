@@ -233,6 +233,16 @@ enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_E
 int vstar_op_gemm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
                   const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int out_f32,
                   int M, int N, int K, int epilogue);
+/* Op-level door for the RMSNorm-folded linears of the LLaMA pass (bf16 output): C = epilogue((A . W^T) * row_scale[m] + bias)
+ * (+ residual); with sumsq_out (VSTAR_EPI_NONE, N % 64 == 0) the epilogue also writes sumsq_out[m * sumsq_ld + n / 64] = the sum
+ * of squares of the 64 stored values C[m, n .. n+63] (fixed summation order, identical in both GEMM kernels).  Either may be null.
+ * vstar_op_rms_rstd: r[m] = rsqrt(mean(x[m]^2) + eps) from x [rows, cols] (x != null) or from such partial sums
+ * (x == null: partials [rows, ld], cols / 64 of them per row) — bit-identical either way. */
+int vstar_op_gemm_norm(void* stream, const uint16_t* dev_A, int64_t lda, const uint16_t* dev_W, const uint16_t* dev_bias,
+                       const uint16_t* dev_residual, int64_t ldr, void* dev_C, int64_t ldc, int M, int N, int K, int epilogue,
+                       const float* dev_row_scale, float* dev_sumsq_out, int sumsq_ld);
+int vstar_op_rms_rstd(void* stream, const uint16_t* dev_x, const float* dev_partials, int ld, int rows, int cols, float eps,
+                      float* dev_r);
 /* Which GEMM kernel the calling thread's last vstar_op_gemm / vstar_op_gemm_fp8 launched: 128, 256, 384 (= 256 + 128: whole
  * rounds of 256x256 tiles over the leading rows and the ragged last round's rows as 128x128 tiles — bit-identical to either
  * kernel alone), or 0 (nothing launched).  Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */

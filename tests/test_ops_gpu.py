@@ -442,3 +442,67 @@ def test_gemm_w8a8_fp8(cuda, lib, M, N, K, epi):
     if epi == 0:
         full = (full + bias[:N].float()).bfloat16().float() + res.float()
         assert float((got - full).norm() / full.norm()) < 0.06
+
+
+# ---- RMSNorm folded into the LLaMA linears: row scale in the epilogue, next norm's statistics from the producing epilogue ----
+def _gemm_norm(lib, a, w, res=None, epi=0, tile=0, row_scale=None, want_sumsq=False):
+    M, K = a.shape
+    N = w.shape[0]
+    n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
+    c = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=a.device)
+    ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=a.device) if want_sumsq else None
+    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256}[tile]
+    rc = lib.vstar_op_gemm_norm(None, P(a), K, P(_pad_w(w)), None, P(res), n_out if res is not None else 0, P(c), n_out, M, N, K,
+                                epi | flag, P(row_scale), P(ss), N // 64)
+    assert rc == 0, lib.vstar_last_error(None)
+    if tile:
+        assert lib.vstar_op_gemm_last_tile() == tile
+    return c, ss
+
+
+@pytest.mark.parametrize("M,N,K", [(1300, 4096, 256), (2048, 512, 1024), (1030, 1024, 128)])
+def test_gemm_sumsq_partials_and_rstd(lib, cuda, M, N, K):
+    """o_proj / down_proj form (x = A.W^T + residual): both kernels write bit-identical 64-column sums of squares of the stored
+    values, rms_rstd from those partials == rms_rstd from the stored x itself == torch's fp32 statistics (to fp32 rounding)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16().to(cuda)
+    res = (3 * torch.randn(M, N, generator=g)).bfloat16().to(cuda)
+    c256, s256 = _gemm_norm(lib, a, w, res, tile=256, want_sumsq=True)
+    c128, s128 = _gemm_norm(lib, a, w, res, tile=128, want_sumsq=True)
+    plain = _gemm(lib, a, w, None, res, tile=256)
+    assert torch.equal(c256, plain) and torch.equal(c128, plain)            # the statistics do not disturb the output
+    assert torch.equal(s256, s128)                                          # same summation tree in both kernels
+    ref = c256.float().view(M, N // 64, 64).pow(2).sum(-1)
+    assert torch.allclose(s256, ref, rtol=1e-5, atol=0)
+    eps = 1e-6
+    r_part = torch.empty(M, dtype=torch.float32, device=cuda)
+    r_rows = torch.empty(M, dtype=torch.float32, device=cuda)
+    assert lib.vstar_op_rms_rstd(None, None, P(s256), N // 64, M, N, eps, P(r_part)) == 0
+    assert lib.vstar_op_rms_rstd(None, P(c256), None, 0, M, N, eps, P(r_rows)) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(r_part, r_rows)                                      # bit-identical: layer 0 (from x) and layers >= 1 (from partials)
+    r_ref = torch.rsqrt(c256.float().pow(2).mean(-1) + eps)
+    assert torch.allclose(r_part, r_ref, rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1300, 768, 256, 0), (1100, 512, 256, 4), (2048, 4096, 512, 0)])
+def test_gemm_row_scale_is_the_folded_rmsnorm(lib, cuda, M, N, K, epi):
+    """Linear(RMSNorm(x)) == rstd[m] * (x . (W * norm_w)^T): the row scale acts on the fp32 accumulators (before SiLU*up / bias);
+    128^2 and 256^2 kernels bit-identical; against torch fp32 at GEMM tolerance."""
+    g = torch.Generator().manual_seed(M * 5 + N + K + epi)
+    x = (2 * torch.randn(M, K, generator=g)).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    packed = _pack_gate_up(w[: N // 2], w[N // 2:]) if epi == _lib.EPI_SILU_MUL else w
+    r = torch.empty(M, dtype=torch.float32, device=cuda)
+    assert lib.vstar_op_rms_rstd(None, P(x), None, 0, M, K, 1e-6, P(r)) == 0
+    c256, _ = _gemm_norm(lib, x, packed.to(cuda), epi=epi, tile=256, row_scale=r)
+    c128, _ = _gemm_norm(lib, x, packed.to(cuda), epi=epi, tile=128, row_scale=r)
+    assert torch.equal(c256, c128)
+    acc = (x.float() @ w.to(cuda).float().T) * r[:, None]
+    if epi == _lib.EPI_SILU_MUL:
+        gf, uf = acc[:, : N // 2].bfloat16().float(), acc[:, N // 2:].bfloat16().float()
+        ref = F.silu(gf).bfloat16().float() * uf
+        assert ((c256.float() - ref).abs() <= ref.abs() * 2 ** -6 + 1e-2).all()
+    else:
+        assert _rel(c256.float(), acc) < 2 ** -7

@@ -19,7 +19,7 @@ EXPORTS = [
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
-    "vstar_op_gemm_last_tile", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
+    "vstar_op_gemm_last_tile", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -107,6 +107,11 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_gemm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_int]
     lib.vstar_op_gemm.restype = c_int
+    lib.vstar_op_gemm_norm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                       c_int, c_void_p, c_void_p, c_int]
+    lib.vstar_op_gemm_norm.restype = c_int
+    lib.vstar_op_rms_rstd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]
+    lib.vstar_op_rms_rstd.restype = c_int
     lib.vstar_op_gemm_last_tile.argtypes = []
     lib.vstar_op_gemm_last_tile.restype = c_int
     lib.vstar_op_gemm_fp8.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -1092,6 +1092,27 @@ int vstar_op_gemm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* 
   if (e == hipSuccess && !nosync) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
+int vstar_op_gemm_norm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* W, const uint16_t* bias,
+                       const uint16_t* residual, int64_t ldr, void* C, int64_t ldc, int M, int N, int K, int epilogue,
+                       const float* row_scale, float* sumsq_out, int sumsq_ld) {
+  GemmParams p{};
+  p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  p.row_scale = row_scale; p.sumsq_out = sumsq_out; p.sumsq_ld = sumsq_ld;
+  if ((epilogue & VSTAR_EPI_TILE128) && (epilogue & VSTAR_EPI_TILE256)) { tls_error() = "both tile overrides set"; return VSTAR_ERR_INVALID; }
+  if (sumsq_out && ((epilogue & 0xff) != VSTAR_EPI_NONE || N % 64)) { tls_error() = "sumsq_out: VSTAR_EPI_NONE and N % 64 == 0 only"; return VSTAR_ERR_INVALID; }
+  p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
+  if (p.tile_force == 256 && !gemm256_eligible(p)) { tls_error() = "VSTAR_EPI_TILE256: shape outside the 256x256 kernel's domain"; return VSTAR_ERR_INVALID; }
+  hipError_t e = gemm_lp(p, epilogue & 0xff, false, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return op_rc(e);
+}
+int vstar_op_rms_rstd(void* stream, const uint16_t* x, const float* partials, int ld, int rows, int cols, float eps, float* r) {
+  hipError_t e = x ? rms_rstd_rows(x, rows, cols, eps, r, (hipStream_t)stream)
+                   : rms_rstd_partials(partials, ld, rows, cols, eps, r, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return op_rc(e);
+}
 int vstar_op_gemm_last_tile(void) { return gemm_last_tile(); }
 int vstar_op_layernorm(void* stream, const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y, int rows,
                        int cols, float eps) {

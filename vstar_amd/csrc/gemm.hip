@@ -132,6 +132,35 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
 
   // ---- epilogue: lane owns row (m*16+fr), columns fq*4..fq*4+3 of each 16x16 fragment ----
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  if (p.row_scale) {       // RMSNorm folded into this linear (see kernels.hpp)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int row = m0 + wr * 64 + m * 16 + fr;
+      const float rs = p.row_scale[map_row(row < p.M ? row : p.M - 1, p.a_group, p.a_gstride, p.a_off)];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][n][e] *= rs;
+    }
+  }
+  if constexpr (EPI == VSTAR_EPI_NONE && !OUT_F32) {
+    if (p.sumsq_out) {     // block-uniform: also write the 64-column sums of squares of the stored values (no early exits: shuffles)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const int row = m0 + wr * 64 + m * 16 + fr;
+        const int64_t crow = map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off);
+        float o[4][4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if (row < p.M) gemm_epilogue_store<EPI, OUT_F32>(p, crow, n0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n], o[n]);
+          else o[n][0] = o[n][1] = o[n][2] = o[n][3] = 0.f;
+        }
+        const float ss = gemm_sumsq_span64_frags(o);
+        if (fq == 0 && row < p.M && n0 + wc * 64 < n_out) p.sumsq_out[crow * p.sumsq_ld + (n0 + wc * 64) / 64] = ss;
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m) {
     const int row = m0 + wr * 64 + m * 16 + fr;
@@ -224,6 +253,8 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
           b.A = p.A + M1 * p.lda;
           b.C = out_f32 ? (void*)((float*)p.C + M1 * p.ldc) : (void*)((lp_t*)p.C + M1 * p.ldc);
           if (p.res) b.res = p.res + M1 * p.ldr;
+          if (p.row_scale) b.row_scale = p.row_scale + M1;
+          if (p.sumsq_out) b.sumsq_out = p.sumsq_out + M1 * p.sumsq_ld;
           b.tile_force = 128;
           hipError_t e = gemm256_lp(a, epilogue, out_f32, s);
           if (e != hipSuccess) return e;

@@ -262,6 +262,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     }
   }
 
+  // ---- RMSNorm folded into this linear: Linear(RMSNorm(x)) = rstd[row] * (x . (W * norm_w)^T) ----
+  if constexpr (!F8) {
+    if (p.row_scale) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int row = em0 + wr * 128 + m * 16 + fr;
+        const float rs = p.row_scale[gemm_map_row(row < p.M ? row : p.M - 1, p.a_group, p.a_gstride, p.a_off)];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[m][n][e] *= rs;
+      }
+    }
+  }
+
   // ---- epilogue ----
   if (!(p.debug_flags & 2)) {
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
@@ -355,9 +370,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
               v[e] = (short)f2lp(rlp(lp2f((lp_t)v[e]) * lp2f((lp_t)c8[e])) + rlp(sgn * lp2f((lp_t)vp[e]) * lp2f((lp_t)s8[e])));
           }
         }
-        if (row < p.M && !(p.debug_flags & 1)) {
-          const int64_t crow = gemm_map_row(row, p.c_group, p.c_gstride, p.c_off);
-          gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
+        const int64_t crow = gemm_map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off);
+        if (row < p.M && !(p.debug_flags & 1)) gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
+        if constexpr (EPI == VSTAR_EPI_NONE) {
+          if (p.sumsq_out) {          // tile-uniform: statistics of the next RMSNorm from the values just stored (8 lanes = this row's 64 columns)
+            const float ss = gemm_sumsq_span64_chunks(v);
+            if (ch == 0 && row < p.M && colbase < n_out) p.sumsq_out[crow * p.sumsq_ld + colbase / 64] = ss;
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -54,7 +54,8 @@ __device__ __forceinline__ void gemm_epilogue_values(const GemmParams& p, int co
 // Direct epilogue (accumulator layout -> global): 4 consecutive output columns of one row per call.
 template <int EPI, bool OUT_F32>
 __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t crow, int col, int n_out, const f32x4& a,
-                                                    const f32x4& u) {
+                                                    const f32x4& u, float* stored = nullptr) {
+  if (stored) stored[0] = stored[1] = stored[2] = stored[3] = 0.f;
   if (col >= n_out) return;
   const bool full = (col + 3 < n_out);
   float o[4];
@@ -84,6 +85,10 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
     }
   } else {
     lp_t* c = (lp_t*)p.C + crow * p.ldc + col;
+    if (stored) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stored[e] = (col + e < n_out) ? rlp(o[e]) : 0.f;       // what lands in memory
+    }
     if (full && ((((uintptr_t)c) & 7) == 0)) {
       lpx4 v = {(short)f2lp(o[0]), (short)f2lp(o[1]), (short)f2lp(o[2]), (short)f2lp(o[3])};
       *(lpx4*)c = v;
@@ -99,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 // instead of 32-byte fragments.  The transcendental activations live here (static 8-element bodies) so that the
 // accumulator-indexed stage-1 loops stay small enough to unroll (a runtime-indexed acc[] would go to scratch).
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8 v) {
+__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8& v) {
   if (col >= n_out) return;
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
@@ -130,6 +135,35 @@ __device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, in
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (lp_t)v[e];
   }
+}
+
+// GemmParams::sumsq_out: sum of squares of a 64-column span of STORED values, canonical order (see kernels.hpp / norm.hip):
+//   chunk (8 consecutive columns): (c0^2 + c1^2 + c2^2 + c3^2 sequentially) + (c4..c7 likewise); chunk pairs; 16-col fragments pairwise.
+// gemm256 layout: 8 consecutive lanes hold the 8 chunks of the span.
+__device__ __forceinline__ float gemm_sumsq_span64_chunks(const lpx8& v) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = lp2f((lp_t)v[e]);
+  const float h0 = ((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]) + f[3] * f[3];
+  const float h1 = ((f[4] * f[4] + f[5] * f[5]) + f[6] * f[6]) + f[7] * f[7];
+  float s = h0 + h1;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  return s;
+}
+// gemm128 layout (accumulator layout): lane (fr = lane & 15, fq = lane >> 4) holds columns n*16 + fq*4 + {0..3} of fragment n = 0..3
+// as o[n][0..3]; half-chunks meet across lane ^ 16, chunks of a fragment across lane ^ 32, fragments inside the lane.
+__device__ __forceinline__ float gemm_sumsq_span64_frags(const float (&o)[4][4]) {
+  float pn[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float h = ((o[n][0] * o[n][0] + o[n][1] * o[n][1]) + o[n][2] * o[n][2]) + o[n][3] * o[n][3];
+    h += __shfl_xor(h, 16, 64);      // h0 + h1 of the chunk
+    h += __shfl_xor(h, 32, 64);      // the fragment's two chunks
+    pn[n] = h;
+  }
+  return (pn[0] + pn[1]) + (pn[2] + pn[3]);
 }
 
 }  // namespace VS_NS

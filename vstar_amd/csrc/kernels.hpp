@@ -34,6 +34,13 @@ struct GemmParams {
   // C = epilogue((A_q · W_q^T) * a_scale[m] * w_scale[n]).  One v_mfma_scale_f32_16x16x128_f8f6f4 (scales 1.0) replaces two
   // 16x16x32 bf16 MFMAs on the same LDS bytes, i.e. twice the K per K-tile at the same LDS/DMA traffic.
   const float* a_scale; const float* w_scale;
+  // RMSNorm folded into the linears (bf16 kernels, llm_forward): `row_scale` [buffer rows] multiplies the accumulators of row r by
+  // row_scale[mapped A row r] before bias / activation / RoPE — with the norm's weight folded into W's columns this IS
+  // Linear(RMSNorm(x)) without the normalised copy of x.  `sumsq_out` (VSTAR_EPI_NONE, bf16 output): the epilogue also writes,
+  // per output row and 64-column span, the sum of squares of the STORED bf16 values to sumsq_out[crow * sumsq_ld + col / 64] —
+  // the statistics of the next RMSNorm, produced where the residual stream is written.  Both kernels add in the same fixed
+  // order (4+4 columns, pairs of 8-column chunks, 16-column fragments pairwise), so the partials are bit-identical.
+  const float* row_scale; float* sumsq_out; int sumsq_ld;
   // kernel choice: 0 = the dispatcher decides, 128 / 256 = force that tile (256 fails with hipErrorInvalidValue when the shape
   // is not gemm256_eligible).  Process-wide default for 0 calls: environment VSTAR_GEMM_TILE (A/B runs).
   int tile_force;
@@ -79,6 +86,13 @@ hipError_t rmsnorm_quant_fp8(const lp_t* x, const lp_t* gamma, uint8_t* q, float
 // y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
 hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t* y, int rows, int cols,
                           float eps, const int32_t* row_index, int act, hipStream_t s);
+// r[row] = rsqrt(mean(x[row]^2) + eps) (LlamaRMSNorm's fp32 statistics) — from x itself, or from the 64-column partial sums a GEMM
+// epilogue wrote (GemmParams::sumsq_out); the two agree bit for bit (same summation tree).  cols % 64 == 0.
+hipError_t rms_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r, hipStream_t s);
+hipError_t rms_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s);
+// W[n, k] = round(W[n, k] * w[k]) for n < rows: folds a norm weight into the columns of a packed Linear; fill_lp: v[i] = value
+hipError_t scale_cols_lp(lp_t* W, const lp_t* w, int64_t rows, int K, hipStream_t s);
+hipError_t fill_lp(lp_t* v, int64_t n, float value, hipStream_t s);
 hipError_t rmsnorm_lp(const lp_t* x, const lp_t* gamma, lp_t* y, int rows, int cols, float eps,
                         const int32_t* row_index, hipStream_t s);
 

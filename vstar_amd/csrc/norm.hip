@@ -97,6 +97,99 @@ hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t
   return hipGetLastError();
 }
 
+namespace {
+// canonical sum of squares of a 64-column span held as 8 values per lane by 8 consecutive lanes: (4 + 4 columns) per lane,
+// then lane pairs (xor 1), fragments pairwise (xor 2, xor 4).  gemm256 / gemm128 epilogues use the same tree.
+__device__ __forceinline__ float sumsq_span64(const float (&v)[8]) {
+  const float h0 = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
+  const float h1 = ((v[4] * v[4] + v[5] * v[5]) + v[6] * v[6]) + v[7] * v[7];
+  float s = h0 + h1;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void rms_rstd_rows_kernel(const lp_t* __restrict__ x, int rows, int cols, float eps, float* __restrict__ r) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const lp_t* xr = x + (int64_t)row * cols;
+  const int nspan = cols >> 6;
+  float total = 0.f;                                   // spans are added in column order, like rms_rstd_partials
+  for (int s0 = 0; s0 < nspan; s0 += 8) {              // 8 spans per pass: lane -> span s0 + lane/8, chunk lane%8
+    const int sp = s0 + (lane >> 3);
+    float v[8];
+    if (sp < nspan) {
+      const lpx8 t = *(const lpx8*)(xr + sp * 64 + (lane & 7) * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = lp2f((lp_t)t[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    const float part = sumsq_span64(v);                // valid in all 8 lanes of the span
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float pj = __shfl(part, j * 8, 64);
+      if (s0 + j < nspan) total += pj;
+    }
+  }
+  if (lane == 0) r[row] = rsqrtf(total / (float)cols + eps);
+}
+
+__global__ void rms_rstd_partials_kernel(const float* __restrict__ partials, int ld, int rows, int cols, float eps, float* __restrict__ r) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  const float* pr = partials + (int64_t)row * ld;
+  const int nspan = cols >> 6;
+  float total = 0.f;
+  for (int j = 0; j < nspan; ++j) total += pr[j];
+  r[row] = rsqrtf(total / (float)cols + eps);
+}
+
+__global__ void scale_cols_kernel(lp_t* __restrict__ W, const lp_t* __restrict__ w, int64_t n_vec, int kv) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_vec) return;
+  const int c = (int)(idx % kv);
+  lpx8 a = *(const lpx8*)(W + idx * 8);
+  const lpx8 g = *(const lpx8*)(w + (int64_t)c * 8);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = (short)f2lp(lp2f((lp_t)a[e]) * lp2f((lp_t)g[e]));
+  *(lpx8*)(W + idx * 8) = a;
+}
+
+__global__ void fill_lp_kernel(lp_t* __restrict__ v, int64_t n, lp_t value) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) v[idx] = value;
+}
+}  // namespace
+
+hipError_t rms_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r, hipStream_t s) {
+  if (cols % 64 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rms_rstd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, eps, r);
+  return hipGetLastError();
+}
+
+hipError_t rms_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s) {
+  if (cols % 64 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(rms_rstd_partials_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, partials, ld, rows, cols, eps, r);
+  return hipGetLastError();
+}
+
+hipError_t scale_cols_lp(lp_t* W, const lp_t* w, int64_t rows, int K, hipStream_t s) {
+  if (K % 8 || rows <= 0) return hipErrorInvalidValue;
+  const int64_t n_vec = rows * (K / 8);
+  hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)((n_vec + 255) / 256)), dim3(256), 0, s, W, w, n_vec, K / 8);
+  return hipGetLastError();
+}
+
+hipError_t fill_lp(lp_t* v, int64_t n, float value, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_lp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, v, n, f2lp(value));
+  return hipGetLastError();
+}
+
 hipError_t rmsnorm_lp(const lp_t* x, const lp_t* gamma, lp_t* y, int rows, int cols, float eps,
                         const int32_t* row_index, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
