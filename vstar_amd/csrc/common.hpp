@@ -64,6 +64,17 @@ __device__ __forceinline__ f32x16 mfma_32x32x16(lpx8 a, lpx8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 #endif
+// v + (v of the lane at xor 1 / xor 2 inside a quad, or of the mirrored lane inside a group of 8) by DPP: no LDS traffic.
+// After the xor-1 and xor-2 steps the four lanes of a quad agree, so the half-mirror step equals an xor-4 exchange.
+__device__ __forceinline__ float dpp_add_xor1(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_add_xor2(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_add_half_mirror(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float rlp(float f) { return lp2f(f2lp(f)); }  // round through the storage type
 
 // fp8 e4m3 (OCP) x fp8 e4m3 -> fp32, K = 128, block scales fixed at 1.0 (E8M0 0x7F): operands are 32 bytes per lane, any

@@ -37,6 +37,11 @@ struct vstar_engine : EngineBase {
   int lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
            const lp_t* res, int64_t ldr, const lp_t* rope_cs = nullptr, int rope_S = 0, int rope_cols = 0);
   bool fused_rope = true;      // VSTAR_FUSED_ROPE=0 keeps RoPE as a separate pass (A/B and the bit-identity test)
+  // RMSNorms of the LLaMA blocks folded into the linears that consume them (default; VSTAR_FOLD_NORMS=0 before vstar_create keeps
+  // the norm kernels): weight folded into W's columns at load, 1/rms applied to the accumulators, statistics from the epilogue
+  // that writes the residual stream.  lr [rows] = rstd of the pass in flight, lpart [rows, H/64] = the epilogue's partial sums.
+  bool fold_norms = true;
+  float *lr = nullptr, *lpart = nullptr;
   lp_t *lx = nullptr, *lh = nullptr, *lqkv = nullptr, *latt = nullptr, *lact = nullptr;
   lp_t* hsel = nullptr;      // [B*(1+V), H] normed hidden rows
   lp_t *sel_att = nullptr, *sel_x = nullptr, *sel_h = nullptr, *sel_act = nullptr;   // last-block row subset
@@ -156,6 +161,20 @@ int vstar_engine::finalize() {
     RC(make_lin({lp + "mlp.gate_proj.weight", lp + "mlp.up_proj.weight"}, {}, &b.gate_up, H, &perm));
     RC(make_lin({lp + "mlp.down_proj.weight"}, {}, &b.down, c.llm_mlp));
   }
+  if (c.llm_w8a8) fold_norms = false;      // W8A8 keeps its quantisation scheme (normalised activations per token, W per channel)
+  if (fold_norms) {
+    // Linear(RMSNorm(x)) = rstd(x) * (x . (W * diag(norm_w))^T): the norm weights move into the columns of the q|k|v and gate|up
+    // matrices (one bf16 rounding of W * w in place of the reference's two activation roundings), and the vectors become 1 so that
+    // every other user of these blocks (decode runner, gathered last-block rows) stays correct as written
+    if (H % 64) { set_error("fold_norms needs llm_hidden % 64 == 0"); return VSTAR_ERR_INVALID; }
+    for (auto& b : llm) {
+      KCHK(scale_cols_lp(b.qkv.W, b.in_norm, (int64_t)((b.qkv.N + 255) / 256 * 256), b.qkv.K, stream));
+      KCHK(scale_cols_lp(b.gate_up.W, b.post_norm, (int64_t)((b.gate_up.N + 255) / 256 * 256), b.gate_up.K, stream));
+      KCHK(fill_lp(b.in_norm, H, 1.0f, stream));
+      KCHK(fill_lp(b.post_norm, H, 1.0f, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+  }
   if (c.llm_w8a8) {
     for (auto& b : llm) {
       RC(make_lin8(b.qkv, &b.qkv8));
@@ -186,6 +205,8 @@ int vstar_engine::finalize() {
   RC(dalloc(&lh, lrows * H));
   RC(dalloc(&lqkv, lrows * 3 * H));
   RC(dalloc(&latt, lrows * H));
+  RC(dalloc(&lr, lrows));
+  RC(dalloc(&lpart, lrows * (size_t)(H / 64 > 0 ? H / 64 : 1)));
   RC(dalloc(&lact, lrows * c.llm_mlp));
   if (c.llm_w8a8) {
     RC(dalloc(&lq8, lrows * (size_t)(c.llm_mlp > H ? c.llm_mlp : H)));
@@ -432,6 +453,7 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
   // the attention runs unchanged over the full sequences after the prefix's q|k|v rows were copied to the head of each, plus
   // one small launch for the prefix sequence itself.
   const int Lp = w8 ? 0 : psh_Lp;
+  const bool fold = fold_norms && !w8;
   const int Sr = S - Lp;
   const int M = Lp ? nseq * Sr + Lp : rows;             // rows of the linears
   const int nrows = Lp ? rows + 2 * Lp : rows;          // rows of the row-wise kernels (slot nseq: [0, 2 Lp))
@@ -453,10 +475,19 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
       if (!fused_rope) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
     } else {
-      KCHK(rmsnorm_lp(lx, b.in_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
-      // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
+      // input RMSNorm: folded (statistics from x for the first block — the spliced embeddings — else from the partial sums the
+      // previous block's down_proj epilogue wrote next to the residual stream) or the norm kernel
       GemmParams p{};
-      p.A = lh; p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = M; p.N = b.qkv.N; p.K = b.qkv.K;
+      if (fold) {
+        if (i == 0) KCHK(rms_rstd_rows(lx, nrows, H, c.llm_rms_eps, lr, stream));
+        else KCHK(rms_rstd_partials(lpart, H / 64, nrows, H, c.llm_rms_eps, lr, stream));
+        p.A = lx; p.row_scale = lr;
+      } else {
+        KCHK(rmsnorm_lp(lx, b.in_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
+        p.A = lh;
+      }
+      // q|k|v projection; RoPE rides in the GEMM epilogue when the 256^2 kernel takes the shape (else a separate pass)
+      p.lda = H; p.W = b.qkv.W; p.C = lqkv; p.ldc = 3 * H; p.M = M; p.N = b.qkv.N; p.K = b.qkv.K;
       if (Lp) { p.a_group = p.c_group = Sr; p.a_gstride = p.c_gstride = S; p.a_off = p.c_off = Lp; }
       const bool fused = fused_rope && gemm256_eligible(p);
       if (fused) {
@@ -495,10 +526,20 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       KCHK(quantize_rows_fp8(lact, c.llm_mlp, lq8, c.llm_mlp, lsa, rows, c.llm_mlp, stream));
       RC(lin8(lq8, lsa, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
     } else {
-      RC(lin(latt, H, b.o, lx, H, M, VSTAR_EPI_NONE, lx, H));
-      KCHK(rmsnorm_lp(lx, b.post_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
-      RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, M, VSTAR_EPI_SILU_MUL));
-      RC(lin(lact, c.llm_mlp, b.down, lx, H, M, VSTAR_EPI_NONE, lx, H));
+      if (fold) {
+        next_sumsq = lpart; next_sumsq_ld = H / 64;
+        RC(lin(latt, H, b.o, lx, H, M, VSTAR_EPI_NONE, lx, H));
+        KCHK(rms_rstd_partials(lpart, H / 64, nrows, H, c.llm_rms_eps, lr, stream));
+        next_row_scale = lr;
+        RC(lin(lx, H, b.gate_up, lact, c.llm_mlp, M, VSTAR_EPI_SILU_MUL));
+        next_sumsq = lpart; next_sumsq_ld = H / 64;
+        RC(lin(lact, c.llm_mlp, b.down, lx, H, M, VSTAR_EPI_NONE, lx, H));
+      } else {
+        RC(lin(latt, H, b.o, lx, H, M, VSTAR_EPI_NONE, lx, H));
+        KCHK(rmsnorm_lp(lx, b.post_norm, lh, nrows, H, c.llm_rms_eps, nullptr, stream));
+        RC(lin(lh, H, b.gate_up, lact, c.llm_mlp, M, VSTAR_EPI_SILU_MUL));
+        RC(lin(lact, c.llm_mlp, b.down, lx, H, M, VSTAR_EPI_NONE, lx, H));
+      }
     }
   }
   return 0;
@@ -849,6 +890,7 @@ int vstar_create(const vstar_config* cfg, int device, vstar_handle** out) {
   vstar_engine* h = new vstar_engine();
   h->cfg = *cfg;
   if (const char* e = getenv("VSTAR_FUSED_ROPE")) h->fused_rope = atoi(e) != 0;
+  if (const char* e = getenv("VSTAR_FOLD_NORMS")) h->fold_norms = atoi(e) != 0;
   h->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) {
     tls_error() = "hipStreamCreate failed";

@@ -205,6 +205,8 @@ struct EngineBase {
     p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr;
     p.C = C; p.ldc = ldc; p.c_group = 0;
     p.M = M; p.N = L.N; p.K = L.K;
+    p.row_scale = next_row_scale; p.sumsq_out = next_sumsq; p.sumsq_ld = next_sumsq_ld;     // one-shot (folded RMSNorm, llm_forward)
+    next_row_scale = nullptr; next_sumsq = nullptr; next_sumsq_ld = 0;
     if (map_group > 0) {      // row map in force (shared-prefix LLaMA pass): compact row r -> (r / group) * gstride + off + r % group
       p.a_group = p.c_group = map_group;
       p.a_gstride = p.c_gstride = map_gstride;
@@ -213,6 +215,7 @@ struct EngineBase {
     return gemm(p, epi, f32);
   }
   int map_group = 0; int64_t map_gstride = 0, map_off = 0;
+  const float* next_row_scale = nullptr; float* next_sumsq = nullptr; int next_sumsq_ld = 0;   // consumed by the next lin()
   void collect_profile() {
     if (!profile) return;
     for (size_t i = 0; i + 1 < ev_used; i += 2) {

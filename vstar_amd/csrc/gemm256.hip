@@ -230,6 +230,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   }
   if (group == 0) BAR();   // every wave must execute the same number of barriers
 
+  // folded RMSNorm: this lane's eight row scales, requested before the next tile's set-up so that they land behind it
+  float rs_v[8];
+  if constexpr (!F8) {
+    if (p.row_scale) {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int row = m0 + wr * 128 + m * 16 + fr;
+        rs_v[m] = p.row_scale[gemm_map_row(row < p.M ? row : p.M - 1, p.a_group, p.a_gstride, p.a_off)];
+      }
+    }
+  }
   // ---- next tile: its K-tile 0 goes into ring buffer 0 now; this tile's coordinates stay in em0/en0 for the epilogue ----
   const int em0 = m0, en0 = n0;
   bid += gridDim.x;
@@ -266,14 +277,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   if constexpr (!F8) {
     if (p.row_scale) {
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int row = em0 + wr * 128 + m * 16 + fr;
-        const float rs = p.row_scale[gemm_map_row(row < p.M ? row : p.M - 1, p.a_group, p.a_gstride, p.a_off)];
+      for (int m = 0; m < 8; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[m][n][e] *= rs;
-      }
+          for (int e = 0; e < 4; ++e) acc[m][n][e] *= rs_v[m];
     }
   }
 

@@ -130,7 +130,10 @@ __device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, in
     }
   }
   if (full) {
-    __builtin_nontemporal_store(v, (lpx8*)c);
+    // streaming store, except when the rows are the next linear's A operand right away (sumsq_out = the residual stream feeding a
+    // folded RMSNorm): those should stay cache-resident
+    if (p.sumsq_out) *(lpx8*)c = v;
+    else __builtin_nontemporal_store(v, (lpx8*)c);
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) if (col + e < n_out) c[e] = (lp_t)v[e];
@@ -146,11 +149,7 @@ __device__ __forceinline__ float gemm_sumsq_span64_chunks(const lpx8& v) {
   for (int e = 0; e < 8; ++e) f[e] = lp2f((lp_t)v[e]);
   const float h0 = ((f[0] * f[0] + f[1] * f[1]) + f[2] * f[2]) + f[3] * f[3];
   const float h1 = ((f[4] * f[4] + f[5] * f[5]) + f[6] * f[6]) + f[7] * f[7];
-  float s = h0 + h1;
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  return s;
+  return dpp_add_half_mirror(dpp_add_xor2(dpp_add_xor1(h0 + h1)));
 }
 // gemm128 layout (accumulator layout): lane (fr = lane & 15, fq = lane >> 4) holds columns n*16 + fq*4 + {0..3} of fragment n = 0..3
 // as o[n][0..3]; half-chunks meet across lane ^ 16, chunks of a fragment across lane ^ 32, fragments inside the lane.

@@ -103,11 +103,15 @@ namespace {
 __device__ __forceinline__ float sumsq_span64(const float (&v)[8]) {
   const float h0 = ((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]) + v[3] * v[3];
   const float h1 = ((v[4] * v[4] + v[5] * v[5]) + v[6] * v[6]) + v[7] * v[7];
-  float s = h0 + h1;
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  return s;
+  return dpp_add_half_mirror(dpp_add_xor2(dpp_add_xor1(h0 + h1)));
+}
+
+// Across the spans of a row: 64 spans at a time, one per lane, added by a butterfly (xor 1 .. 32); passes of 64 spans are added in
+// order.  rms_rstd_rows and rms_rstd_partials share this, so the two agree bit for bit.
+__device__ __forceinline__ float sum_spans64(float v) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
 
 __global__ __launch_bounds__(256) void rms_rstd_rows_kernel(const lp_t* __restrict__ x, int rows, int cols, float eps, float* __restrict__ r) {
@@ -116,36 +120,42 @@ __global__ __launch_bounds__(256) void rms_rstd_rows_kernel(const lp_t* __restri
   if (row >= rows) return;
   const lp_t* xr = x + (int64_t)row * cols;
   const int nspan = cols >> 6;
-  float total = 0.f;                                   // spans are added in column order, like rms_rstd_partials
-  for (int s0 = 0; s0 < nspan; s0 += 8) {              // 8 spans per pass: lane -> span s0 + lane/8, chunk lane%8
-    const int sp = s0 + (lane >> 3);
-    float v[8];
-    if (sp < nspan) {
-      const lpx8 t = *(const lpx8*)(xr + sp * 64 + (lane & 7) * 8);
+  float total = 0.f;
+  for (int p0 = 0; p0 < nspan; p0 += 64) {             // 64 spans per pass
+    float mine = 0.f;                                  // the partial sum of span p0 + lane
+    for (int s0 = 0; s0 < 64; s0 += 8) {               // 8 spans per load: lane -> span p0 + s0 + lane/8, chunk lane%8
+      const int sp = p0 + s0 + (lane >> 3);
+      float v[8];
+      if (sp < nspan) {
+        const lpx8 t = *(const lpx8*)(xr + sp * 64 + (lane & 7) * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = lp2f((lp_t)t[e]);
-    } else {
+        for (int e = 0; e < 8; ++e) v[e] = lp2f((lp_t)t[e]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      const float part = sumsq_span64(v);              // valid in all 8 lanes of the span
+      const float got = __shfl(part, (lane & 7) * 8, 64);      // lane l (< 8 relevant) fetches span s0 + (l & 7)
+      if ((lane >> 3) == (s0 >> 3)) mine = got;        // lanes s0 .. s0+7 keep spans p0 + s0 .. p0 + s0 + 7
     }
-    const float part = sumsq_span64(v);                // valid in all 8 lanes of the span
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float pj = __shfl(part, j * 8, 64);
-      if (s0 + j < nspan) total += pj;
-    }
+    total += sum_spans64(mine);
   }
   if (lane == 0) r[row] = rsqrtf(total / (float)cols + eps);
 }
 
-__global__ void rms_rstd_partials_kernel(const float* __restrict__ partials, int ld, int rows, int cols, float eps, float* __restrict__ r) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void rms_rstd_partials_kernel(const float* __restrict__ partials, int ld, int rows, int cols, float eps,
+                                                                float* __restrict__ r) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* pr = partials + (int64_t)row * ld;
   const int nspan = cols >> 6;
   float total = 0.f;
-  for (int j = 0; j < nspan; ++j) total += pr[j];
-  r[row] = rsqrtf(total / (float)cols + eps);
+  for (int p0 = 0; p0 < nspan; p0 += 64) {
+    const float mine = (p0 + lane < nspan) ? pr[p0 + lane] : 0.f;      // one coalesced 256-byte read per row and pass
+    total += sum_spans64(mine);
+  }
+  if (lane == 0) r[row] = rsqrtf(total / (float)cols + eps);
 }
 
 __global__ void scale_cols_kernel(lp_t* __restrict__ W, const lp_t* __restrict__ w, int64_t n_vec, int kv) {
@@ -173,7 +183,7 @@ hipError_t rms_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r,
 
 hipError_t rms_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s) {
   if (cols % 64 || rows <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(rms_rstd_partials_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, partials, ld, rows, cols, eps, r);
+  hipLaunchKernelGGL(rms_rstd_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, partials, ld, rows, cols, eps, r);
   return hipGetLastError();
 }
 
