@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
         const int64_t crow = gemm_map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off);
         if (row < p.M && !(p.debug_flags & 1)) gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
-        if constexpr (EPI == VSTAR_EPI_NONE) {
+        if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
           if (p.sumsq_out) {          // tile-uniform: statistics of the next RMSNorm from the values just stored (8 lanes = this row's 64 columns)
             const float ss = gemm_sumsq_span64_chunks(v);
             if (ch == 0 && row < p.M && colbase < n_out) p.sumsq_out[crow * p.sumsq_ld + colbase / 64] = ss;
