@@ -334,3 +334,79 @@ def test_prompts_match_the_references_conversation_templates():
         assert got == g["prompt"], (g["conv_type"], g["use_mm_start_end"], g["answer"])
     with pytest.raises(ValueError):
         pp.build_prompt("q", True, None, conv_type="mpt")
+
+
+# ---------------- grouped scoring bookkeeping (VSM._score_boxes_grouped) on a CPU stand-in for the engine ----------------
+import warnings  # noqa: E402
+
+from vstar_amd.synthetic import synthetic_image  # noqa: E402
+class _GroupedFakeEngine(_FakeEngine):
+    """Adds the on-device entry points: crops travel as boxes; a record is a function of (box, the prompt's token ids), whichever
+    entry point produced it — so any slip in the grouping's index bookkeeping shows up as a wrong record in the caller's order."""
+
+    def __init__(self, max_batch=4, max_text_len=96):
+        super().__init__(max_batch)
+        from vstar_amd.config import VSMConfig
+        self.cfg = VSMConfig.tiny(max_batch=max_batch, max_text_len=max_text_len)
+        self.grouped_calls, self.plain_calls, self._boxes = [], [], None
+
+    def set_image(self, image):
+        self.image = image
+
+    @staticmethod
+    def _rec(box, ids):
+        import zlib
+        from vstar_amd import _lib
+        rec = np.zeros(_lib.RESULT_FLOATS, np.float32)
+        seed = zlib.crc32(repr((tuple(int(v) for v in box), tuple(int(t) for t in ids if t != 0))).encode()) % (2 ** 31)
+        rec[:16] = np.random.default_rng(seed).standard_normal(16)
+        return rec
+
+    def score_boxes(self, xyxy, ids, loc, verify_pos=None, raw=False, out_dev=None, share_prefix=None):
+        self.plain_calls.append(len(xyxy))
+        assert len(xyxy) <= self.cfg.max_batch
+        out = np.stack([self._rec(b, row) for b, row in zip(np.asarray(xyxy), np.asarray(ids))])
+        return out if raw else self.unpack(out, 0)
+
+    def preprocess_boxes(self, xyxy):
+        self._boxes = np.asarray(xyxy)
+
+    def score_grouped(self, clip, owl, prefix_ids, suffix_ids, loc_in_suffix, verify_in_suffix=None, raw=False, internal_pixels=False):
+        G, T, Ls = suffix_ids.shape
+        assert internal_pixels and len(self._boxes) == G and G * T <= self.cfg.max_batch and Ls <= 32
+        self.grouped_calls.append((G, T))
+        out = np.stack([self._rec(self._boxes[g], list(prefix_ids) + list(suffix_ids[g, t])) for g in range(G) for t in range(T)])
+        return out if raw else self.unpack(out, 0)
+
+
+@pytest.mark.parametrize("mode", [True, "always"])
+def test_grouped_scoring_bookkeeping_returns_records_in_the_callers_order(mode):
+    from vstar_amd.vsm import VSM
+    eng = _GroupedFakeEngine(max_batch=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(eng.cfg.llm_vocab), strict_template=False)
+        vsm.set_image(synthetic_image(400, 300, 1))
+        vsm.group_prompts = mode
+        qs = [pp.LOCATE_QUESTION.format(n) for n in ("kite", "red umbrella", "dog")] + ["What is shown here?"]
+        boxes = [[0, 0, 400, 300], [0, 0, 200, 150], [200, 0, 200, 150], [0, 150, 200, 150]]
+        # box 0: three template prompts + one foreign question; box 1: two prompts; box 2: one prompt; box 3: the foreign question only
+        pairs = [(0, 0), (1, 1), (0, 1), (2, 2), (0, 2), (1, 0), (0, 3), (3, 3)]
+        out = vsm.inference_boxes([boxes[b] for b, _ in pairs], [qs[q] for _, q in pairs], mode="detection", upsample=False)
+    want = []
+    for b, q in pairs:
+        ids = vsm._ids(qs[q])[0]
+        x, y, w, h = boxes[b]
+        want.append(_GroupedFakeEngine._rec([x, y, x + w, y + h], ids))
+    got = np.stack([o[0].numpy().ravel() for o in out])      # pred_boxes of each result
+    from vstar_amd.engine import VstarEngine
+    ref = VstarEngine.unpack(np.stack(want), 0)["pred_boxes"].reshape(len(pairs), -1)
+    assert np.array_equal(got, ref)
+    # the foreign question never takes the grouped entry point; template prompts of multi-prompt crops always do
+    assert (1, 3) in eng.grouped_calls or any(T == 3 for _, T in eng.grouped_calls)
+    if mode == "always":
+        assert any(T == 1 for _, T in eng.grouped_calls)            # box 2's single prompt goes through the grouped entry too
+        assert sum(eng.plain_calls) == 2                            # only the two foreign-question pairs stay on the plain path
+    else:
+        assert all(T >= 2 for _, T in eng.grouped_calls)
+        assert sum(eng.plain_calls) == 3
