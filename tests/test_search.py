@@ -299,3 +299,47 @@ def test_lock_step_many_equals_loop_on_random_settings(seed):
     pairs = [p for c in many_vsm.calls for p in c]
     assert len(pairs) == len(set(pairs))
     assert sorted(pairs) == sorted(p for c in solo.calls for p in c)
+
+
+class _BoxVSMStats(_BoxVSM):
+    """_BoxVSM + on-device-style heat-map statistics (single and batched), recording how the scheduler asks for them."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.stat_calls = []
+
+    @property
+    def supports_device_reductions(self):
+        return True
+
+    def heatmap_stats(self, low, h, w, rects=None):
+        self.stat_calls.append(1)
+        return self._stats(low, h, w, rects)
+
+    def _stats(self, low, h, w, rects):
+        H = self.upsample_heatmap(torch.as_tensor(np.asarray(low)), h, w).double().numpy()
+        return np.asarray([H.min(), H.max(), H.sum()] + [H[y:y + rh, x:x + rw].sum() for x, y, rw, rh in (rects or [])], np.float64)
+
+    def heatmap_stats_batch(self, items):
+        self.stat_calls.append(len(items))
+        return [self._stats(*it) for it in items]
+
+
+def test_lock_step_batches_the_heat_map_statistics_of_all_targets():
+    """Device reductions in lock step: every target's statistics requests of a round (a node's own map and its ancestors') are
+    served by ONE batched call; the searches equal the per-target loop's, which equal the one-call-per-map path."""
+    from vstar_amd.search import smallest_size_for, visual_search, visual_search_many
+    img = synthetic_image(1100, 700, 5)
+    smallest = smallest_size_for(1100, 700, 4.0)
+    names = ["kite", "dog", "boat"]
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    loop_vsm = _BoxVSMStats()
+    loop = [visual_search(loop_vsm, img, n, None, smallest, **kw) for n in names]
+    many_vsm = _BoxVSMStats()
+    many = visual_search_many(many_vsm, img, names, None, smallest, **kw)
+    for a, b in zip(loop, many):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert float(a[0]["score"] or 0) == float(b[0]["score"] or 0)
+    assert sum(many_vsm.stat_calls) == sum(loop_vsm.stat_calls)          # the same statistics in total ...
+    assert len(many_vsm.stat_calls) < len(loop_vsm.stat_calls)           # ... in fewer calls
+    assert max(many_vsm.stat_calls) >= len(names)                        # a round's requests of all targets in one call
