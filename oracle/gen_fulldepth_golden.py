@@ -5,7 +5,10 @@ on crops of the EXACT batch bench.py scores (vstar_amd.synthetic.bench_inputs, B
 
 TEST INFRASTRUCTURE.  Run once in the build container (needs /root/reference, ~45 GB RAM, ~6 min on 8 cores):
     python -m oracle.gen_fulldepth_golden
-Writes tests/golden/full7b_336.npz (outputs only: fp32 reference + the reference in bf16 as the noise yardstick).
+    python -m oracle.gen_fulldepth_golden --image-size 224 --crops 0,11,21,31      # the geometry the reference really runs
+Writes tests/golden/full7b_{336,224}.npz (outputs only: fp32 reference + the reference in bf16 as the noise yardstick).
+Round 3: eight crops of the 336^2 bench batch and four of the 224^2 / S = 320 batch
+(CLIP-L/14@224, 256 image tokens: VisualSearch/model/VSM.py:230-234,466-473 hard-code that geometry).
 The GPU test (tests/test_fulldepth_gpu.py) scores the whole 32-crop batch and compares the recorded crops: this is what pins
 error growth over 32+23+12 layers and arg-max / top-k stability at the bench shape.
 """
@@ -25,8 +28,8 @@ from vstar_amd.config import VSMConfig  # noqa: E402
 from vstar_amd.synthetic import bench_inputs  # noqa: E402
 from vstar_amd.weights import random_state_dict  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "full7b_336.npz")
-CROPS = (0, 17)          # indices into the bench batch
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CROPS = (0, 4, 9, 13, 17, 22, 26, 31)          # indices into the bench batch (0 and 17 were the round-2 pair)
 B, T = 32, 64
 
 
@@ -55,10 +58,10 @@ def build_reference(cfg, loc_id, sd):
     return model
 
 
-def run(model, cfg, loc_id, clip, owl, ids, verify, dtype):
+def run(model, cfg, loc_id, clip, owl, ids, verify, dtype, crops=CROPS):
     P = cfg.n_img_tokens
     rec = {}
-    for ci in CROPS:
+    for ci in crops:
         # fresh CLIP tower per call (transformers 5.x harness artefact, see gen_golden.py; verified to reproduce the tiny goldens)
         from transformers import CLIPVisionModel
         vt = model.get_model().get_vision_tower()
@@ -95,9 +98,17 @@ def run(model, cfg, loc_id, clip, owl, ids, verify, dtype):
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--image-size", type=int, default=336, choices=(224, 336))
+    ap.add_argument("--crops", type=str, default=None)
+    ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
+    a = ap.parse_args()
+    crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else CROPS
+    out_path = os.path.join(GOLDEN, f"full7b_{a.image_size}.npz")
     assert ref_shim.available(), "reference tree not found"
-    torch.set_num_threads(len(os.sched_getaffinity(0)))
-    cfg = VSMConfig.seal_7b(336, max_batch=B, max_text_len=T + 1)
+    torch.set_num_threads(a.threads)
+    cfg = VSMConfig.seal_7b(a.image_size, max_batch=B, max_text_len=T + 1)
     loc_id = cfg.llm_vocab - 1
     clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
     t0 = time.time()
@@ -105,14 +116,14 @@ def main():
     model = build_reference(cfg, loc_id, sd)
     del sd
     print(f"reference built + loaded in {time.time() - t0:.0f}s", flush=True)
-    f32 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.float32)
+    f32 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.float32, crops)
     model = model.bfloat16()
-    b16 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.bfloat16)
+    b16 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.bfloat16, crops)
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))  # noqa: E731
     print("reference-bf16 vs reference-fp32 rel-L2:", {k: "%.2e" % rel(b16[k], f32[k]) for k in f32 if k.startswith(("pred", "low", "llm", "embed", "sam"))})
-    np.savez_compressed(OUT, crops=np.asarray(CROPS), batch=B, text_tokens=T, weight_seed=0,
+    np.savez_compressed(out_path, crops=np.asarray(crops), batch=B, text_tokens=T, weight_seed=0, image_size=a.image_size,
                         **{k: v for k, v in f32.items()}, **{"bf16_" + k: v for k, v in b16.items()})
-    print("->", OUT, os.path.getsize(OUT) // 1024, "KiB")
+    print("->", out_path, os.path.getsize(out_path) // 1024, "KiB")
 
 
 if __name__ == "__main__":

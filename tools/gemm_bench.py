@@ -14,6 +14,9 @@ from vstar_amd import _lib  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--rotate", type=int, default=1, help="cycle through this many copies of W (small batches: one copy would sit in the "
+                "256 MB Infinity Cache, while the engine streams every layer's own weights from HBM)")
+ap.add_argument("--only", type=str, default="", help="substring filter on the shape name")
 args = ap.parse_args()
 lib = _lib.load()
 dev = torch.device("cuda:0")
@@ -29,16 +32,22 @@ shapes = [("llama qkv", B * S, 12288, 4096, 0, 0), ("llama o +res", B * S, 4096,
 P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
 print(f"{'shape':<22s} {'M':>7s} {'N':>6s} {'K':>6s} {'ms':>8s} {'TFLOP/s':>8s}")
 for name, M, N, K, epi, has_res in shapes:
+    if args.only and args.only not in name:
+        continue
     a = torch.randn(M, K, device=dev).bfloat16()
     npad = (N + 255) // 256 * 256
     w = torch.zeros(npad, K, device=dev, dtype=torch.bfloat16)
     w[:N] = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    ws = [w] + [w.clone() for _ in range(args.rotate - 1)]
+    it = [0]
     n_out = N // 2 if epi == 4 else N
     c = torch.empty(M, n_out, device=dev, dtype=torch.bfloat16)
     res = torch.randn(M, n_out, device=dev).bfloat16() if has_res else None
     bias = torch.randn(npad, device=dev).bfloat16() if name.split()[0] in ("clip", "owl", "sam") else None
 
     def run():
+        w = ws[it[0] % len(ws)]
+        it[0] += 1
         rc = lib.vstar_op_gemm(None, P(a), K, P(w), P(bias) if bias is not None else None, P(res) if res is not None else None, n_out, P(c), n_out, 0, M, N, K,
                                epi | 0x100)
         assert rc == 0

@@ -26,8 +26,11 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int LDS_TILE = BM * BK * 2;            // 16 KiB per operand tile
-constexpr int LDS_BUF = 2 * LDS_TILE;            // A + W
-constexpr int LDS_TOTAL = 2 * LDS_BUF;           // double buffered = 64 KiB
+constexpr int LDS_BUF = 2 * LDS_TILE;            // A + W = 32 KiB per K-tile
+// STAGES = 2: double buffer (64 KiB, two workgroups per CU), every K-tile ends in __syncthreads (vmcnt(0) + barrier).
+// STAGES = 3 (round 3, the default): 96-KiB ring, the DMA runs TWO K-tiles ahead behind a COUNTED vmcnt(8) and there is one
+// bare s_barrier per K-tile — the latency regime of small batches (M = 640..2560: under-filled grids, one workgroup per CU,
+// every weight byte straight from HBM) no longer pays a full DMA round trip per K-tile.  Same K order: bit-identical.
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -36,8 +39,17 @@ __device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, in
   return gemm_map_row(r, group, gstride, off);
 }
 
-template <int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
+#define BAR128()                                       \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    asm volatile("s_barrier" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+
+template <int EPI, bool OUT_F32, int MODE>
+__global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm128_kernel(const GemmParams p) {
+  constexpr bool LDR = MODE == 5;
+  constexpr int STAGES = LDR ? 3 : MODE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -88,6 +100,44 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
     }
   };
 
+  if constexpr (LDR) {
+    if (wave == 4) {
+      // ---- loader wave: all 16 A pieces + 16 W pieces of every K-tile, two K-tiles ahead of the compute waves ----
+      const lp_t* a_all[16];
+      const lp_t* w_all[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = j * 8 + st_r;
+        const int cg = st_c ^ ((r >> 1) & 7);
+        int ar = m0 + r;
+        ar = ar < p.M ? ar : p.M - 1;
+        a_all[j] = p.A + map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8;
+        w_all[j] = p.W + (int64_t)(n0 + r) * p.K + cg * 8;
+      }
+      auto issue = [&](int buf, int k0) {
+        char* base = smem + buf * LDS_BUF;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          __builtin_amdgcn_global_load_lds((gptr_t)(a_all[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gptr_t)(w_all[j] + k0), (lptr_t)(base + LDS_TILE + j * 1024), 16, 0, 0);
+        }
+      };
+      const int nk = p.K / BK;
+      issue(0, 0);
+      if (nk > 1) issue(1, BK);
+      int slot = 2;
+      for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // K-tile kt has landed, kt+1 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BAR128();                 // publishes K-tile kt; every compute wave is done with slot (kt-1) % 3
+        if (kt + 2 < nk) issue(slot, (kt + 2) * BK);
+        slot = slot == 2 ? 0 : slot + 1;
+      }
+      return;
+    }
+  }
+
   // ---- fragment read offsets ----
   const int wr = wave >> 1, wc = wave & 1;
   const int fr = lane & 15, fq = lane >> 4;
@@ -107,12 +157,35 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nkt = p.K / BK;
-  stage(0, 0);
-  __syncthreads();   // drains the DMA (vmcnt(0)) and makes tile 0 visible
+  if constexpr (!LDR) stage(0, 0);
+  if constexpr (LDR) {
+  } else if constexpr (STAGES == 2) {
+    __syncthreads();   // drains the DMA (vmcnt(0)) and makes tile 0 visible
+  } else {
+#pragma unroll
+    for (int t = 1; t < STAGES - 1; ++t)
+      if (t < nkt) stage(t, t * BK);
+  }
 
+  int cur = 0;         // ring slot of K-tile kt
   for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nkt) stage(cur ^ 1, (kt + 1) * BK);
+    if constexpr (LDR) {
+      BAR128();          // the loader wave has K-tile kt in slot `cur`
+    } else if constexpr (STAGES == 2) {
+      cur = kt & 1;
+      if (kt + 1 < nkt) stage(cur ^ 1, (kt + 1) * BK);
+    } else {
+      // this wave's 8 DMA pieces of K-tile kt have landed once at most the 8 of K-tile kt+1 are still in flight (vmcnt retires
+      // in order); the barrier then makes every wave's pieces visible AND proves that every wave is done reading slot
+      // (kt-1) % STAGES (its fragment reads were consumed by MFMAs issued before this point) — the slot K-tile kt+STAGES-1 goes
+      // into.
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      BAR128();
+      if (kt + STAGES - 1 < nkt) stage(cur >= 1 ? cur - 1 : STAGES - 1, (kt + STAGES - 1) * BK);      // (cur + STAGES - 1) % STAGES
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const char* base = smem + cur * LDS_BUF;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -127,7 +200,11 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
         for (int n = 0; n < 4; ++n)
           acc[m][n] = mfma_16x16x32(wf[n], af[m], acc[m][n]);
     }
-    __syncthreads();   // next tile landed (vmcnt(0)) + everyone done reading buf[cur]
+    if constexpr (!LDR && STAGES == 2) {
+      __syncthreads();   // next tile landed (vmcnt(0)) + everyone done reading buf[cur]
+    } else {
+      cur = cur == STAGES - 1 ? 0 : cur + 1;
+    }
   }
 
   // ---- epilogue: lane owns row (m*16+fr), columns fq*4..fq*4+3 of each 16x16 fragment ----
@@ -178,18 +255,39 @@ __global__ __launch_bounds__(256, 2) void gemm128_kernel(const GemmParams p) {
   }
 }
 
-template <int EPI, bool OUT_F32>
-hipError_t launch(const GemmParams& p, hipStream_t s) {
+}  // namespace
+int gemm_device_cus();
+namespace {
+
+template <int EPI, bool OUT_F32, int MODE>
+hipError_t launch_stages(const GemmParams& p, hipStream_t s) {
   static bool attr_done = false;
-  auto kern = gemm128_kernel<EPI, OUT_F32>;
+  auto kern = gemm128_kernel<EPI, OUT_F32, MODE>;
+  constexpr int lds = (MODE == 5 ? 3 : MODE) * LDS_BUF;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(MODE == 5 ? 320 : 256), lds, s, p);
   return hipGetLastError();
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch(const GemmParams& p, hipStream_t s) {
+  // Under-filled grids (at most one tile per CU: the small-batch o_proj / down_proj, CLIP out / fc2) take the loader-wave ring
+  // (MODE 5): one workgroup per CU anyway, so the 96-KiB ring costs no occupancy.  Fuller grids keep the 64-KiB double buffer,
+  // where two co-resident workgroups per CU hide each other's DMA round trips and a ragged last round costs nothing.
+  // Measured (profiles/r03_gemm_small_batch.txt, M = 640): o_proj 65 -> 40 us, down_proj 169 -> 104 us, CLIP fc2 54 -> 37 us;
+  // with more tiles than CUs the double buffer wins by 5-15 %.  What bounds both: a CU pulls operand tiles from L2 at
+  // ~65 (one workgroup) to ~88 KB/us (two) whatever the instruction (tools/probes/dma_probe.hip), and a 128^2 tile needs 32 KiB
+  // per K-tile.  VSTAR_GEMM128_STAGES=2|5 forces one variant (A/B runs).  Same K order in both: bit-identical results.
+  static const int force = [] { const char* e = getenv("VSTAR_GEMM128_STAGES"); return e ? atoi(e) : 0; }();
+  const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int mode = force == 2 || force == 5 ? force : (tiles <= gemm_device_cus() && p.K >= 4 * BK ? 5 : 2);
+  if (mode == 5) return launch_stages<EPI, OUT_F32, 5>(p, s);
+  return launch_stages<EPI, OUT_F32, 2>(p, s);
 }
 
 }  // namespace
