@@ -107,9 +107,9 @@ def rms_norm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * xf.to(dt)
 
 
-def rope_tables(S: int, hd: int, theta: float, dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor]:
-    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
-    f = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+def rope_tables(S: int, hd: int, theta: float, dtype: torch.dtype, device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
+    f = torch.outer(torch.arange(S, dtype=torch.float32, device=device), inv)
     emb = torch.cat([f, f], dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
 
@@ -142,8 +142,8 @@ def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, 
     B, S, H = x.shape
     lin8 = (lambda key, t: linear_w8a8(t, sd[key + ".weight"])) if w8a8 else None
     hd = H // heads
-    cos, sin = rope_tables(S, hd, theta, x.dtype)
-    mask = torch.full((S, S), float("-inf")).triu(1)
+    cos, sin = rope_tables(S, hd, theta, x.dtype, x.device)
+    mask = torch.full((S, S), float("-inf"), device=x.device).triu(1)
     for i in range(layers):
         lp = f"model.layers.{i}."
         h = rms_norm(x, sd[lp + "input_layernorm.weight"], eps)
@@ -209,7 +209,7 @@ def owl_heads(sd: SD, feature_map: torch.Tensor, query: torch.Tensor) -> Tuple[t
     logits = (logits + shift) * scale
     bh = "model.owlvit.box_head."
     b = _lin(sd, bh + "dense2", F.gelu(_lin(sd, bh + "dense1", F.gelu(_lin(sd, bh + "dense0", feats)))))
-    b += owl_box_bias(g)
+    b += owl_box_bias(g).to(b.device)
     return logits, torch.sigmoid(b)
 
 
@@ -219,7 +219,7 @@ def owl_heads(sd: SD, feature_map: torch.Tensor, query: torch.Tensor) -> Tuple[t
 def dense_pe(sd: SD, grid: int = 48) -> torch.Tensor:
     """PromptEncoder.get_dense_pe -> [1, 256, g, g] (prompt_encoder.py:67-76,216-229)."""
     gm = sd["model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"]
-    ones = torch.ones((grid, grid), dtype=gm.dtype)
+    ones = torch.ones((grid, grid), dtype=gm.dtype, device=gm.device)
     y = (ones.cumsum(dim=0) - 0.5) / grid
     x = (ones.cumsum(dim=1) - 0.5) / grid
     c = 2 * torch.stack([x, y], dim=-1) - 1
@@ -347,12 +347,12 @@ def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.T
         w = torch.where(input_ids[b] == loc_token_idx)[0]
         assert w.numel() == 1, "one [LOC] per crop"
         loc_pos.append(int(w[0]) - 1 + (P - 1))
-    loc_pos_t = torch.tensor(loc_pos)
-    h_loc = hidden[torch.arange(B), loc_pos_t]
+    loc_pos_t = torch.tensor(loc_pos, device=hidden.device)
+    h_loc = hidden[torch.arange(B, device=hidden.device), loc_pos_t]
     out = {"clip_features": feats, "projector": proj, "llm_hidden_loc": h_loc, "loc_pos": loc_pos_t,
            "embed_det": text_hidden_fcs(sd, "det", h_loc), "embed_seg": text_hidden_fcs(sd, "seg", h_loc)}
     if verify_pos is not None:
-        hv = hidden[torch.arange(B).unsqueeze(1), verify_pos]
+        hv = hidden[torch.arange(B, device=hidden.device).unsqueeze(1), torch.as_tensor(verify_pos, device=hidden.device)]
         out["tf_logits"] = F.linear(hv, sd["lm_head.weight"]).float()        # [B, V, vocab]: lets a test judge arg-max margins
         out["tf_argmax"] = out["tf_logits"].argmax(-1)
     if images is not None:

@@ -42,3 +42,56 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
 
 def fmt(report):
     return "  ".join(f"{k} {a:.2e}/{b:.2e}" for k, (a, b) in report.items())
+
+
+# ---------------- decision-level parity (what the scheduler actually reads) ----------------
+# The search loop (visual_search.py:390-516) consumes a crop's outputs only through a handful of decisions:
+#   * detection: arg-max box of the bf16 sigmoid scores, `top > confidence_high (0.5)`, `top >= confidence_low (0.3)`;
+#   * heat map:  clamp(mask, 0).max() > threshold (6.0 * 0.7^(level-1), floor 3.0) -> cue branch or not;
+#                min-max normalised mass of the four child rectangles -> child ORDER in the priority queue.
+# `decisions()` evaluates them on one crop's raw outputs (on the 192^2 low-res map: the bilinear upsample is a fixed linear map
+# applied to both sides), `decision_agreement()` compares two evaluations of the same crops.
+CUE_THRESHOLDS = (6.0, 6.0 * 0.7, 3.0)
+
+
+def decisions(pred_logits, pred_boxes, low_res_mask):
+    import torch
+    lg = np.asarray(pred_logits, np.float32).reshape(-1)
+    scores = torch.from_numpy(lg).to(torch.bfloat16).sigmoid().float().numpy()       # visual_search.py:225 keeps bf16
+    top = int(scores.argmax())                                                          # first maximum, like tensor.argmax()
+    heat = np.maximum(np.asarray(low_res_mask, np.float64).reshape(192, 192), 0.0)      # visual_search.py:224 clamp(min=0)
+    mx, mn = float(heat.max()), float(heat.min())
+    norm = (heat - mn) / (mx - mn) if mx != mn else heat * 0
+    tot = norm.sum()
+    quads = np.asarray([norm[:96, :96].sum(), norm[:96, 96:].sum(), norm[96:, :96].sum(), norm[96:, 96:].sum()])
+    shares = quads / tot if tot > 0 else quads * 0
+    return {"top_index": top, "top_score": float(scores[top]), "top_box": np.asarray(pred_boxes, np.float64).reshape(-1, 4)[top],
+            "n_valid": int((scores > 0.5).sum()), "score_max": mx, "pos_frac": float((heat > 0).mean()), "child_shares": shares,
+            "child_order": tuple(np.argsort(-shares, kind="stable"))}
+
+
+def decision_agreement(a, b, score_thresholds=(0.5, 0.3), cue_thresholds=CUE_THRESHOLDS):
+    """Identity rates of the scheduler's decisions between two evaluations `a`, `b` (lists of decisions()) of the same crops."""
+    n = len(a)
+    box_iou = []
+    for x, y in zip(a, b):
+        bx, by = x["top_box"], y["top_box"]
+        x1, y1 = max(bx[0] - bx[2] / 2, by[0] - by[2] / 2), max(bx[1] - bx[3] / 2, by[1] - by[3] / 2)
+        x2, y2 = min(bx[0] + bx[2] / 2, by[0] + by[2] / 2), min(bx[1] + bx[3] / 2, by[1] + by[3] / 2)
+        inter = max(0.0, x2 - x1) * max(0.0, y2 - y1)
+        box_iou.append(inter / max(bx[2] * bx[3] + by[2] * by[3] - inter, 1e-12))
+    rep = {"n": n,
+           "argmax_box_same_index": float(np.mean([x["top_index"] == y["top_index"] for x, y in zip(a, b)])),
+           "argmax_box_iou_ge_0.9": float(np.mean([v >= 0.9 for v in box_iou])),
+           "child_order_same": float(np.mean([x["child_order"] == y["child_order"] for x, y in zip(a, b)])),
+           "best_child_same": float(np.mean([x["child_order"][0] == y["child_order"][0] for x, y in zip(a, b)])),
+           "child_share_max_abs_diff": float(np.max([np.abs(x["child_shares"] - y["child_shares"]).max() for x, y in zip(a, b)])),
+           "child_share_rms_diff": float(np.sqrt(np.mean([((x["child_shares"] - y["child_shares"]) ** 2).mean() for x, y in zip(a, b)]))),
+           "pos_frac_max_abs_diff": float(np.max([abs(x["pos_frac"] - y["pos_frac"]) for x, y in zip(a, b)])),
+           "pos_frac_rms_diff": float(np.sqrt(np.mean([(x["pos_frac"] - y["pos_frac"]) ** 2 for x, y in zip(a, b)]))),
+           "score_max_rel_rms": float(np.sqrt(np.mean([((x["score_max"] - y["score_max"]) / max(abs(y["score_max"]), 1e-9)) ** 2 for x, y in zip(a, b)])))}
+    for t in score_thresholds:
+        rep[f"top_score_gt_{t:g}_same"] = float(np.mean([(x["top_score"] > t) == (y["top_score"] > t) for x, y in zip(a, b)]))
+    for t in cue_thresholds:
+        rep[f"score_max_gt_{t:.3g}_same"] = float(np.mean([(x["score_max"] > t) == (y["score_max"] > t) for x, y in zip(a, b)]))
+    return rep
