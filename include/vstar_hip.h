@@ -171,6 +171,16 @@ int vstar_vsm_score_grouped(vstar_handle* h, int G, int T, const uint16_t* clip_
 int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width);
 int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy);
 
+/* Image SLOTS (round 3): several full images resident in HBM at once, so that one engine batch can hold crops of DIFFERENT
+ * images — the cross-image lock-step search (vstar_amd/search.py::visual_search_stream) keeps a window of concurrent
+ * (image, target) searches and fills every batch with the crops they need next, instead of the reference's one-sample-at-a-time
+ * loop (visual_search.py:536-560, vstar_bench_eval.py:190-262).  vstar_image_set == slot 0; vstar_preprocess_crops == every box
+ * from slot 0.  slot in [0, VSTAR_MAX_IMAGE_SLOTS); `slots` [B] names the image of each box (null: all slot 0).  A 4K image is
+ * 25 MB: 64 slots are 1.6 GB of the 288 GB. */
+#define VSTAR_MAX_IMAGE_SLOTS 64
+int vstar_image_set_slot(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width);
+int vstar_preprocess_crops_slots(vstar_handle* h, int B, const int32_t* boxes_xyxy, const int32_t* slots);
+
 /* Greedy free-text decode of ONE crop with a KV cache — VSMForCausalLM.inference for mode='vqa' (VSM.py:438-462 ->
  * generate(max_new_tokens, greedy); called from VSM.inference at visual_search.py:198-219 for the contextual-cue branch,
  * :427-443).  The reference re-runs the whole prefix for every new token (use_cache=False); here the prompt is prefilled

@@ -158,8 +158,11 @@ def test_attention(lib, cuda, B, S, H, D, causal, theta):
     o = out.float().cpu()
     assert not torch.isnan(o).any()
     # P is rounded to bf16 before the PV product and the output is bf16: ~1e-2 absolute on unit-variance V
-    assert (o - ref).abs().max().item() < 3e-2
-    assert _rel(o, ref) < 2e-2
+    print(f"ATTN_ERR plain B{B} S{S} H{H} D{D} c{causal} rope{int(theta > 0)}: abs {(o - ref).abs().max().item():.3e} rel {_rel(o, ref):.3e}")
+    # gates = 2 x the measured error of this kernel (profiles/r03_attention_op_error.txt: abs <= 8.2e-3, rel <= 5.3e-3 over these
+    # shapes; spiked key <= 1.44e-2 abs): a 2 x regression fails
+    assert (o - ref).abs().max().item() < 1.7e-2
+    assert _rel(o, ref) < 1.1e-2
     # a spiked key (rule: force the online-softmax rescale branch): one huge q.k at a late tile
     if S >= 64:
         x = qkv.clone().view(B, S, 3, H, D)
@@ -169,7 +172,8 @@ def test_attention(lib, cuda, B, S, H, D, causal, theta):
         dq2 = x.view(B * S, -1).to(cuda)
         rc = lib.vstar_op_attention(None, P(dq2), P(out), P(ws), ws_bytes, B, S, H, D, causal, 0.0)
         assert rc == 0
-        assert (out.float().cpu() - ref2).abs().max().item() < 3e-2
+        print(f"ATTN_ERR spike B{B} S{S} H{H} D{D} c{causal}: abs {(out.float().cpu() - ref2).abs().max().item():.3e}")
+        assert (out.float().cpu() - ref2).abs().max().item() < 2.9e-2
 
 
 @pytest.mark.parametrize("S,H,D,causal", [(577, 2, 64, 0), (640, 2, 128, 1), (200, 1, 128, 1)])
@@ -197,9 +201,11 @@ def test_attention_softmax_dynamic_range(lib, cuda, S, H, D, causal, profile):
     o = out.float().cpu()
     assert torch.isfinite(o).all()
     # the pre-scaled q (bf16) moves a score of magnitude 90 by ~0.15; a CPU emulation of the kernel's rounding points lands at
-    # 5e-3 relative on these profiles — gate at the plain test's tolerance
-    assert (o - ref).abs().max().item() < 6e-2
-    assert _rel(o, ref) < 3e-2
+    # 5e-3 relative on these profiles
+    print(f"ATTN_ERR range S{S} D{D} c{causal} {profile}: abs {(o - ref).abs().max().item():.3e} rel {_rel(o, ref):.3e}")
+    # measured: abs <= 8.2e-3, rel <= 6.1e-3 (profiles/r03_attention_op_error.txt); gate = 2 x
+    assert (o - ref).abs().max().item() < 1.7e-2
+    assert _rel(o, ref) < 1.25e-2
 
 
 # ---- the 256x256 8-phase kernel (M >= 1024, N >= 256, K % 128 == 0): tails, long K, epilogues, race screen ----

@@ -20,6 +20,7 @@ EXPORTS = [
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
+    "vstar_image_set_slot", "vstar_preprocess_crops_slots",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -29,6 +30,7 @@ EXPORTS_VQA = [
 ]
 
 F32, F16, BF16 = 0, 1, 2
+MAX_IMAGE_SLOTS = 64
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
 EPI_NOSYNC, EPI_TILE128, EPI_TILE256 = 0x100, 0x200, 0x400
 F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS, F_SHARE_PREFIX = 1, 2, 4, 8, 16, 32
@@ -88,6 +90,10 @@ def load() -> ctypes.CDLL:
     lib.vstar_image_set.restype = c_int
     lib.vstar_preprocess_crops.argtypes = [H, c_int, c_void_p]
     lib.vstar_preprocess_crops.restype = c_int
+    lib.vstar_image_set_slot.argtypes = [H, c_int, c_void_p, c_int, c_int]
+    lib.vstar_image_set_slot.restype = c_int
+    lib.vstar_preprocess_crops_slots.argtypes = [H, c_int, c_void_p, c_void_p]
+    lib.vstar_preprocess_crops_slots.restype = c_int
     lib.vstar_heatmap_stats.argtypes = [H, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     lib.vstar_heatmap_stats.restype = c_int
     lib.vstar_heatmap_stats_batch.argtypes = [H, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]

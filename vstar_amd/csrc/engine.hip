@@ -63,7 +63,9 @@ struct vstar_engine : EngineBase {
   void* d_stats = nullptr;
   void* d_stats_batch = nullptr; size_t stats_batch_cap = 0;      // vstar_heatmap_stats_batch scratch
   // GPU-side preprocessing state
-  uint8_t* d_image = nullptr; size_t image_cap = 0; int img_H = 0, img_W = 0;
+  // resident full images, one per slot (vstar_image_set_slot): crops of different images can share an engine batch
+  struct ImageSlot { uint8_t* d = nullptr; size_t cap = 0; int H = 0, W = 0; };
+  ImageSlot images[VSTAR_MAX_IMAGE_SLOTS];
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
   int32_t* d_tables = nullptr; size_t tables_cap = 0;
   PreJob* d_jobs = nullptr;
@@ -71,7 +73,7 @@ struct vstar_engine : EngineBase {
   std::vector<int32_t> h_tables;
   std::vector<PreJob> h_jobs;
   struct AxisTab { int off_b, off_c, ks; };
-  int preprocess(int B, const int32_t* boxes);
+  int preprocess(int B, const int32_t* boxes, const int32_t* slots = nullptr);
   std::vector<int32_t> h_rowidx;
 
   LlmCached gen;                // KV-cached runner for the free-text decode (built on first use: 0.5 GiB of cache)
@@ -328,10 +330,14 @@ int vstar_engine::finalize() {
 }
 
 // crop + pad + Pillow-exact resize + normalise for B boxes of the resident image -> d_clip_pix / d_owl_pix
-int vstar_engine::preprocess(int B, const int32_t* boxes) {
+int vstar_engine::preprocess(int B, const int32_t* boxes, const int32_t* slots) {
   if (!finalized) { set_error("vstar_finalize_weights has not been called"); return VSTAR_ERR_STATE; }
-  if (!d_image) { set_error("no image resident: call vstar_image_set first"); return VSTAR_ERR_STATE; }
   if (B <= 0 || B > cfg.max_batch || !boxes) { set_error("bad preprocess arguments"); return VSTAR_ERR_INVALID; }
+  for (int b = 0; b < B; ++b) {
+    const int sl = slots ? slots[b] : 0;
+    if (sl < 0 || sl >= VSTAR_MAX_IMAGE_SLOTS) { set_error("image slot out of range"); return VSTAR_ERR_INVALID; }
+    if (!images[sl].d) { set_error("no image resident in the slot: call vstar_image_set / vstar_image_set_slot first"); return VSTAR_ERR_STATE; }
+  }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamSynchronize(stream));   // the staging vectors below are reused across calls
   const int I = cfg.clip_image_size, O = cfg.owl_image_size;
@@ -357,11 +363,13 @@ int vstar_engine::preprocess(int B, const int32_t* boxes) {
   for (int b = 0; b < B; ++b) {
     const int x0 = boxes[b * 4], y0 = boxes[b * 4 + 1], x1 = boxes[b * 4 + 2], y1 = boxes[b * 4 + 3];
     const int cw = x1 - x0, ch = y1 - y0;
-    if (x0 < 0 || y0 < 0 || cw <= 0 || ch <= 0 || x1 > img_W || y1 > img_H) { set_error("crop box outside the image"); return VSTAR_ERR_INVALID; }
+    const ImageSlot& im = images[slots ? slots[b] : 0];
+    if (x0 < 0 || y0 < 0 || cw <= 0 || ch <= 0 || x1 > im.W || y1 > im.H) { set_error("crop box outside the image"); return VSTAR_ERR_INVALID; }
     const int side = cw > ch ? cw : ch;
     for (int which = 0; which < 2; ++which) {
       PreJob& j = h_jobs[(size_t)b * 2 + which];
       j.x0 = x0; j.y0 = y0; j.cw = cw; j.ch = ch;
+      j.img = im.d; j.img_w = im.W;
       j.in_w = which == 0 ? side : cw;
       j.in_h = which == 0 ? side : ch;
       j.out = which == 0 ? I : O;
@@ -387,8 +395,8 @@ int vstar_engine::preprocess(int B, const int32_t* boxes) {
   }
   HIPCHK(hipMemcpyAsync(d_tables, h_tables.data(), h_tables.size() * 4, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_jobs, h_jobs.data(), h_jobs.size() * sizeof(PreJob), hipMemcpyHostToDevice, stream));
-  KCHK(preprocess_launch(d_image, img_W, d_jobs, d_tables, d_temp, d_lut, d_clip_pix, 0, B, I, max_h_clip, stream));
-  KCHK(preprocess_launch(d_image, img_W, d_jobs, d_tables, d_temp, d_lut, d_owl_pix, 1, B, O, max_h_owl, stream));
+  KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_clip_pix, 0, B, I, max_h_clip, stream));
+  KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_owl_pix, 1, B, O, max_h_owl, stream));
   return 0;
 }
 
@@ -909,7 +917,7 @@ void vstar_destroy(vstar_handle* h) {
   h->release_base();
   if (h->d_stats) hipFree(h->d_stats);
   if (h->d_stats_batch) hipFree(h->d_stats_batch);
-  if (h->d_image) hipFree(h->d_image);
+  for (auto& im : h->images) if (im.d) hipFree(im.d);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
   hipStreamDestroy(h->stream);
@@ -949,29 +957,35 @@ int vstar_vsm_generate(vstar_handle* h, const uint16_t* clip_pix, const int32_t*
   return h->generate(clip_pix, ids, L, max_new_tokens, eos_id, flags, out_ids, n_out);
 }
 
-int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) {
-  if (!h || !rgb || height <= 0 || width <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+int vstar_image_set_slot(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width) {
+  if (!h || !rgb || height <= 0 || width <= 0 || slot < 0 || slot >= VSTAR_MAX_IMAGE_SLOTS) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
   const size_t bytes = (size_t)height * width * 3;
+  // crops of the slot's previous image may still be in flight on the stream
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
-  if (bytes > h->image_cap) {
+  auto& im = h->images[slot];
+  if (bytes > im.cap) {
     // (d_stats is a fixed-size scratch of vstar_heatmap_stats, independent of the image: it is NOT touched here)
-    if (h->d_image) hipFree(h->d_image);
-    h->d_image = nullptr;
-    h->image_cap = 0;
-    if (hipMalloc((void**)&h->d_image, bytes) != hipSuccess) { h->set_error("hipMalloc(image) failed"); return VSTAR_ERR_NOMEM; }
-    h->image_cap = bytes;
+    if (im.d) hipFree(im.d);
+    im.d = nullptr;
+    im.cap = 0;
+    if (hipMalloc((void**)&im.d, bytes) != hipSuccess) { h->set_error("hipMalloc(image) failed"); return VSTAR_ERR_NOMEM; }
+    im.cap = bytes;
   }
-  if (hipMemcpy(h->d_image, rgb, bytes, hipMemcpyHostToDevice) != hipSuccess) { h->set_error("image upload failed"); return VSTAR_ERR_HIP; }
-  h->img_H = height;
-  h->img_W = width;
+  if (hipMemcpy(im.d, rgb, bytes, hipMemcpyHostToDevice) != hipSuccess) { h->set_error("image upload failed"); return VSTAR_ERR_HIP; }
+  im.H = height;
+  im.W = width;
   return VSTAR_OK;
 }
 
-int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy) {
+int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) { return vstar_image_set_slot(h, 0, rgb, height, width); }
+
+int vstar_preprocess_crops_slots(vstar_handle* h, int B, const int32_t* boxes_xyxy, const int32_t* slots) {
   if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
-  return h->preprocess(B, boxes_xyxy);
+  return h->preprocess(B, boxes_xyxy, slots);
 }
+
+int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy) { return vstar_preprocess_crops_slots(h, B, boxes_xyxy, nullptr); }
 
 int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_out, int n_rects, const int32_t* rects_xywh,
                         double* out) {

@@ -159,13 +159,14 @@ struct PreJob {            // one (crop, target) pair; jobs are stored as [crop]
   int out;                 // output side (I or 768)
   int hb_off, hc_off, hks; // horizontal bounds / coefficients offsets (int32 units) and kernel size
   int vb_off, vc_off, vks;
-  int pad0;
+  int img_w;               // row pitch (pixels) of the image this crop is cut from
   int64_t temp_off;        // byte offset of this job's uint8 intermediate [in_h][out][3]
   int64_t out_off;         // element offset into the bf16 pixel buffer [3][out][out]
+  const uint8_t* img;      // the resident image (slot) this crop is cut from
 };
 void pil_bicubic_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize);
 void clip_norm_lut(lp_t* lut);
-hipError_t preprocess_launch(const uint8_t* img, int W, const PreJob* jobs, const int32_t* tables, uint8_t* temp,
+hipError_t preprocess_launch(const PreJob* jobs, const int32_t* tables, uint8_t* temp,
                              const lp_t* lut, lp_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s);
 
 }  // namespace VS_NS

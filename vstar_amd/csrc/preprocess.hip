@@ -23,7 +23,7 @@ __device__ __forceinline__ int clip8(int v) {
 }
 
 // horizontal pass: temp[y][xo][c] for y in [0, in_h)
-__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict__ img, int W, const PreJob* __restrict__ jobs,
+__global__ __launch_bounds__(256) void resize_h_kernel(const PreJob* __restrict__ jobs,
                                                        const int32_t* __restrict__ tables, uint8_t* __restrict__ temp,
                                                        int which) {
   const PreJob j = jobs[blockIdx.z * 2 + which];
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t* __restrict
   const int32_t* k = tables + j.hc_off + xo * j.hks;
   int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
   const bool row_in = y < j.ch;
-  const uint8_t* row = img + ((int64_t)(j.y0 + (row_in ? y : 0)) * W + j.x0) * 3;
+  const uint8_t* row = j.img + ((int64_t)(j.y0 + (row_in ? y : 0)) * j.img_w + j.x0) * 3;      // the job's own image slot
   for (int t = 0; t < cnt; ++t) {
     const int sx = xmin + t;
     int r = 122, g = 116, bl = 104;                      // expand2square background = int(CLIP mean * 255)
@@ -132,10 +132,10 @@ void clip_norm_lut(lp_t* lut /*[3*256]*/) {
     }
 }
 
-hipError_t preprocess_launch(const uint8_t* img, int W, const PreJob* jobs, const int32_t* tables, uint8_t* temp,
+hipError_t preprocess_launch(const PreJob* jobs, const int32_t* tables, uint8_t* temp,
                              const lp_t* lut, lp_t* out, int which, int B, int out_size, int max_in_h, hipStream_t s) {
   dim3 gh((out_size + 255) / 256, max_in_h, B);
-  hipLaunchKernelGGL(resize_h_kernel, gh, dim3(256), 0, s, img, W, jobs, tables, temp, which);
+  hipLaunchKernelGGL(resize_h_kernel, gh, dim3(256), 0, s, jobs, tables, temp, which);
   dim3 gv((out_size + 255) / 256, out_size, B);
   hipLaunchKernelGGL(resize_v_kernel, gv, dim3(256), 0, s, jobs, tables, temp, lut, out, which);
   return hipGetLastError();

@@ -174,21 +174,31 @@ class VstarEngine:
         return out if raw else self.unpack(out, nv)
 
     # ---- GPU-side preprocessing ----
-    def set_image(self, image) -> None:
-        """Uploads the full RGB image (PIL.Image or uint8 [H,W,3]) once; crops are then just boxes."""
+    def set_image(self, image, slot: int = 0) -> None:
+        """Uploads the full RGB image (PIL.Image or uint8 [H,W,3]) once into image slot `slot` (0 .. _lib.MAX_IMAGE_SLOTS-1);
+        crops are then just (slot, box) pairs, and one batch may mix crops of different resident images."""
         arr = np.ascontiguousarray(np.asarray(image.convert("RGB") if hasattr(image, "convert") else image, dtype=np.uint8))
         assert arr.ndim == 3 and arr.shape[2] == 3
         self._image_hw = arr.shape[:2]
-        _lib.check(self.lib.vstar_image_set(self.handle, arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
+        _lib.check(self.lib.vstar_image_set_slot(self.handle, int(slot), arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
                    self.handle)
 
+    def _preprocess(self, boxes: np.ndarray, slots) -> None:
+        sp = None
+        if slots is not None:
+            sl = np.ascontiguousarray(np.asarray(slots, dtype=np.int32)).reshape(-1)
+            assert sl.shape[0] == boxes.shape[0]
+            sp = sl.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self.lib.vstar_preprocess_crops_slots(self.handle, boxes.shape[0], boxes.ctypes.data_as(ctypes.c_void_p), sp), self.handle)
+
     def score_boxes(self, boxes_xyxy, input_ids, loc_pos, verify_pos=None, raw: bool = False,
-                    out_dev: Optional[torch.Tensor] = None, share_prefix: Optional[bool] = None):
-        """Crop + pad + PIL-exact resize + normalise on the GPU for `boxes_xyxy` [B,4] (ints, as passed to image.crop),
-        then the same scoring pass as `score_batch` (out_dev: see there)."""
+                    out_dev: Optional[torch.Tensor] = None, share_prefix: Optional[bool] = None, slots=None):
+        """Crop + pad + PIL-exact resize + normalise on the GPU for `boxes_xyxy` [B,4] (ints, as passed to image.crop) of the
+        resident image(s) (`slots` [B]: the image slot of each box; None = slot 0), then the same scoring pass as `score_batch`
+        (out_dev: see there)."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
         B = boxes.shape[0]
-        _lib.check(self.lib.vstar_preprocess_crops(self.handle, B, boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        self._preprocess(boxes, slots)
         ids = np.ascontiguousarray(np.asarray(input_ids, dtype=np.int32))
         loc = np.ascontiguousarray(np.asarray(loc_pos, dtype=np.int32))
         nv, vptr = 0, None
@@ -207,17 +217,17 @@ class VstarEngine:
             return None
         return out if raw else self.unpack(out, nv)
 
-    def preprocess_boxes(self, boxes_xyxy) -> None:
+    def preprocess_boxes(self, boxes_xyxy, slots=None) -> None:
         """Crop + pad + resize + normalise on the GPU into the engine's pixel buffers (consumed by a following call with
         internal pixels: score_grouped(internal_pixels=True))."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
-        _lib.check(self.lib.vstar_preprocess_crops(self.handle, boxes.shape[0], boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        self._preprocess(boxes, slots)
 
-    def preprocess_only(self, boxes_xyxy):
+    def preprocess_only(self, boxes_xyxy, slots=None):
         """(clip [B,3,I,I], owl [B,3,768,768]) float32 views of the device-side preprocessing result (tests)."""
         boxes = np.ascontiguousarray(np.asarray(boxes_xyxy, dtype=np.int32)).reshape(-1, 4)
         B = boxes.shape[0]
-        _lib.check(self.lib.vstar_preprocess_crops(self.handle, B, boxes.ctypes.data_as(ctypes.c_void_p)), self.handle)
+        self._preprocess(boxes, slots)
         I, O = self.cfg.clip_image_size, self.cfg.owl_image_size
         return (self.debug_read("clip_pixels", B * 3 * I * I).reshape(B, 3, I, I),
                 self.debug_read("owl_pixels", B * 3 * O * O).reshape(B, 3, O, O))
