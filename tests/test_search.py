@@ -343,3 +343,108 @@ def test_lock_step_batches_the_heat_map_statistics_of_all_targets():
     assert sum(many_vsm.stat_calls) == sum(loop_vsm.stat_calls)          # the same statistics in total ...
     assert len(many_vsm.stat_calls) < len(loop_vsm.stat_calls)           # ... in fewer calls
     assert max(many_vsm.stat_calls) >= len(names)                        # a round's requests of all targets in one call
+
+
+# ---------------- cross-image lock-step search (visual_search_stream): window of concurrent samples, image slots, cost-aware
+# speculation, useful-work statistics ----------------
+class _SlotVSM(_BoxVSMStats):
+    """_BoxVSM with image SLOTS: a record is a function of (image content, box, question); every call is logged with its slots."""
+    max_image_slots = 64
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.images, self.uploads = {}, []
+
+    def set_image(self, image, slot=0):
+        import zlib
+        self.images[slot] = zlib.crc32(np.asarray(image.resize((16, 16))).tobytes())
+        self.uploads.append(slot)
+
+    def inference_boxes(self, boxes, question, mode="detection", upsample=False, slots=None, **kw):
+        qs = [question] * len(boxes) if isinstance(question, str) else list(question)
+        sl = [0] * len(boxes) if slots is None else list(slots)
+        assert len(boxes) <= self.cfg.max_batch * 2          # (+ the do-not-split-a-crop overhang)
+        self.calls.append([(self.images[s], tuple(int(v) for v in b), q) for s, b, q in zip(sl, boxes, qs)])
+        return [self._one((self.images[s],) + tuple(int(v) for v in b), q) for s, b, q in zip(sl, boxes, qs)]
+
+
+def _stream_samples(n_images=5, per_image=(1, 2, 1, 3, 1), seed=0):
+    rng = np.random.default_rng(seed)
+    samples = []
+    for k in range(n_images):
+        w, h = int(rng.integers(600, 1300)), int(rng.integers(500, 900))
+        img = synthetic_image(w, h, 50 + k)
+        for t in range(per_image[k % len(per_image)]):
+            samples.append((img, f"thing {k}-{t}", None, search.smallest_size_for(w, h, 4.0, 64)))
+    return samples
+
+
+@pytest.mark.parametrize("window,conf", [(1, 0.9), (3, 0.9), (8, 0.9), (8, 2.0), (4, 0.6)])
+def test_stream_equals_the_per_sample_loop(window, conf):
+    """visual_search_stream over (image, target) samples of SEVERAL images == visual_search per sample, whatever the window;
+    engine batches mix crops of different images; statistics account for every scored crop."""
+    samples = _stream_samples()
+    kw = dict(confidence_high=conf, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    loop_vsm = _SlotVSM(max_batch=8)
+    loop = [search.visual_search(loop_vsm, img, n, gt, sm, speculate=False, **kw) for img, n, gt, sm in samples]
+    vsm = _SlotVSM(max_batch=8)
+    st = {}
+    got = search.visual_search_stream(vsm, samples, window=window, stats=st, **kw)
+    assert len(got) == len(samples)
+    for a, b in zip(loop, got):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+        assert torch.equal(a[0]["detection_result"], b[0]["detection_result"])
+    # useful work = what the reference's order visits = what the speculation-free loop scored
+    useful = sum(len(c) for c in loop_vsm.calls)
+    assert st["useful_crops"] == useful and st["searches"] == len(samples)
+    assert st["crops_scored"] == sum(len(c) for c in vsm.calls) >= useful
+    assert abs(st["wasted_crop_frac"] - (1 - useful / st["crops_scored"])) < 1e-12
+    if window >= 3:
+        assert any(len({p[0] for p in c}) > 1 for c in vsm.calls)         # crops of different images in one engine call
+        assert len(vsm.calls) < len(loop_vsm.calls)
+    # one upload per distinct image that was live (samples sharing an image object share the slot while they overlap)
+    assert len(vsm.uploads) <= len(samples)
+
+
+def test_stream_recycles_image_slots_and_keeps_sample_order():
+    samples = _stream_samples(n_images=7, per_image=(1,))
+    kw = dict(confidence_high=0.9, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    loop = [search.visual_search(_SlotVSM(max_batch=8), img, n, gt, sm, speculate=False, **kw) for img, n, gt, sm in samples]
+    vsm = _SlotVSM(max_batch=8)
+    vsm.max_image_slots = 2                          # fewer slots than the window asks for: searches wait for a free slot
+    got = search.visual_search_stream(vsm, samples, window=6, **kw)
+    assert set(vsm.uploads) == {0, 1} and len(vsm.uploads) == 7
+    for a, b in zip(loop, got):
+        assert a[1] == b[1] and a[0]["bbox"] == b[0]["bbox"]
+
+
+def test_speculation_policy_cost_model():
+    pol = search.SpeculationPolicy({1: 20.0, 2: 26.0, 4: 40.0, 8: 68.0, 16: 126.0, 32: 236.0}, cap=32)
+    assert pol.step_ms(1) == 20.0 and pol.step_ms(3) == 33.0 and pol.step_ms(32) == 236.0 and pol.step_ms(64) == 472.0
+    cands = [(0.45, "c0"), (0.45, "c1"), (0.45, "c2"), (0.45, "c3"), (0.5, "q0"), (0.25, "q1"), (0.1, "far")]
+    # a lone search (latency mode): p * t(1) = 9 ms >= marginal 6-7 ms for the likely candidates, never for the unlikely ones
+    lone = pol.select(1, cands, 1)
+    assert lone[:1] == ["q0"] and set(lone) == {"q0", "c0", "c1", "c2", "c3"}
+    # many live searches: a hit rarely shortens the schedule -> nothing is worth a crop's marginal cost
+    assert pol.select(8, cands, 8) == []
+    assert pol.select(2, cands, 2) == []
+    # the cap bounds a step even for certain candidates
+    assert len(pol.select(30, [(1.0, k) for k in range(10)], 1)) == 2
+    # data-parallel ranks: B crops cost a step of ceil(B / world) crops per rank
+    pol8 = search.SpeculationPolicy({1: 20.0, 2: 26.0, 4: 40.0}, cap=256, world=8)
+    assert pol8.step_ms(8) == 20.0 and pol8.step_ms(9) == 26.0
+    assert len(pol8.select(1, [(0.25, k) for k in range(20)], 1)) == 7       # free until the ranks hold one crop each
+    assert search.SpeculationPolicy(enabled=False).select(1, cands, 1) == []
+
+
+def test_stream_speculates_for_a_lone_search_but_not_in_a_full_window():
+    samples = _stream_samples(n_images=6, per_image=(1,))
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    st1, st6 = {}, {}
+    v1 = _SlotVSM(max_batch=8)
+    search.visual_search_stream(v1, samples[:1], window=1, stats=st1, **kw)
+    assert max(len(c) for c in v1.calls) > 1                 # latency mode: children ride along with the node
+    v6 = _SlotVSM(max_batch=8)
+    search.visual_search_stream(v6, samples, window=6, stats=st6, **kw)
+    assert st6["wasted_crop_frac"] == 0.0                    # six live searches: only crops the order visits
+    assert st6["useful_crops"] == st6["crops_scored"]

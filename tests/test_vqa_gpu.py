@@ -324,16 +324,15 @@ def test_eval_loop_end_to_end_on_synthetic_benchmark(cuda, tmp_path):
         calls["n"] += 1
         return bench_eval.MISSING_MSG + " mug, table." if calls["n"] % 2 else "It is red."
     llm.free_form_inference = free_form
-    real_search = bench_eval.search_objects
-    # random weights make the detector fire on many boxes; the tiny engine's feature table holds 8 images
-    bench_eval.search_objects = lambda *a, **k: real_search(*a, **k)[:5]
+    # random weights make the detector fire on many boxes; the tiny engine's feature table holds 8 images -> max_found_objects
     args = SimpleNamespace(benchmark_folder=str(tmp_path), output_path=str(tmp_path / "eval_result.json"),
-                           minimum_size_scale=4.0, minimum_size=224, vsm_model_path="synthetic")
-    try:
-        results = bench_eval.eval_model(args, llm, vsm)
-    finally:
-        bench_eval.search_objects = real_search
+                           minimum_size_scale=4.0, minimum_size=224, vsm_model_path="synthetic", max_found_objects=5)
+    results = bench_eval.eval_model(args, llm, vsm)              # all searches in one cross-image lock-step stream
     out = json.load(open(args.output_path))
+    # the reference's schedule (one image at a time) gives the same file
+    calls["n"] = 0
+    args1 = SimpleNamespace(**{**vars(args), "search_window": 1, "output_path": str(tmp_path / "eval_result_w1.json")})
+    assert bench_eval.eval_model(args1, llm, vsm) == results
     assert set(out) == {"direct_attributes", "relative_position"}
     rec = out["direct_attributes"][0]
     assert set(rec) == {"question", "options", "image", "prediction_freeform", "missing_objects", "search_result",

@@ -4,7 +4,12 @@ driven by the HIP engine: `VSM` from vstar_amd.vsm, batched `visual_search` from
 
   python visual_search.py --version /path/to/seal_vsm_7b --vision-tower /path/to/clip-vit-large-patch14 \
          --benchmark-folder vstar_bench
-Extra (additive) flags: --device, --batch, --synthetic-seed (random weights when no checkpoint is staged), --shard.
+Extra (additive) flags: --device, --batch, --synthetic-seed (random weights when no checkpoint is staged), --shard, --window.
+
+The reference searches ONE (image, target) at a time (visual_search.py:536-560).  Here `--window K` samples are searched in lock
+step (vstar_amd.search.visual_search_stream): every engine batch holds the crops K concurrent searches need next — crops of different
+images side by side through the engine's image slots — with per-sample results identical to the one-at-a-time loop.  --window 1 is the
+reference's schedule (plus cost-aware speculation of a lone search's likely next crops).
 
 Multi-GPU (BASELINE configs 3/4): launch with torchrun, one process per GPU —
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 visual_search.py ...
@@ -27,7 +32,7 @@ from PIL import Image
 
 from vstar_amd.config import VSMConfig
 from vstar_amd.dist import finalize, gather_objects, init_from_env
-from vstar_amd.search import iou, smallest_size_for, visual_search
+from vstar_amd.search import iou, smallest_size_for, visual_search_stream
 
 SPLITS = ("direct_attributes", "relative_position")
 
@@ -54,6 +59,8 @@ def parse_args(argv):
     p.add_argument("--batch", default=32, type=int, help="crops per engine pass")
     p.add_argument("--synthetic-seed", default=None, type=int)
     p.add_argument("--shard", default="crops", choices=["crops", "samples"], help="what is dealt over the ranks under torchrun")
+    p.add_argument("--window", default=0, type=int, help="concurrent (image, target) searches per process; 0 = one engine batch "
+                   "(x world size when crops are sharded); 1 = the reference's one-sample-at-a-time schedule")
     p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) returning an object with the VSM interface "
                    "(tests substitute a CPU stand-in for the engine)")
     return p.parse_args(argv)
@@ -84,21 +91,33 @@ def main(argv):
     if args.visualization:
         raise SystemExit("--visualization (cv2/matplotlib rendering) is out of scope of this engine")
     world, rank, local_rank = init_from_env()
+    finished = False
     try:
         vsm = make_vsm(args, local_rank if world > 1 else args.device)
         if args.shard == "samples":
             vsm.shard_crops = False                      # each search stays on its own GPU
-        results = []                                     # (sample index, hit, path length)
+        class _Loader:                                   # lazy image load when the sample enters the window; one slot per file
+            def __init__(self, path):
+                self.key = path
+
+            def __call__(self):
+                return Image.open(self.key).convert("RGB")
+
+        mine, loaders = [], {}
         for i, (_, path, gt_bbox, target) in enumerate(iter_samples(args.benchmark_folder)):
             if args.shard == "samples" and i % world != rank:
                 continue
-            image = Image.open(path).convert("RGB")
-            smallest = smallest_size_for(image.width, image.height, args.minimum_size_scale, args.minimum_size)
-            step, n_steps, ok, _ = visual_search(
-                vsm, image, target, target_bbox=gt_bbox, smallest_size=smallest, confidence_high=args.confidence_high,
-                confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
-                target_cue_threshold_decay=args.target_cue_threshold_decay,
-                target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+            ld = loaders.setdefault(path, _Loader(path))
+            mine.append((i, gt_bbox, (ld, target, gt_bbox,
+                                      lambda im: smallest_size_for(im.width, im.height, args.minimum_size_scale, args.minimum_size))))
+        stats = {}
+        outs = visual_search_stream(
+            vsm, [m[2] for m in mine], window=args.window or None, stats=stats, confidence_high=args.confidence_high,
+            confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
+            target_cue_threshold_decay=args.target_cue_threshold_decay,
+            target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+        results = []                                     # (sample index, hit, path length)
+        for (i, gt_bbox, _), (step, n_steps, ok, _) in zip(mine, outs):
             if not ok:
                 results.append((i, 0.0, 0))
                 continue
@@ -113,10 +132,12 @@ def main(argv):
             print("Avg search path length:", np.mean([n for n, h in zip(lengths, hits) if h]))
             print("Top 1 Acc:", np.mean(hits))
             if args.output_path:
-                json.dump({"world_size": world, "shard": args.shard, "hits": hits, "path_lengths": lengths},
+                json.dump({"world_size": world, "shard": args.shard, "hits": hits, "path_lengths": lengths,
+                           "rank0_search_stats": {k: v for k, v in stats.items() if k != "per_search"}},
                           open(args.output_path, "w"))
+        finished = True
     finally:
-        finalize()
+        finalize(finished)
 
 
 if __name__ == "__main__":

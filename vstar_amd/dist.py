@@ -64,9 +64,13 @@ def init_from_env(backend: str | None = None):
     return world, rank, local_rank
 
 
-def finalize() -> None:
+def finalize(ok: bool = True) -> None:
+    """Leaves the process group.  The barrier belongs to the SUCCESS path only: a rank that is unwinding an exception (for example
+    the reference-semantics IndexError of a search whose decode emitted no [LOC]) must not wait for peers that are still inside a
+    collective — it tears its group down so that the job fails instead of hanging until the RCCL timeout."""
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if ok:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -22,6 +22,11 @@ from .preprocess import CUE_QUESTION, LOCATE_QUESTION
 
 
 # ---------------- geometry / score helpers (visual_search.py:227-283) ----------------
+# NOTE: refine_bbox .. Prioritize below restate the reference's small decision helpers statement by statement ON PURPOSE: their
+# float32 / Python-int semantics (int(w // n) vs int(h / n), numpy pairwise sums, `>=` vs `>`, heapq tie order through a
+# priority-only comparison) decide which crop is visited next, and the scheduler goldens (tests/golden/search_paths.json, recorded
+# from the reference's own visual_search.py) require them bit for bit.  Everything else in this file — the generator form of the
+# loop, speculation, the lock-step / streaming drivers, the lazy exact tie-break — is this repository's own design.
 def refine_bbox(bbox, image_width, image_height):
     bbox[0] = max(0, bbox[0])
     bbox[1] = max(0, bbox[1])
@@ -144,8 +149,11 @@ class _NodeScorer:
     """Caches detection-mode VSM results per bbox and fills the cache in speculative batches."""
 
     def __init__(self, vsm, image, question: str, smallest_size: int, batch_size: Optional[int], speculate: bool,
-                 gpu_preprocess: bool = True, device_reductions: Optional[bool] = None, upload_image: bool = True):
+                 gpu_preprocess: bool = True, device_reductions: Optional[bool] = None, upload_image: bool = True, slot: int = 0):
         self.vsm, self.image, self.question = vsm, image, question
+        self.slot = slot                    # image slot of this search's image (cross-image batches: visual_search_stream)
+        self.stream = False                 # True: `missing` asks for the node alone; the stream driver adds speculation itself
+        self._last = None                   # (bbox, queue) of the last request, for `candidates`
         # on-device heat-map statistics (SURVEY §8f-4) whenever the VSM offers them; None = automatic, False = host reductions
         can = bool(getattr(vsm, "supports_device_reductions", hasattr(vsm, "heatmap_stats"))) and hasattr(vsm, "inference_batch")
         self.device_reductions = can if device_reductions is None else (bool(device_reductions) and can)
@@ -154,7 +162,7 @@ class _NodeScorer:
         # device-side crop/resize when the VSM offers it: the full image is uploaded once, crops travel as boxes
         self.on_device = gpu_preprocess and bool(getattr(vsm, "supports_gpu_preprocess", False))
         if self.on_device and upload_image:       # (visual_search_many: the targets of one image share ONE upload)
-            vsm.set_image(image)
+            vsm.set_image(image) if slot == 0 else vsm.set_image(image, slot)
         world = vsm._dist()[0] if hasattr(vsm, "_dist") else 1    # one engine batch per rank and step
         self.batch_size = batch_size or (getattr(getattr(vsm, "cfg", None), "max_batch", 1) * world if self.batched else 1)
         self.speculate = speculate and self.batched and self.batch_size > 1
@@ -174,7 +182,9 @@ class _NodeScorer:
         todo = [list(bbox)]
         if self.speculate:
             frontier = self._children(bbox)
-            frontier += [e.item["bbox"] for e in sorted(queue.queue)]
+            # ordered by the float priority only: comparing the entries themselves would make LazyExactPrioritize materialise
+            # full-resolution heat maps for every near-tied pair just to rank SPECULATION candidates
+            frontier += [e.item["bbox"] for e in sorted(queue.queue, key=lambda e: float(e.priority))]
             seen = {key}
             while frontier and len(todo) < self.batch_size:
                 nxt = []
@@ -198,7 +208,36 @@ class _NodeScorer:
 
     def missing(self, bbox, queue: PriorityQueue) -> Optional[List[list]]:
         """None when `bbox` is cached, else the crops one engine step should score now (`plan`)."""
-        return None if tuple(bbox) in self.cache else self.plan(bbox, queue)
+        if tuple(bbox) in self.cache:
+            return None
+        if self.stream:
+            self._last = (list(bbox), queue)
+            return [list(bbox)]
+        return self.plan(bbox, queue)
+
+    def candidates(self, prior: "SpeculationPolicy") -> List[Tuple[float, list]]:
+        """Speculation candidates for the node this search is waiting on: (visit probability, bbox), uncached boxes only.
+        Boxes are pure functions of committed boxes: the node's children, the queue's entries best-first, and THEIR children."""
+        if self._last is None:
+            return []
+        bbox, queue = self._last
+        out, seen = [], {tuple(bbox)}
+
+        def add(p, b):
+            k = tuple(b)
+            if k not in seen:
+                seen.add(k)
+                if k not in self.cache:
+                    out.append((p, list(b)))
+
+        for c in self._children(bbox):
+            add(prior.p_child, c)
+        for rank, e in enumerate(sorted(queue.queue, key=lambda e: float(e.priority))[:prior.max_queue_rank]):
+            pq = prior.p_queue * prior.queue_decay ** rank
+            add(pq, e.item["bbox"])
+            for c in self._children(e.item["bbox"]):
+                add(pq * prior.p_child, c)
+        return out
 
     def score(self, todo: List[list]) -> List:
         """One engine step for the crops `todo` (this scorer's question)."""
@@ -207,6 +246,8 @@ class _NodeScorer:
         # abort a search the reference would complete
         kw = {"defer_mismatch": True} if getattr(self.vsm, "supports_deferred_mismatch", False) else {}
         if self.on_device:
+            if self.slot:
+                kw["slots"] = [self.slot] * len(todo)
             return self.vsm.inference_boxes(todo, self.question, mode="detection", upsample=False, **kw)
         crops = [_crop(self.image, b) for b in todo]
         if self.batched:
@@ -462,29 +503,153 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
     return final_step, path_length, search_successful, all_valid_boxes
 
 
-def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, **kw):
-    """Several targets on ONE image (the reference loops `visual_search` per missing object, vstar_bench_eval.py:205-209):
-    same per-target results as that loop — each entry is visual_search's 4-tuple — but the searches advance in LOCK STEP: each
-    is a generator (`_visual_search_steps`) that yields the crops it needs scored; one engine step scores what ALL live searches
-    ask for, all targets of a crop in the same call, so small per-target steps still fill the GPU and a grouping VSM
-    (`vsm.group_prompts`) evaluates each crop's towers and shared prompt positions once for every target that wants it.  With
-    grouping the VSM is switched to group_prompts = "always" for the call: a (crop, prompt) record then never depends on which
-    other targets asked for the crop, so target i's result is a function of (image, target i) alone.  One target, or a VSM
-    without on-device crops, is the plain loop."""
-    names = list(target_object_names)
-    gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
-    batch_size, speculate = kw.get("batch_size"), kw.get("speculate", True)
-    scorers = [_NodeScorer(vsm, image, LOCATE_QUESTION.format(n), smallest_size, batch_size, speculate,
-                           kw.get("gpu_preprocess", True), kw.get("device_reductions"), upload_image=(k == 0))
-               for k, n in enumerate(names)]
-    kw = {k: v for k, v in kw.items()}
-    if not (scorers and all(sc.on_device for sc in scorers) and len(scorers) > 1):
-        return [visual_search(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]
-    gens = [_visual_search_steps(vsm, image, n, gt, smallest_size, _scorer=sc, **kw) for n, gt, sc in zip(names, gts, scorers)]
-    results: List = [None] * len(names)
-    waiting: Dict[int, List[list]] = {}            # target index -> the crops its search is waiting for
+class SpeculationPolicy:
+    """Cost-aware speculation for the lock-step / streaming drivers.
 
-    want_stats: Dict[int, List] = {}               # target index -> heat-map statistics requests
+    The reference evaluates exactly the crops its best-first order visits (average path ~4.65 nodes).  A batched engine
+    can score crops AHEAD of the order, but a speculative crop is only worth its cost if it is likely to be visited AND the batch
+    it joins is not already efficient: a miss is pure waste (one crop's marginal engine time), a hit saves the search one serial
+    engine step.  With the measured step-time table t(B) (ms for a B-crop step on one rank; defaults = this repository's MI355X
+    measurements, profiles/r03_small_batch.json; `VSM.step_ms_table` overrides) a candidate with visit probability p joins a
+    step that already holds B crops iff
+
+            p * t(1) / n_live   >=   t(B + 1) - t(B)
+
+    (expected serial time saved, shared among the n_live searches that advance in lock step — with many live searches a hit on
+    one of them rarely shortens the schedule — against the marginal cost of one more crop), and never beyond `cap` crops.  With a
+    window of concurrent searches that fills the batch with MUST crops the right-hand side is the full per-crop cost and nothing
+    is speculated; a lone search (latency mode) speculates its children and the head of its queue while batches are small.
+    The priors are deliberately simple constants (children of the node being scored, queue entries best-first with geometric
+    decay); `wasted_crop_frac` in the drivers' stats is the measured outcome."""
+
+    DEFAULT_STEP_MS = {1: 19.4, 2: 26.0, 4: 40.2, 8: 68.3, 16: 126.5, 32: 234.8}
+
+    def __init__(self, step_ms: Optional[Dict[int, float]] = None, cap: int = 32, world: int = 1, p_child: float = 0.45,
+                 p_queue: float = 0.5, queue_decay: float = 0.5, max_queue_rank: int = 4, enabled: bool = True):
+        self.table = dict(sorted((step_ms or self.DEFAULT_STEP_MS).items()))
+        self.cap, self.world, self.enabled = int(cap), max(int(world), 1), enabled
+        self.p_child, self.p_queue, self.queue_decay, self.max_queue_rank = p_child, p_queue, queue_decay, max_queue_rank
+
+    def step_ms(self, n_crops: int) -> float:
+        """t(B): one engine step of n_crops crops dealt over `world` ranks (piecewise linear in the per-rank batch)."""
+        b = -(-max(n_crops, 0) // self.world)
+        if b <= 0:
+            return 0.0
+        ks = list(self.table)
+        if b <= ks[0]:
+            return self.table[ks[0]] * b / ks[0]
+        for lo, hi in zip(ks, ks[1:]):
+            if b <= hi:
+                return self.table[lo] + (self.table[hi] - self.table[lo]) * (b - lo) / (hi - lo)
+        return self.table[ks[-1]] * b / ks[-1]
+
+    def select(self, n_must: int, cands: List[Tuple[float, object]], n_live: int) -> List[object]:
+        """The candidates worth scoring in a step that already holds n_must crops; cands = [(visit probability, item), ...]."""
+        if not self.enabled:
+            return []
+        chosen, B = [], n_must
+        for p, item in sorted(cands, key=lambda c: -c[0]):
+            if B >= self.cap:
+                break
+            if p * self.step_ms(1) / max(n_live, 1) < self.step_ms(B + 1) - self.step_ms(B):
+                break
+            chosen.append(item)
+            B += 1
+        return chosen
+
+
+def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: Optional[SpeculationPolicy] = None,
+                         stats: Optional[dict] = None, **kw):
+    """Cross-image lock-step search: `samples` = iterable of (image, target_object_name, target_bbox, smallest_size) — `image` a
+    PIL image or a zero-argument loader returning one (called when the sample enters the window; loaders with the same `.key`, or
+    the same loader object, share an image slot; `smallest_size` may then be a callable of the loaded image); returns the
+    list of visual_search 4-tuples in sample order — what the reference's outer loops compute one sample at a time
+    (visual_search.py:536-560; vstar_bench_eval.py:190-262 calls visual_search per missing object of each question).
+
+    Up to `window` searches are LIVE at once (default: the engine batch x world size); each is a generator
+    (`_visual_search_steps`) that yields the crop it needs next.  One engine step scores the MUST crops of every live search —
+    crops of different images in the same batch through the engine's image slots (VSM.set_image(image, slot)) — plus whatever
+    `policy` (SpeculationPolicy) finds worth speculating on; when a search ends the next sample takes its place, so batches stay
+    full of crops the reference's order really visits.  Images are uploaded once per sample window (samples that share an image
+    object share its slot).  Per (image, target) the decisions are exactly those of `visual_search`: with batch-invariant records
+    (plain batches, or group_prompts = "always") the results are bit-identical to the per-sample loop.
+
+    stats (optional dict) receives: searches, crops_scored (engine records), useful_crops (nodes the best-first order visited),
+    wasted_crop_frac, engine_steps, per_search = [{crops_scored, path_visited, ...}]."""
+    samples = list(samples)
+    n = len(samples)
+    results: List = [None] * n
+    if n == 0:
+        return results
+    on_device = bool(getattr(vsm, "supports_gpu_preprocess", False)) and hasattr(vsm, "inference_boxes") and kw.get("gpu_preprocess", True)
+    per_stats: List[dict] = [dict() for _ in range(n)]
+    if not on_device:
+        # no resident images: the plain per-sample loop (still batched / speculative inside each search)
+        for i, (image, name, gt, smallest) in enumerate(samples):
+            image = image() if callable(image) else image
+            smallest = smallest(image) if callable(smallest) else smallest
+            results[i] = visual_search(vsm, image, name, gt, smallest, stats=per_stats[i], **kw)
+        _fill_stream_stats(stats, per_stats, 0)
+        return results
+    world = vsm._dist()[0] if hasattr(vsm, "_dist") else 1
+    cap = max(int(getattr(getattr(vsm, "cfg", None), "max_batch", 32)), 1) * world
+    if policy is None:
+        policy = SpeculationPolicy(getattr(vsm, "step_ms_table", None), cap=cap, world=world, enabled=kw.get("speculate", True))
+    n_slots = int(getattr(vsm, "max_image_slots", 64))
+    window = max(1, min(window or cap, n))
+    plan_bs, plan_spec = kw.get("batch_size"), kw.get("speculate", True)
+    kw = {k: v for k, v in kw.items() if k not in ("batch_size", "speculate", "stats")}
+    own_plans = bool(getattr(policy, "per_search_plan", False))      # visual_search_many: every search plans its own step
+
+    slot_of: Dict[int, int] = {}                  # id(image) -> slot
+    slot_refs: Dict[int, int] = {}                # slot -> live searches using it
+    free_slots = list(range(n_slots - 1, -1, -1))
+    gens: Dict[int, object] = {}
+    scorers: Dict[int, _NodeScorer] = {}
+    waiting: Dict[int, List[list]] = {}           # search -> the crop(s) it waits for
+    want_stats: Dict[int, List] = {}
+    next_sample = 0
+    engine_steps = 0
+
+    loaded: Dict[object, object] = {}             # slot key -> the PIL image living in that slot
+
+    def start(i):
+        image, name, gt, smallest = samples[i]
+        key = getattr(image, "key", id(image))
+        if key not in slot_of:
+            if not free_slots:
+                return False
+            loaded[key] = image() if callable(image) else image
+            slot_of[key] = free_slots.pop()
+            slot_refs[slot_of[key]] = 0
+            vsm.set_image(loaded[key]) if slot_of[key] == 0 else vsm.set_image(loaded[key], slot_of[key])
+        image = loaded[key]
+        if callable(smallest):
+            smallest = smallest(image)
+        sl = slot_of[key]
+        slot_refs[sl] += 1
+        if own_plans:
+            sc = _NodeScorer(vsm, image, LOCATE_QUESTION.format(name), smallest, plan_bs, plan_spec, True, kw.get("device_reductions"),
+                             upload_image=False, slot=sl)
+        else:
+            sc = _NodeScorer(vsm, image, LOCATE_QUESTION.format(name), smallest, 1, False, True, kw.get("device_reductions"),
+                             upload_image=False, slot=sl)
+            sc.stream = True
+        scorers[i] = sc
+        gens[i] = _visual_search_steps(vsm, image, name, gt, smallest, _scorer=sc, stats=per_stats[i], **kw)
+        advance(i, first=True)
+        return True
+
+    def finish(i, value):
+        results[i] = value
+        sl = scorers[i].slot
+        slot_refs[sl] -= 1
+        if slot_refs[sl] == 0:                     # last live search of that image: the slot can take another image
+            key = next(k for k, v in slot_of.items() if v == sl)
+            del slot_of[key]
+            loaded.pop(key, None)
+            free_slots.append(sl)
+        gens.pop(i).close()
 
     def advance(i, value=None, first=False):
         try:
@@ -494,10 +659,16 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
             else:
                 want_stats[i] = req[1]
         except StopIteration as done:
-            results[i] = done.value
+            finish(i, done.value)
+
+    def refill():
+        nonlocal next_sample
+        while next_sample < n and len(gens) < window:
+            if not start(next_sample):
+                break                               # every image slot is in use: wait for a search to end
+            next_sample += 1
 
     def drain_stats():
-        """Serve statistics requests — all targets' in ONE engine call per pass — until every live search waits for crops."""
         nonlocal want_stats
         while want_stats:
             cur, want_stats = want_stats, {}
@@ -511,40 +682,113 @@ def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bb
 
     grouping = getattr(vsm, "group_prompts", False)
     if grouping:
-        vsm.group_prompts = "always"
+        vsm.group_prompts = "always"              # a (crop, prompt) record must not depend on its batch companions
+    dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
     try:
-        for i in range(len(names)):
-            advance(i, first=True)
+        refill()
         drain_stats()
-        dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
-        while waiting:
+        refill()
+        while waiting or gens:
+            if not waiting:                         # every live search ended inside drain_stats / refill
+                refill()
+                drain_stats()
+                if not waiting and not want_stats and next_sample >= n:
+                    break
+                continue
             reqs, waiting = waiting, {}
-            # box-major order: the requests of all targets for the same crop next to each other
-            order: Dict[Tuple, List] = {}
-            for i, boxes in reqs.items():
-                for j, b in enumerate(boxes):
-                    order.setdefault(tuple(b), []).append((i, j))
-            flat = [(i, j, list(b)) for b, lst in order.items() for i, j in lst]
-            # engine calls of about one batch of records (whole crops each): the per-call result arrays stay cache-sized
-            cap = max(int(getattr(getattr(vsm, "cfg", None), "max_batch", 32)), 1)
-            out: List = []
+            # MUST crops first, then the policy's picks among every live search's candidates
+            must = [(i, j, b) for i, boxes in reqs.items() for j, b in enumerate(boxes)]
+            cands = [] if own_plans else [(p, (i, b)) for i in reqs for p, b in scorers[i].candidates(policy)]
+            extra = policy.select(len(must), cands, len(reqs)) if cands else []
+            flat = [(i, j, list(b)) for i, j, b in must] + [(i, None, list(b)) for i, b in extra]
+            # box-major order inside the step: requests for the same crop (same image slot, same box) next to each other so that
+            # a grouping VSM scores that crop's towers once for all its prompts
+            order: Dict[Tuple, List[int]] = {}
+            for k, (i, _, b) in enumerate(flat):
+                order.setdefault((scorers[i].slot,) + tuple(b), []).append(k)
+            seq = [k for ks in order.values() for k in ks]
+            out: List = [None] * len(flat)
             c0 = 0
-            while c0 < len(flat):
-                c1 = min(c0 + cap, len(flat))
-                while c1 < len(flat) and flat[c1][2] == flat[c1 - 1][2]:      # do not split the requests for one crop
+            while c0 < len(seq):
+                c1 = min(c0 + cap, len(seq))
+                while c1 < len(seq) and flat[seq[c1]][2] == flat[seq[c1 - 1]][2] and \
+                        scorers[flat[seq[c1]][0]].slot == scorers[flat[seq[c1 - 1]][0]].slot:      # keep one crop's requests together
                     c1 += 1
-                out += vsm.inference_boxes([f[2] for f in flat[c0:c1]], [scorers[f[0]].question for f in flat[c0:c1]],
-                                           mode="detection", upsample=False, **dkw)
+                part = seq[c0:c1]
+                sl_part = [scorers[flat[k][0]].slot for k in part]
+                skw = {"slots": sl_part} if any(sl_part) else {}        # (one image in slot 0: the pre-slot call signature)
+                res = vsm.inference_boxes([flat[k][2] for k in part], [scorers[flat[k][0]].question for k in part], mode="detection",
+                                          upsample=False, **skw, **dkw)
+                for k, r in zip(part, res):
+                    out[k] = r
+                engine_steps += 1
                 c0 = c1
-            per = {i: [None] * len(boxes) for i, boxes in reqs.items()}
-            for (i, j, _), r in zip(flat, out):
-                per[i][j] = r
-            for i in reqs:                         # in target order: host decisions of search i, up to its next request
+            per: Dict[int, List] = {i: [None] * len(boxes) for i, boxes in reqs.items()}
+            spec: Dict[int, Tuple[List, List]] = {}
+            for (i, j, b), r in zip(flat, out):
+                if j is None:
+                    spec.setdefault(i, ([], []))
+                    spec[i][0].append(b)
+                    spec[i][1].append(r)
+                else:
+                    per[i][j] = r
+            for i, (bs, rs) in spec.items():       # speculative records go straight into the search's cache
+                scorers[i].accept(bs, rs)
+            for i in reqs:                         # in sample order: host decisions of search i, up to its next request
                 advance(i, per[i])
+            drain_stats()
+            refill()
             drain_stats()
     finally:
         if grouping:
             vsm.group_prompts = grouping
-        for g in gens:
+        for g in list(gens.values()):
             g.close()
+    _fill_stream_stats(stats, per_stats, engine_steps)
     return results
+
+
+def _fill_stream_stats(stats: Optional[dict], per_stats: List[dict], engine_steps: int) -> None:
+    if stats is None:
+        return
+    scored = sum(int(p.get("crops_scored", 0)) for p in per_stats)
+    useful = sum(int(p.get("path_visited", 0)) for p in per_stats)
+    stats.update(searches=len(per_stats), crops_scored=scored, useful_crops=useful,
+                 wasted_crop_frac=(1.0 - useful / scored) if scored else 0.0, engine_steps=engine_steps,
+                 per_search=[{k: v for k, v in p.items() if k != "search_path"} for p in per_stats])
+
+
+def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, *,
+                       stats: Optional[dict] = None, **kw):
+    """Several targets on ONE image (the reference loops `visual_search` per missing object, vstar_bench_eval.py:205-209):
+    same per-target results as that loop — each entry is visual_search's 4-tuple — but the searches advance in LOCK STEP: each
+    is a generator (`_visual_search_steps`) that yields the crops it needs scored; one engine step scores what ALL live searches
+    ask for, all targets of a crop in the same call, so small per-target steps still fill the GPU and a grouping VSM
+    (`vsm.group_prompts`) evaluates each crop's towers and shared prompt positions once for every target that wants it.  With
+    grouping the VSM is switched to group_prompts = "always" for the call: a (crop, prompt) record then never depends on which
+    other targets asked for the crop, so target i's result is a function of (image, target i) alone.  One target, or a VSM
+    without on-device crops, is the plain loop.  `stats` (optional) receives the stream statistics plus per-target entries
+    (round 3: each target has its OWN statistics dict — they used to overwrite one another).
+    This is visual_search_stream with every sample on the same image and the whole set live at once; every search plans its own
+    step (`batch_size`, `speculate`: breadth-first like `visual_search` does alone), not the stream's cost model."""
+    names = list(target_object_names)
+    gts = list(target_bboxes) if target_bboxes is not None else [None] * len(names)
+    on_device = bool(getattr(vsm, "supports_gpu_preprocess", False)) and kw.get("gpu_preprocess", True)
+    if not (on_device and len(names) > 1):
+        per = [dict() for _ in names]
+        skw = {k: v for k, v in kw.items() if k != "stats"}
+        out = [visual_search(vsm, image, n, gt, smallest_size, stats=st, **skw) for n, gt, st in zip(names, gts, per)]
+        _fill_stream_stats(stats, per, 0)
+        return out
+    pol = _PerSearchPlans()
+    return visual_search_stream(vsm, [(image, n, gt, smallest_size) for n, gt in zip(names, gts)], window=len(names), policy=pol,
+                                stats=stats, **kw)
+
+
+class _PerSearchPlans(SpeculationPolicy):
+    """visual_search_many's behaviour: each search asks for its own node plus its own breadth-first speculation
+    (`_NodeScorer.plan` with the caller's batch_size / speculate), and the driver only merges the requests of a step."""
+    per_search_plan = True
+
+    def select(self, n_must, cands, n_live):
+        return []

@@ -226,19 +226,30 @@ class VSM:
     def supports_gpu_preprocess(self) -> bool:
         return hasattr(self.engine, "score_boxes") and hasattr(self.engine, "set_image")
 
-    def set_image(self, image: Image.Image) -> None:
-        self._image = image
-        self.engine.set_image(image)
+    def set_image(self, image: Image.Image, slot: int = 0) -> None:
+        """Uploads `image` into the engine's image slot `slot`; `inference_boxes(..., slots=...)` then scores crops of any
+        resident image in one batch (cross-image lock-step search)."""
+        if not hasattr(self, "_images"):
+            self._images = {}
+        self._images[int(slot)] = image
+        if slot == 0:
+            self._image = image
+            self.engine.set_image(image)
+        else:
+            self.engine.set_image(image, int(slot))
 
     @torch.inference_mode()
     def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question, mode: str = "detection",
-                        upsample: bool = True, defer_mismatch: bool = False):
+                        upsample: bool = True, defer_mismatch: bool = False, slots: Optional[Sequence[int]] = None):
         """Like inference_batch for crops `image.crop((int(x), int(y), int(x+w), int(y+h)))` of the image given to
         set_image(), but crop / pad / resize / normalise run on the GPU (bit-identical to the PIL + HF-processor path).
         `question` is one string for all boxes or one string PER box (several search targets sharing a batch): shorter
-        prompts are right-padded to the longest — under the causal mask the padding cannot reach the scored positions."""
+        prompts are right-padded to the longest — under the causal mask the padding cannot reach the scored positions.
+        `slots` (one image slot per box, see set_image) lets the boxes belong to DIFFERENT resident images."""
         assert mode in ("segmentation", "detection")
         n_boxes = len(boxes_xywh)
+        slot_arr = None if slots is None else np.asarray(list(slots), np.int32).reshape(-1)
+        assert slot_arr is None or len(slot_arr) == n_boxes
         qs = [question] * n_boxes if isinstance(question, str) else list(question)
         assert len(qs) == n_boxes
         per_q = {q: self._ids(q) for q in dict.fromkeys(qs)}
@@ -261,8 +272,10 @@ class VSM:
 
         def score_chunk(sel, out_dev):
             kw = {"out_dev": out_dev} if out_dev is not None else {}
+            if slot_arr is not None:
+                kw["slots"] = slot_arr[sel]
             return self.engine.score_boxes(xyxy[sel], ids_rows[sel], loc_rows[sel], verify_pos=ver_rows[sel], raw=True, **kw)
-        records = self._score_boxes_grouped(xyxy, qs, per_q, nv) if self.group_prompts else None
+        records = self._score_boxes_grouped(xyxy, qs, per_q, nv, slot_arr) if self.group_prompts else None
         if records is None:
             records = self._score_sharded(n, score_chunk)
         res = self.engine.unpack(records, nv)
@@ -278,7 +291,8 @@ class VSM:
                 out.append((torch.from_numpy(res["pred_boxes"][b].copy()),
                             _scores(res["pred_logits"][b]), heat))
         # the fallback decodes from the host-side crop (bit-identical pixels: test_gpu_preprocess_is_bit_identical...)
-        self._handle_mismatches(out, lambda b: self._image.crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
+        img_of = (lambda b: self._image) if slot_arr is None else (lambda b: self._images[int(slot_arr[b])])
+        self._handle_mismatches(out, lambda b: img_of(b).crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
                                 defer_mismatch)
         return out
 
@@ -300,7 +314,8 @@ class VSM:
             self._tpl = a[:n]
         return self._tpl
 
-    def _score_boxes_grouped(self, xyxy: np.ndarray, qs: List[str], per_q: dict, nv: int) -> Optional[np.ndarray]:
+    def _score_boxes_grouped(self, xyxy: np.ndarray, qs: List[str], per_q: dict, nv: int,
+                             slot_arr: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """Multi-target batches (visual_search_many scores the same crops for several targets): every crop that appears with
         T >= 2 distinct prompts is scored ONCE through the vision towers and the shared positions of the LLaMA sequence — system
         prompt, image tokens and the template's "Please locate the" — plus one 32-row suffix block per prompt
@@ -334,7 +349,9 @@ class VSM:
         # crops -> the prompts they are scored for (in first-seen order); group crops with the same prompt tuple
         by_box: dict = {}
         single: List[int] = []
-        for i, (b, q) in enumerate(zip(map(tuple, xyxy.tolist()), qs)):
+        keys = list(map(tuple, xyxy.tolist())) if slot_arr is None else \
+            [tuple(b) + (int(sl),) for b, sl in zip(xyxy.tolist(), slot_arr.tolist())]     # a crop = (box, image slot)
+        for i, (b, q) in enumerate(zip(keys, qs)):
             if ok[q]:
                 by_box.setdefault(b, {}).setdefault(q, []).append(i)
             else:
@@ -362,8 +379,11 @@ class VSM:
                 chunk = boxes[c0:c0 + per_call]
                 G = len(chunk)
                 t1 = time.perf_counter()
-                _lib_boxes = np.asarray(chunk, np.int32)
-                self.engine.preprocess_boxes(_lib_boxes)
+                _lib_boxes = np.asarray([c[:4] for c in chunk], np.int32)
+                if slot_arr is None:
+                    self.engine.preprocess_boxes(_lib_boxes)
+                else:
+                    self.engine.preprocess_boxes(_lib_boxes, np.asarray([c[4] for c in chunk], np.int32))
                 rec = self.engine.score_grouped(None, None, prefix, np.tile(suf[None], (G, 1, 1)), np.tile(loc_in[None], (G, 1)),
                                                 np.tile(ver_in[None], (G, 1, 1)) if nv else None, raw=True, internal_pixels=True)
                 self.timers["engine_s"] += time.perf_counter() - t1
@@ -384,8 +404,9 @@ class VSM:
                 sl = slice(s0, s0 + mb)
                 idx = sel_all[sl]
                 t1 = time.perf_counter()
+                skw = {} if slot_arr is None else {"slots": slot_arr[idx]}
                 records[idx] = self.engine.score_boxes(xyxy[idx], ids_rows[sl], np.asarray([per_q[qs[i]][1] for i in idx], np.int32),
-                                                       verify_pos=np.asarray([per_q[qs[i]][2][-nv:] for i in idx], np.int32), raw=True)
+                                                       verify_pos=np.asarray([per_q[qs[i]][2][-nv:] for i in idx], np.int32), raw=True, **skw)
                 self.timers["engine_s"] += time.perf_counter() - t1
                 self.timers["crops"] += len(idx)
         return records

@@ -25,6 +25,8 @@ def parse_args(argv):
     p.add_argument("--vqa-llm", default=None, help="module:factory providing another VQA-LLM implementation")
     p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) providing another VSM implementation")
     p.add_argument("--device", default=0, type=int)
+    p.add_argument("--search-window", dest="search_window", default=0, type=int, help="concurrent visual searches per engine batch "
+                   "(cross-image lock step); 0 = one engine batch, 1 = one image at a time like the reference")
     return p.parse_args(argv)
 
 
@@ -35,6 +37,7 @@ def main(argv):
     args = parse_args(argv)
     from vstar_amd.dist import finalize, init_from_env
     world, rank, local_rank = init_from_env()
+    finished = False
     try:
         if world > 1:
             args.device = local_rank
@@ -52,8 +55,9 @@ def main(argv):
         elif world > 1:
             vsm = make_vsm(args, local_rank)
         eval_model(args, vqa_llm, vsm, world=world, rank=rank)
+        finished = True
     finally:
-        finalize()
+        finalize(finished)
 
 
 if __name__ == "__main__":
