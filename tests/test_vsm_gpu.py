@@ -313,3 +313,37 @@ def test_search_with_device_reductions_equals_host_path(vsm):
     sa = [float(p["score"]) for p in a["search_path"][1:]]
     sb = [float(p["score"]) for p in b["search_path"][1:]]
     assert np.allclose(sa, sb, rtol=1e-5, atol=1e-7)
+
+
+def test_cross_image_stream_equals_per_sample_loop_and_mixes_images(vsm):
+    """visual_search_stream on the engine: (image, target) samples of THREE different images searched in a window
+    — crops of different images in the same engine batch through the image slots — give bit-identical results to the reference's
+    one-sample-at-a-time loop; the GPU preprocessing reads every crop from its own slot."""
+    from vstar_amd.search import visual_search_stream
+    sizes = [(1280, 720), (900, 1100), (1500, 640)]
+    imgs = [synthetic_image(w, h, 70 + k) for k, (w, h) in enumerate(sizes)]
+    samples = [(imgs[0], "kite", None, smallest_size_for(*sizes[0])), (imgs[1], "dog", None, smallest_size_for(*sizes[1])),
+               (imgs[0], "small red umbrella", None, smallest_size_for(*sizes[0])), (imgs[2], "boat", None, smallest_size_for(*sizes[2])),
+               (imgs[1], "traffic light", None, smallest_size_for(*sizes[1]))]
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm.group_prompts = False
+        try:
+            loop = [visual_search(vsm, im, n, gt, sm, speculate=False, **kw) for im, n, gt, sm in samples]
+            st = {}
+            got = visual_search_stream(vsm, samples, window=4, stats=st, **kw)
+            # slot-addressed preprocessing == slot 0 preprocessing of the same image
+            vsm.set_image(imgs[1], 5)
+            vsm.set_image(imgs[1], 0)
+            a = vsm.engine.preprocess_only(np.asarray([[10, 20, 500, 700]], np.int32), [5])
+            b = vsm.engine.preprocess_only(np.asarray([[10, 20, 500, 700]], np.int32))
+        finally:
+            vsm.group_prompts = True
+    for x, y in zip(loop, got):
+        assert x[1] == y[1] and x[2] == y[2] and x[0]["bbox"] == y[0]["bbox"]
+        assert torch.equal(x[0]["detection_result"], y[0]["detection_result"])
+    assert st["searches"] == 5
+    assert st["crops_scored"] >= st["useful_crops"] > 5 and 0.0 <= st["wasted_crop_frac"] < 1.0
+    assert st["engine_steps"] < st["useful_crops"]            # several searches per engine step
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
