@@ -220,6 +220,23 @@ int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t 
 /* Stream handle (hipStream_t) the engine launches on, for HIP-event timing by the caller. */
 void* vstar_stream(vstar_handle* h);
 
+/* The data-parallel exchange of the search loop: one process per GPU, each engine step's crops dealt round-robin
+ * over the ranks, then ONE all-gather of the fixed-size records so that every rank takes the same next-step decision
+ * (replaces nothing in the reference, which is single-GPU: visual_search.py:520-566; it is what BASELINE configs 3/4 add).
+ * RCCL (ncclAllGather over xGMI) on the ENGINE'S stream, bound at run time (dlopen; no link-time dependency).
+ *   vstar_comm_unique_id : rank 0 obtains the 128-byte id and hands it to the other ranks by the host's own means
+ *                          (torch.distributed store, MPI, a file: vstar_amd/dist.py::engine_comm_init shows the torch way)
+ *   vstar_comm_init      : collective over all `world` ranks (ncclCommInitRank on the engine's device)
+ *   vstar_allgather_results : local_dev [n_local] -> gathered_dev [world * n_local] (rank-major; both DEVICE pointers, e.g. the
+ *                          VSTAR_F_DEVICE_OUTPUT buffer of vstar_vsm_score_batch); every rank passes the same n_local (pad the
+ *                          last shard); flags: VSTAR_F_NO_SYNC leaves the gather in flight on the engine's stream
+ *   vstar_comm_destroy   : also called by vstar_destroy */
+#define VSTAR_COMM_ID_BYTES 128
+int vstar_comm_unique_id(uint8_t* id_out /* [VSTAR_COMM_ID_BYTES] */);
+int vstar_comm_init(vstar_handle* h, const uint8_t* id, int world, int rank);
+int vstar_allgather_results(vstar_handle* h, const vstar_result* local_dev, int n_local, vstar_result* gathered_dev, unsigned flags);
+int vstar_comm_destroy(vstar_handle* h);
+
 /* Last-call kernel timing: the engine brackets the dominant GEMM family with HIP events when enabled.
  * Returns accumulated GEMM kernel milliseconds and launch count since the last reset. */
 int vstar_profile_enable(vstar_handle* h, int on);

@@ -57,8 +57,30 @@ def test_device_record_gather_equals_host_records(cuda):
     try:
         devp = vsm.inference_boxes(boxes, q, mode="detection", upsample=False)
         assert vsm.timers["gather_s"] > 0
+        # the C-ABI's own collective (SURVEY §8b `vstar_allgather_results`): the engine gets an RCCL communicator over the group's
+        # ranks (id broadcast through the torch group, ncclCommInitRank, ncclAllGather on the engine's stream) and the product path
+        # switches to it
+        from vstar_amd.dist import engine_comm_init
+        engine_comm_init(eng)
+        assert eng.comm_world == 1
+        local = torch.arange(3 * eng.lib_result_floats(), dtype=torch.float32, device="cuda:0").reshape(3, -1)
+        got = eng.allgather_results(local)
+        assert torch.equal(got, local)
+        devc = vsm.inference_boxes(boxes, q, mode="detection", upsample=False)
     finally:
         dist.destroy_process_group()
-    for a, b in zip(host, devp):
+    for a, b, c in zip(host, devp, devc):
         assert all(torch.equal(x, y) for x, y in zip(a, b))
+        assert all(torch.equal(x, y) for x, y in zip(a, c))
+    eng.close()
+
+
+def test_comm_entry_points_report_misuse(cuda):
+    from vstar_amd._lib import VstarError
+    from vstar_amd.config import VSMConfig
+    from vstar_amd.engine import VstarEngine
+    eng = VstarEngine(VSMConfig.tiny(max_batch=2), 0)
+    with pytest.raises(VstarError, match="vstar_comm_init"):
+        eng.comm_world = 1
+        eng.allgather_results(torch.zeros(1, eng.lib_result_floats(), device="cuda:0"))
     eng.close()

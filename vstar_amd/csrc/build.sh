@@ -15,7 +15,7 @@ stale() {  # stale <object> <source>
   return 1
 }
 # bf16 instantiation: every kernel file + the VSM engine
-for f in gemm gemm256 norm attention elementwise decode quant heads preprocess engine; do
+for f in gemm gemm256 norm attention elementwise decode quant heads preprocess engine comm; do
   if stale build/$f.o $f.hip; then $HIPCC $FLAGS -c $f.hip -o build/$f.o & pids+=($!); fi
 done
 # fp16 instantiation (-DVSTAR_LP_F16): the dtype-generic kernel files + the VQA-LLM engine

@@ -62,6 +62,8 @@ struct vstar_engine : EngineBase {
   int last_B = 0, last_S = 0;
   void* d_stats = nullptr;
   void* d_stats_batch = nullptr; size_t stats_batch_cap = 0;      // vstar_heatmap_stats_batch scratch
+  void* comm = nullptr;                                           // ncclComm_t of vstar_comm_init (comm.hip), or null
+  float* d_up = nullptr; size_t up_cap = 0;                       // vstar_upsample_mask scratch: [192*192 in | h*w out], grow-only
   // GPU-side preprocessing state
   // resident full images, one per slot (vstar_image_set_slot): crops of different images can share an engine batch
   struct ImageSlot { uint8_t* d = nullptr; size_t cap = 0; int H = 0, W = 0; };
@@ -913,10 +915,12 @@ void vstar_destroy(vstar_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
+  vstar_comm_destroy(h);
   h->gen.release();
   h->release_base();
   if (h->d_stats) hipFree(h->d_stats);
   if (h->d_stats_batch) hipFree(h->d_stats_batch);
+  if (h->d_up) hipFree(h->d_up);
   for (auto& im : h->images) if (im.d) hipFree(im.d);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
@@ -1021,6 +1025,7 @@ int vstar_heatmap_stats_batch(vstar_handle* h, int n, const float* lowres, const
   const size_t need = per * (size_t)n;
   if (need > h->stats_batch_cap) {
     if (h->d_stats_batch) hipFree(h->d_stats_batch);
+  if (h->d_up) hipFree(h->d_up);
     h->d_stats_batch = nullptr; h->stats_batch_cap = 0;
     if (hipMalloc(&h->d_stats_batch, need) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats_batch"); return VSTAR_ERR_NOMEM; }
     h->stats_batch_cap = need;
@@ -1048,13 +1053,18 @@ int vstar_upsample_mask(vstar_handle* h, const float* lowres, int h_out, int w_o
 int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int w_out, int clamp_min0, float* out) {
   if (!h || !lowres || !out || h_out <= 0 || w_out <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipSetDevice(h->device);
-  float *din = nullptr, *dout = nullptr;
+  // persistent grow-only scratch (round 2 allocated and freed two buffers per call: the cue / segmentation path and every
+  // committed node of a host-reductions search paid two hipMalloc/hipFree pairs)
   const size_t nin = (size_t)VSTAR_MASK_RES * VSTAR_MASK_RES, nout = (size_t)h_out * w_out;
-  if (hipMalloc(&din, nin * 4) != hipSuccess || hipMalloc(&dout, nout * 4) != hipSuccess) {
-    if (din) hipFree(din);
-    h->set_error("hipMalloc failed in vstar_upsample_mask");
-    return VSTAR_ERR_NOMEM;
+  if (nin + nout > h->up_cap) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
+    if (h->d_up) hipFree(h->d_up);
+    h->d_up = nullptr; h->up_cap = 0;
+    const size_t want = nin + nout + nout / 4;
+    if (hipMalloc((void**)&h->d_up, want * 4) != hipSuccess) { h->set_error("hipMalloc failed in vstar_upsample_mask"); return VSTAR_ERR_NOMEM; }
+    h->up_cap = want;
   }
+  float *din = h->d_up, *dout = h->d_up + nin;
   int rc = VSTAR_OK;
   if (hipMemcpyAsync(din, lowres, nin * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
       resize_bilinear_clamp(din, VSTAR_MASK_RES, VSTAR_MASK_RES, dout, h_out, w_out, h->stream, clamp_min0) != hipSuccess ||
@@ -1063,8 +1073,6 @@ int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int 
     h->set_error("vstar_upsample_mask: HIP failure");
     rc = VSTAR_ERR_HIP;
   }
-  hipFree(din);
-  hipFree(dout);
   return rc;
 }
 
@@ -1244,3 +1252,8 @@ int vstar_op_attention(void* stream, uint16_t* qkv, uint16_t* out, void* ws, siz
 }
 
 }  // extern "C"
+
+// accessors for comm.hip (the handle's layout is private to this file)
+int vstar_handle_device(vstar_handle* h) { return h->device; }
+void vstar_handle_set_error(vstar_handle* h, const char* msg) { h->set_error(msg); }
+void** vstar_handle_comm_slot(vstar_handle* h) { return &h->comm; }

@@ -37,6 +37,25 @@ def allgather_records(local: torch.Tensor, n_items: int, group=None) -> torch.Te
     return gathered[idx % world, idx // world]
 
 
+def engine_comm_init(engine, group=None) -> None:
+    """Gives `engine` (VstarEngine) its own RCCL communicator over the ranks of the torch process group: rank 0 draws the
+    128-byte unique id (vstar_comm_unique_id) and broadcasts it through the group's store — any backend, the id is host bytes —
+    then every rank enters vstar_comm_init.  Afterwards VSM._score_sharded gathers the records with vstar_allgather_results on
+    the engine's stream (no torch.distributed on the data path)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [engine.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    engine.comm_init(box[0], world, rank)
+
+
+def reorder_gathered(gathered: torch.Tensor, world: int, n_items: int) -> torch.Tensor:
+    """[world * per, R] rank-major (what an all-gather of round-robin shards returns) -> [n_items, R] in item order."""
+    per = gathered.shape[0] // world
+    g = gathered.view(world, per, *gathered.shape[1:])
+    idx = torch.arange(n_items, device=gathered.device)
+    return g[idx % world, idx // world]
+
+
 def allgather_numpy(local: np.ndarray, n_items: int, device: str = "cpu") -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(local)).to(device)
     return allgather_records(t, n_items).cpu().numpy()

@@ -232,6 +232,36 @@ class VstarEngine:
         return (self.debug_read("clip_pixels", B * 3 * I * I).reshape(B, 3, I, I),
                 self.debug_read("owl_pixels", B * 3 * O * O).reshape(B, 3, O, O))
 
+    # ---- the search loop's one collective, inside the C-ABI (include/vstar_hip.h: vstar_comm_*, vstar_allgather_results) ----
+    def comm_unique_id(self) -> bytes:
+        buf = (ctypes.c_uint8 * 128)()
+        _lib.check(self.lib.vstar_comm_unique_id(buf), self.handle)
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes, world: int, rank: int) -> None:
+        """Collective: every rank calls it with rank 0's id (vstar_amd.dist.engine_comm_init distributes it)."""
+        assert len(uid) == 128
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(uid)
+        _lib.check(self.lib.vstar_comm_init(self.handle, buf, int(world), int(rank)), self.handle)
+        self.comm_world, self.comm_rank = int(world), int(rank)
+
+    def allgather_results(self, local_dev: torch.Tensor, sync: bool = True) -> torch.Tensor:
+        """local_dev [n_local, RESULT_FLOATS] fp32 on this engine's device -> [world * n_local, RESULT_FLOATS] (rank-major), by
+        ncclAllGather on the engine's stream."""
+        assert local_dev.is_cuda and local_dev.dtype == torch.float32 and local_dev.is_contiguous() and local_dev.shape[1] == _lib.RESULT_FLOATS
+        n = local_dev.shape[0]
+        out = torch.empty((self.comm_world * n, _lib.RESULT_FLOATS), dtype=torch.float32, device=local_dev.device)
+        _lib.check(self.lib.vstar_allgather_results(self.handle, ctypes.c_void_p(local_dev.data_ptr()), n, ctypes.c_void_p(out.data_ptr()),
+                                                    0 if sync else _lib.F_NO_SYNC), self.handle)
+        return out
+
+    comm_world = 0
+    comm_rank = 0
+
+    @staticmethod
+    def lib_result_floats() -> int:
+        return _lib.RESULT_FLOATS
+
     @staticmethod
     def unpack(rec: np.ndarray, n_verify: int = 0) -> Dict[str, np.ndarray]:
         B = rec.shape[0]

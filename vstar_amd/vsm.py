@@ -139,7 +139,12 @@ class VSM:
             self.timers["engine_s"] += time.perf_counter() - t1
             self.timers["crops"] += len(sel)
         t2 = time.perf_counter()
-        if on_device:
+        if on_device and getattr(self.engine, "comm_world", 0) == world and getattr(self, "use_engine_comm", True):
+            # the C-ABI's own collective (vstar_allgather_results: ncclAllGather on the engine's stream, queued behind the kernels
+            # that wrote the records)
+            from .dist import reorder_gathered
+            records = reorder_gathered(self.engine.allgather_results(local), world, n).cpu().numpy()
+        elif on_device:
             records = allgather_records(local, n).cpu().numpy()
         elif world == 1:
             records = local[:n]
