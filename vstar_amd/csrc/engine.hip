@@ -1025,7 +1025,6 @@ int vstar_heatmap_stats_batch(vstar_handle* h, int n, const float* lowres, const
   const size_t need = per * (size_t)n;
   if (need > h->stats_batch_cap) {
     if (h->d_stats_batch) hipFree(h->d_stats_batch);
-  if (h->d_up) hipFree(h->d_up);
     h->d_stats_batch = nullptr; h->stats_batch_cap = 0;
     if (hipMalloc(&h->d_stats_batch, need) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats_batch"); return VSTAR_ERR_NOMEM; }
     h->stats_batch_cap = need;
@@ -1065,15 +1064,28 @@ int vstar_upsample_mask_ex(vstar_handle* h, const float* lowres, int h_out, int 
     h->up_cap = want;
   }
   float *din = h->d_up, *dout = h->d_up + nin;
-  int rc = VSTAR_OK;
-  if (hipMemcpyAsync(din, lowres, nin * 4, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-      resize_bilinear_clamp(din, VSTAR_MASK_RES, VSTAR_MASK_RES, dout, h_out, w_out, h->stream, clamp_min0) != hipSuccess ||
-      hipMemcpyAsync(out, dout, nout * 4, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-      hipStreamSynchronize(h->stream) != hipSuccess) {
-    h->set_error("vstar_upsample_mask: HIP failure");
-    rc = VSTAR_ERR_HIP;
+  hipError_t e;
+  const char* what = "H2D copy";
+  if ((e = hipMemcpyAsync(din, lowres, nin * 4, hipMemcpyHostToDevice, h->stream)) == hipSuccess) {
+    what = "resize kernel";
+    if ((e = resize_bilinear_clamp(din, VSTAR_MASK_RES, VSTAR_MASK_RES, dout, h_out, w_out, h->stream, clamp_min0)) == hipSuccess) {
+      what = "D2H copy";
+      if ((e = hipMemcpyAsync(out, dout, nout * 4, hipMemcpyDeviceToHost, h->stream)) == hipSuccess) {
+        what = "stream sync";
+        e = hipStreamSynchronize(h->stream);
+      }
+    }
   }
-  return rc;
+  if (e != hipSuccess) {
+    char dbg[256];
+    hipPointerAttribute_t at{};
+    const hipError_t pa = hipPointerGetAttributes(&at, din);
+    snprintf(dbg, sizeof(dbg), " [din=%p cap=%zu nin=%zu nout=%zu lowres=%p out=%p attr=%d type=%d dev=%d]", (void*)din, h->up_cap, nin, nout,
+             (const void*)lowres, (void*)out, (int)pa, (int)at.type, at.device);
+    h->set_error(std::string("vstar_upsample_mask: ") + what + ": " + hipGetErrorString(e) + dbg);
+    return VSTAR_ERR_HIP;
+  }
+  return VSTAR_OK;
 }
 
 int64_t vstar_debug_read(vstar_handle* h, const char* name, float* out, int64_t cap) {
