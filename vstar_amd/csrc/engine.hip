@@ -95,6 +95,16 @@ struct vstar_engine : EngineBase {
   int llm_forward(int nseq, int S, int nsel);
   int llm_heads(int nrec, int n_verify);
   int owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_div);
+  int owl_features(const lp_t* opix, int Bimg);                   // the part of a9-a11 that does not depend on the LLaMA path
+  int owl_finish(int Bimg, int nrec, int img_div);                // the part that needs embed_det / embed_seg
+  // Small batches leave most CUs idle in every kernel (under-filled grids), and the OWL-ViT tower + box head + visual projection do
+  // not depend on the CLIP -> LLaMA chain: they run on a SECOND stream, concurrently with it, and join before the class logits
+  // (round 3; same kernels, same results).  Off for large batches (every kernel fills the chip on its own; concurrency would only
+  // thrash the caches) and under event profiling.  VSTAR_OWL_OVERLAP=0/1 forces it.
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int owl_overlap = -1;                                            // -1: automatic (crops <= 8), 0 / 1: forced
+  bool fork_owl(const lp_t* opix, int Bimg, int* rc);              // true: owl_features was enqueued on stream2
   int finish_records(int nrec, int n_verify, unsigned flags, vstar_result* out);
   int stage_pixels(int B, const lp_t* clip_pix, const lp_t* owl_pix, unsigned flags, bool skip_owl, const lp_t** cpix, const lp_t** opix);
   lp_t* grp_feats = nullptr;        // [max_batch * P, H] projected image features (grouped scoring)
@@ -576,11 +586,28 @@ int vstar_engine::llm_heads(int nrec, int n_verify) {
 // ---- a9-a11: OWL-ViT tower on Bimg crops, class/box heads and the SAM-style mask head for nrec records; record n reads the image
 // features of crop n / img_div (grouped scoring: img_div prompts per crop; 1 otherwise)
 int vstar_engine::owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_div) {
+  RC(owl_features(opix, Bimg));
+  return owl_finish(Bimg, nrec, img_div);
+}
+
+bool vstar_engine::fork_owl(const lp_t* opix, int Bimg, int* rc) {
+  *rc = 0;
+  const bool want = owl_overlap >= 0 ? owl_overlap != 0 : Bimg <= 8;
+  if (!want || profile || !stream2) return false;
+  // everything already queued on the main stream (pixel staging, the previous call's copy-out of d_results) precedes the fork
+  if (hipEventRecord(ev_fork, stream) != hipSuccess || hipStreamWaitEvent(stream2, ev_fork, 0) != hipSuccess) {
+    set_error("owl overlap: fork failed"); *rc = VSTAR_ERR_HIP; return false;
+  }
+  std::swap(stream, stream2);                  // the launch helpers enqueue on `stream`
+  *rc = owl_features(opix, Bimg);
+  std::swap(stream, stream2);
+  if (*rc == 0 && hipEventRecord(ev_join, stream2) != hipSuccess) { set_error("owl overlap: join event failed"); *rc = VSTAR_ERR_HIP; }
+  return true;
+}
+
+int vstar_engine::owl_features(const lp_t* opix, int Bimg) {
   const vstar_config& c = cfg;
-  const int B = nrec;
-  const int OH = c.owl_hidden, NP = owl.P, irow = Bimg * NP, prow = nrec * NP;
-  const int rstride = (int)(sizeof(vstar_result) / 4);
-  float* res_f = (float*)d_results;
+  const int OH = c.owl_hidden, NP = owl.P, irow = Bimg * NP;
   // ---- a9: OWL-ViT tower + get_visual_embs (owlvit.py:121-148) ----
   RC(run_tower(owl, opix, Bimg));
   KCHK(layernorm_lp(owl.x, owl_post_g, owl_post_b, owl.h, Bimg * owl.N, OH, 1e-5f, nullptr, 0, stream));
@@ -589,14 +616,27 @@ int vstar_engine::owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_di
   // ---- a10: class + box heads (owlvit.py:150-170) ----
   const int cld = cls_fused.N + 2;
   RC(lin(owl_feats, OH, cls_fused, cls_emb, cld, irow, VSTAR_EPI_NONE, nullptr, 0, true));
-  KCHK(owl_class_logits(cls_emb, cld, c.owl_query_dim, emb_det, res_f + offsetof(vstar_result, pred_logits) / 4, rstride, nrec,
-                        NP, stream, img_div));
   RC(lin(owl_feats, OH, box0, box_t0, OH, irow, VSTAR_EPI_GELU));
   RC(lin(box_t0, OH, box1, box_t1, OH, irow, VSTAR_EPI_GELU));
   RC(lin(box_t1, OH, box2, box_raw, 4, irow, VSTAR_EPI_NONE, nullptr, 0, true));
-  KCHK(owl_box_finish(box_raw, 4, res_f + offsetof(vstar_result, pred_boxes) / 4, rstride, nrec, owl.grid, stream, img_div));
-  // ---- a11: visual_projection + prompt encoder + two-way transformer + upscaling (VSM.py:515-533) ----
+  // ---- a11 (first step): visual_projection (VSM.py:515-517) ----
   RC(lin(owl_feats, OH, vis_proj, s_src, 256, irow));
+  return 0;
+}
+
+int vstar_engine::owl_finish(int Bimg, int nrec, int img_div) {
+  const vstar_config& c = cfg;
+  const int B = nrec;
+  const int NP = owl.P, prow = nrec * NP;
+  const int rstride = (int)(sizeof(vstar_result) / 4);
+  float* res_f = (float*)d_results;
+  const int cld = cls_fused.N + 2;
+  (void)Bimg;
+  // ---- a10: class logits against the det embedding, box finisher (owlvit.py:150-170) ----
+  KCHK(owl_class_logits(cls_emb, cld, c.owl_query_dim, emb_det, res_f + offsetof(vstar_result, pred_logits) / 4, rstride, nrec,
+                        NP, stream, img_div));
+  KCHK(owl_box_finish(box_raw, 4, res_f + offsetof(vstar_result, pred_boxes) / 4, rstride, nrec, owl.grid, stream, img_div));
+  // ---- a11: prompt encoder + two-way transformer + upscaling (VSM.py:518-533) ----
   if (img_div <= 1) {
     KCHK(add_bcast(s_src, no_mask, s_keys, prow, 256, 1, stream));              // src = image_embeddings + dense (no_mask_embed)
   } else {
@@ -705,6 +745,9 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
   const lp_t *cpix = nullptr, *opix = nullptr;
   RC(stage_pixels(B, clip_pix, owl_pix, flags, skip_owl, &cpix, &opix));
+  int frc_owl = 0;
+  const bool forked = !skip_owl && fork_owl(opix, B, &frc_owl);       // OWL-ViT side of the graph on stream2 (small batches)
+  RC(frc_owl);
   last_B = B; last_S = S;
   grp_R0 = grp_Lc = 0;
 
@@ -735,7 +778,14 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   psh_Lp = 0;
   RC(frc);
   RC(llm_heads(B, n_verify));
-  if (!skip_owl) RC(owl_heads_sam(opix, B, B, 1));
+  if (!skip_owl) {
+    if (forked) {
+      HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+      RC(owl_finish(B, B, 1));
+    } else {
+      RC(owl_heads_sam(opix, B, B, 1));
+    }
+  }
   return finish_records(B, n_verify, flags, out);
 }
 
@@ -804,6 +854,9 @@ int vstar_engine::score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* 
   HIPCHK(hipMemcpyAsync(d_rowidx, rowidx.data(), rowidx.size() * 4, hipMemcpyHostToDevice, stream));
   const lp_t *cpix = nullptr, *opix = nullptr;
   RC(stage_pixels(G, clip_pix, owl_pix, flags, false, &cpix, &opix));
+  int frc_owl = 0;
+  const bool forked = fork_owl(opix, G, &frc_owl);
+  RC(frc_owl);
   last_B = nrec; last_S = S;
   // ---- a2 + a3: CLIP tower and projector for the G crops -> feature table; a4: splice by row sources ----
   RC(run_tower(clip, cpix, G));
@@ -819,7 +872,12 @@ int vstar_engine::score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* 
   grp_R0 = grp_Lc = 0;
   RC(rc);
   RC(llm_heads(nrec, n_verify));
-  RC(owl_heads_sam(opix, G, nrec, T));
+  if (forked) {
+    HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+    RC(owl_finish(G, nrec, T));
+  } else {
+    RC(owl_heads_sam(opix, G, nrec, T));
+  }
   return finish_records(nrec, n_verify, flags, out);
 }
 
@@ -907,6 +965,11 @@ int vstar_create(const vstar_config* cfg, int device, vstar_handle** out) {
     delete h;
     return VSTAR_ERR_HIP;
   }
+  if (const char* e = getenv("VSTAR_OWL_OVERLAP")) h->owl_overlap = atoi(e) != 0;
+  if (hipStreamCreate(&h->stream2) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
+    h->stream2 = nullptr;                       // no second stream: everything stays on the main stream
+  }
   *out = h;
   return VSTAR_OK;
 }
@@ -924,6 +987,9 @@ void vstar_destroy(vstar_handle* h) {
   for (auto& im : h->images) if (im.d) hipFree(im.d);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_fork) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) hipEventDestroy(h->ev_join);
   hipStreamDestroy(h->stream);
   delete h;
 }
