@@ -146,7 +146,10 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
     from vstar_amd.search import smallest_size_for, visual_search_stream
     from vstar_amd.synthetic import synthetic_image
     from vstar_amd.vsm import VSM
-    W, H = 3840, 2160
+    W, H = getattr(args, "stream_image_wh", (3840, 2160))
+    on_gpu = torch.cuda.is_available() and not getattr(args, "fake_engine", False)
+    red_dev = f"cuda:{eng.device}" if on_gpu else "cpu"
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     n_img = max(args.stream_samples // args.stream_targets_per_image, 1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -175,26 +178,38 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
             vsm.timers[k] = 0
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
         st = {}
         t0 = time.perf_counter()
         res = visual_search_stream(vsm, mine, window=args.stream_window or None, stats=st, confidence_high=conf_high, **base)
-        torch.cuda.synchronize()
+        sync()
         dt = time.perf_counter() - t0
     t = dict(vsm.timers)
     if world > 1:
         # the job ends when the slowest rank ends; under 'samples' the per-rank counters add up
-        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{eng.device}")
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         if shard == "samples":
             cnt = torch.tensor([st["searches"], st["crops_scored"], st["useful_crops"], st["engine_steps"]], dtype=torch.float64,
-                               device=f"cuda:{eng.device}")
+                               device=red_dev)
             dist.all_reduce(cnt)
             st.update(searches=int(cnt[0]), crops_scored=int(cnt[1]), useful_crops=int(cnt[2]), engine_steps=int(cnt[3]))
             st["wasted_crop_frac"] = 1.0 - st["useful_crops"] / max(st["crops_scored"], 1)
     paths = [int(r[1]) for r in res]
     visited = [int(p.get("path_visited", 0)) for p in st.get("per_search", [])]
+    if getattr(args, "fake_engine", False):
+        # plumbing check: a digest of every search's outcome, so that tests can compare world sizes / shard modes
+        import zlib
+        digest = zlib.crc32(repr([(int(r[1]), bool(r[2]), tuple(r[0]["bbox"])) for r in res]).encode())
+        if world > 1 and shard == "samples":
+            allp = [None] * world
+            dist.all_gather_object(allp, [(int(r[1]), bool(r[2]), tuple(r[0]["bbox"])) for r in res])
+            merged = [None] * len(samples)
+            for rk, part in enumerate(allp):
+                merged[rk::world] = part
+            digest = zlib.crc32(repr(merged).encode())
+        st["outcome_digest"] = digest
     steps = max(int(st["engine_steps"]), 1)
     return {"searches": int(st["searches"]), "searches_per_s": round(st["searches"] / dt, 2),
             "useful_crops_per_s": round(st["useful_crops"] / dt, 2), "records_per_s": round(st["crops_scored"] / dt, 2),
@@ -210,7 +225,8 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
             "stage_s": {"engine_incl_gpu_preprocess": round(t["engine_s"], 3), "record_allgather_and_d2h": round(t["gather_s"], 3),
                         "heatmap_statistics": round(t["post_s"], 3),
                         "allgather_us_per_step": round(t["gather_s"] / steps * 1e6, 1)},
-            "order": "best-first with early stop (reference semantics); speculation by vstar_amd.search.SpeculationPolicy"}
+            "order": "best-first with early stop (reference semantics); speculation by vstar_amd.search.SpeculationPolicy",
+            **({"outcome_digest": st["outcome_digest"]} if "outcome_digest" in st else {})}
 
 
 def small_batch_table(eng, cfg, args, dev, T: int) -> dict:
@@ -243,6 +259,43 @@ def small_batch_table(eng, cfg, args, dev, T: int) -> dict:
         out[str(b)] = {"ms_per_step": round(ms, 2), "crops_per_s": round(b / ms * 1e3, 1)}
     out["note"] = "crops per rank per step -> full-path step time on one GPU; an 8-way sharded 32-crop search step is the '4' row on every rank"
     return out
+
+
+class _FakeStreamEngine:
+    """CPU stand-in for VstarEngine's on-device entry points (--fake-engine): a record is a deterministic function of (image
+    content, box, prompt ids).  Lets the N-process stream legs — crop sharding with the per-step record all-gather, sample sharding,
+    the max-over-ranks timing — run under gloo without a GPU (tests/test_host.py).  NOT a measurement."""
+
+    def __init__(self, cfg):
+        self.cfg, self.device, self.images = cfg, 0, {}
+
+    def set_image(self, image, slot=0):
+        import zlib
+        self.images[int(slot)] = zlib.crc32(np.asarray(image.resize((24, 24))).tobytes())
+
+    def score_boxes(self, xyxy, ids, loc, verify_pos=None, raw=False, out_dev=None, share_prefix=None, slots=None):
+        import zlib
+        xyxy, ids = np.asarray(xyxy), np.asarray(ids)
+        sl = np.zeros(len(xyxy), np.int32) if slots is None else np.asarray(slots)
+        out = np.zeros((len(xyxy), _lib.RESULT_FLOATS), np.float32)
+        for b in range(len(xyxy)):
+            seed = zlib.crc32(repr((self.images[int(sl[b])], tuple(int(v) for v in xyxy[b]), tuple(int(t) for t in ids[b] if t))).encode())
+            rng = np.random.default_rng(seed)
+            out[b, :2304] = rng.standard_normal(2304) * 1.5 - 2.0
+            out[b, 2304:2304 * 5] = rng.random(2304 * 4)
+            out[b, 2304 * 5:2304 * 5 + 192 * 192] = np.repeat(np.repeat(rng.standard_normal((12, 12)) * 6, 16, 0), 16, 1).ravel()
+        return out if raw else VstarEngine.unpack(out, 0)
+
+    unpack = staticmethod(VstarEngine.unpack)
+
+    def upsample_mask(self, low, h, w, clamp=True):
+        t = torch.nn.functional.interpolate(torch.from_numpy(np.asarray(low, np.float32).reshape(1, 1, 192, 192)), (h, w), mode="bilinear",
+                                            align_corners=False)[0, 0]
+        return (t.clamp(min=0) if clamp else t).numpy()
+
+    def heatmap_stats(self, low, h, w, rects=None):
+        H = self.upsample_mask(low, h, w).astype(np.float64)
+        return np.asarray([H.min(), H.max(), H.sum()] + [H[y:y + rh, x:x + rw].sum() for x, y, rw, rh in (rects or [])], np.float64)
 
 
 def fake_engine_run(args, world, rank, dist):
@@ -280,12 +333,18 @@ def fake_engine_run(args, world, rank, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
         assert [float(out[r * B, 0]) for r in range(world)] == [float(r) for r in range(world)]     # rank order of the gather
+    # the stream legs of main() on the stand-in engine: same driver code, gloo collectives, small images
+    args.stream_image_wh = (960, 540)
+    args.stream_samples, args.stream_targets_per_image = min(args.stream_samples, 12), 2
+    fcfg = VSMConfig.tiny(max_batch=4, max_text_len=96)
+    stream = stream_leg(_FakeStreamEngine(fcfg), fcfg, args, world, rank, "crops")
+    stream_samples = stream_leg(_FakeStreamEngine(fcfg), fcfg, args, world, rank, "samples") if world > 1 else None
     if rank == 0:
         fake_line = json.dumps({"metric": "FAKE-ENGINE plumbing check (not a measurement)", "value": round(world * B * args.steps / dt, 3),
                           "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "none", "data": "stub", "config": {"workload": "stub", "parallelism": f"dp{world}"},
-                          "roofline": None, "cpu_baseline": None})
+                          "roofline": None, "cpu_baseline": None, "search_stream": stream, "search_stream_shard_samples": stream_samples})
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -211,6 +211,21 @@ def test_bench_multiprocess_launch_path_on_cpu():
     assert d["ms_per_step"] >= 20.0          # rank 1 sleeps 20 ms per step: max over ranks, not rank 0's 10 ms
     for k in ("metric", "value", "unit", "higher_is_better", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d
+    # the best-first stream legs at N = 2: crop sharding (every rank walks the same searches; each step's crops
+    # dealt over the ranks, records all-gathered) and sample sharding (searches dealt over the ranks) must reach exactly the outcomes
+    # of the single-process run — same searches, same visited nodes, same final boxes
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--fake-engine"],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])["search_stream"]
+    for key in ("search_stream", "search_stream_shard_samples"):
+        leg = d[key]
+        assert "error" not in leg, leg
+        assert leg["ranks"] == 2 and leg["searches"] == ref["searches"] == 12
+        assert leg["useful_crops"] == ref["useful_crops"] and leg["outcome_digest"] == ref["outcome_digest"], (key, leg, ref)
+        assert leg["wasted_crop_frac"] >= 0.0 and leg["searches_per_s"] > 0
+    assert d["search_stream"]["shard"] == "crops" and d["search_stream_shard_samples"]["shard"] == "samples"
+    assert d["search_stream"]["per_rank_crops_per_step"] <= d["search_stream"]["mean_crops_per_step"] / 2 + 1e-9
 
 
 def _make_bench_folder(root):
