@@ -11,7 +11,7 @@ RAW=/tmp/prof_$TAG
 mkdir -p $OUT $RAW
 python bench.py 2>/dev/null | tail -1 > $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-search-leg"
+B="python $R/bench.py --no-cpu-baseline --no-search-leg --no-small-batch --no-config5-line"
 rocprofv3 --kernel-trace --stats -d $RAW/stats -o k -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m" \
          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA:s1" \
@@ -24,7 +24,7 @@ cd $R
 python tools/rocpd_summary.py $RAW/stats/k_results.db > $OUT/kernel_stats.csv
 python tools/pmc_summary.py $RAW/pmc_f/pmc_results.db $RAW/pmc_w/pmc_results.db $RAW/pmc_m/pmc_results.db > $OUT/pmc.json
 python tools/pmc_dump.py $RAW/pmc_s1/pmc_results.db $RAW/pmc_s2/pmc_results.db $RAW/pmc_t/pmc_results.db > $OUT/sq_counters.json 2>/dev/null || true
-python bench.py --fp8 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp8.json
+python bench.py --fp8 --no-cpu-baseline --no-small-batch 2>/dev/null | tail -1 > $OUT/bench_fp8.json
 python tools/gemm_bench.py --iters 40 > $OUT/gemm_bench.txt 2>/dev/null
 python tools/attn_kernel_bench.py > $OUT/attn_kernel_bench.txt 2>/dev/null
 python tools/vqa_bench.py --out $OUT/vqa_bench.json > /dev/null 2>&1 || true
