@@ -46,10 +46,19 @@ __device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, in
     __builtin_amdgcn_sched_barrier(0);                 \
   } while (0)
 
-template <int EPI, bool OUT_F32, int MODE>
-__global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm128_kernel(const GemmParams p) {
+// NW = 64-column wave columns of the tile: 2 = the 128 x 128 tile (2 x 2 waves of 64 x 64), 1 = a 128 x 64 tile (4 x 1 waves of
+// 32 x 64; loader-wave mode only, 72-KiB ring: TWO workgroups per CU) for under-filled grids — twice the workgroups, so every
+// CU gets work and the two co-resident workgroups of a CU pull at 88 instead of 65 KB/us (tools/probes/dma_probe.hip).  A wave
+// always owns whole 64-column spans, so the sumsq epilogue and the gate|up pairing are the same code.
+template <int EPI, bool OUT_F32, int MODE, int NW = 2>
+__global__ __launch_bounds__(MODE == 5 ? 320 : 256, (MODE == 2 || NW == 1) ? 2 : 1) void gemm128_kernel(const GemmParams p) {
   constexpr bool LDR = MODE == 5;
   constexpr int STAGES = LDR ? 3 : MODE;
+  static_assert(NW == 2 || LDR, "the 128 x 64 tile exists in loader-wave mode only");
+  constexpr int BN = 64 * NW;                      // shadows the file-level BN (= 128)
+  constexpr int MF = NW == 2 ? 4 : 2;              // 16-row fragments per wave
+  constexpr int W_TILE = BN * BK * 2;
+  constexpr int LDS_BUF = LDS_TILE + W_TILE;       // shadows the file-level LDS_BUF (= 32 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -103,8 +112,9 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
   if constexpr (LDR) {
     if (wave == 4) {
       // ---- loader wave: all 16 A pieces + 16 W pieces of every K-tile, two K-tiles ahead of the compute waves ----
+      constexpr int WP = BN / 8;                     // 1-KiB pieces of the W tile
       const lp_t* a_all[16];
-      const lp_t* w_all[16];
+      const lp_t* w_all[WP];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int r = j * 8 + st_r;
@@ -112,14 +122,14 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
         int ar = m0 + r;
         ar = ar < p.M ? ar : p.M - 1;
         a_all[j] = p.A + map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8;
-        w_all[j] = p.W + (int64_t)(n0 + r) * p.K + cg * 8;
+        if (j < WP) w_all[j] = p.W + (int64_t)(n0 + r) * p.K + cg * 8;
       }
       auto issue = [&](int buf, int k0) {
         char* base = smem + buf * LDS_BUF;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           __builtin_amdgcn_global_load_lds((gptr_t)(a_all[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((gptr_t)(w_all[j] + k0), (lptr_t)(base + LDS_TILE + j * 1024), 16, 0, 0);
+          if (j < WP) __builtin_amdgcn_global_load_lds((gptr_t)(w_all[j] + k0), (lptr_t)(base + LDS_TILE + j * 1024), 16, 0, 0);
         }
       };
       const int nk = p.K / BK;
@@ -128,8 +138,10 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
       int slot = 2;
       for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");      // K-tile kt has landed, kt+1 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // K-tile kt has landed, the 16 + BN / 8 pieces of kt+1 may be in flight
+        if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         BAR128();                 // publishes K-tile kt; every compute wave is done with slot (kt-1) % 3
         if (kt + 2 < nk) issue(slot, (kt + 2) * BK);
         slot = slot == 2 ? 0 : slot + 1;
@@ -139,20 +151,20 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
   }
 
   // ---- fragment read offsets ----
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = NW == 2 ? wave >> 1 : wave, wc = NW == 2 ? wave & 1 : 0;
   const int fr = lane & 15, fq = lane >> 4;
   const int swz = (fr >> 1) & 7;
   int a_rd[2], w_rd[2];
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk) {
     const int ch = ((kk * 4 + fq) ^ swz) * 16;
-    a_rd[kk] = (wr * 64 + fr) * 128 + ch;
+    a_rd[kk] = (wr * (MF * 16) + fr) * 128 + ch;
     w_rd[kk] = LDS_TILE + (wc * 64 + fr) * 128 + ch;
   }
 
-  f32x4 acc[4][4];
+  f32x4 acc[MF][4];
 #pragma unroll
-  for (int m = 0; m < 4; ++m)
+  for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -189,13 +201,13 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
     const char* base = smem + cur * LDS_BUF;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      lpx8 af[4], wf[4];
+      lpx8 af[MF], wf[4];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) af[m] = *(const lpx8*)(base + a_rd[kk] + m * 2048);
+      for (int m = 0; m < MF; ++m) af[m] = *(const lpx8*)(base + a_rd[kk] + m * 2048);
 #pragma unroll
       for (int n = 0; n < 4; ++n) wf[n] = *(const lpx8*)(base + w_rd[kk] + n * 2048);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < MF; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n)
           acc[m][n] = mfma_16x16x32(wf[n], af[m], acc[m][n]);
@@ -211,8 +223,8 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
   const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
   if (p.row_scale) {       // RMSNorm folded into this linear (see kernels.hpp)
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const int row = m0 + wr * 64 + m * 16 + fr;
+    for (int m = 0; m < MF; ++m) {
+      const int row = m0 + wr * (MF * 16) + m * 16 + fr;
       const float rs = p.row_scale[map_row(row < p.M ? row : p.M - 1, p.a_group, p.a_gstride, p.a_off)];
 #pragma unroll
       for (int n = 0; n < 4; ++n)
@@ -223,8 +235,8 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
   if constexpr (EPI == VSTAR_EPI_NONE && !OUT_F32) {
     if (p.sumsq_out) {     // block-uniform: also write the 64-column sums of squares of the stored values (no early exits: shuffles)
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const int row = m0 + wr * 64 + m * 16 + fr;
+      for (int m = 0; m < MF; ++m) {
+        const int row = m0 + wr * (MF * 16) + m * 16 + fr;
         const int64_t crow = map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off);
         float o[4][4];
 #pragma unroll
@@ -239,8 +251,8 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
     }
   }
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
-    const int row = m0 + wr * 64 + m * 16 + fr;
+  for (int m = 0; m < MF; ++m) {
+    const int row = m0 + wr * (MF * 16) + m * 16 + fr;
     if (row >= p.M) continue;
     const int64_t crow = map_row(row, p.c_group, p.c_gstride, p.c_off);
     if (EPI == VSTAR_EPI_SILU_MUL) {
@@ -259,17 +271,18 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, MODE == 2 ? 2 : 1) void gemm
 int gemm_device_cus();
 namespace {
 
-template <int EPI, bool OUT_F32, int MODE>
+template <int EPI, bool OUT_F32, int MODE, int NW = 2>
 hipError_t launch_stages(const GemmParams& p, hipStream_t s) {
   static bool attr_done = false;
-  auto kern = gemm128_kernel<EPI, OUT_F32, MODE>;
-  constexpr int lds = (MODE == 5 ? 3 : MODE) * LDS_BUF;
+  auto kern = gemm128_kernel<EPI, OUT_F32, MODE, NW>;
+  constexpr int bn = 64 * NW;
+  constexpr int lds = (MODE == 5 ? 3 : MODE) * (LDS_TILE + bn * BK * 2);
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn - 1) / bn);
   hipLaunchKernelGGL(kern, dim3(tiles), dim3(MODE == 5 ? 320 : 256), lds, s, p);
   return hipGetLastError();
 }
@@ -282,12 +295,19 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
   // Measured (profiles/r03_gemm_small_batch.txt, M = 640): o_proj 65 -> 40 us, down_proj 169 -> 104 us, CLIP fc2 54 -> 37 us;
   // with more tiles than CUs the double buffer wins by 5-15 %.  What bounds both: a CU pulls operand tiles from L2 at
   // ~65 (one workgroup) to ~88 KB/us (two) whatever the instruction (tools/probes/dma_probe.hip), and a 128^2 tile needs 32 KiB
-  // per K-tile.  VSTAR_GEMM128_STAGES=2|5 forces one variant (A/B runs).  Same K order in both: bit-identical results.
+  // per K-tile.  VSTAR_GEMM128_STAGES=2|5|6 forces one variant (A/B runs).  Same K order in both: bit-identical results.
   static const int force = [] { const char* e = getenv("VSTAR_GEMM128_STAGES"); return e ? atoi(e) : 0; }();
   const int64_t tiles = (int64_t)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
-  const int mode = force == 2 || force == 5 ? force : (tiles <= gemm_device_cus() && p.K >= 4 * BK ? 5 : 2);
-  if (mode == 5) return launch_stages<EPI, OUT_F32, 5>(p, s);
-  return launch_stages<EPI, OUT_F32, 2>(p, s);
+  // 6 = loader-wave ring on the 128 x 64 tile: grids that fill less than HALF the CUs (CLIP / OWL-ViT out-proj and fc2 at small
+  // batches: 40 - 114 tiles) — twice the workgroups beats the extra A traffic (12 vs 18 us, 27 vs 37 us at M = 577); between half
+  // and all CUs (LLaMA o_proj / down_proj at M = 640: 160 tiles, K up to 11008) the 128 x 128 tile moves fewer bytes and wins
+  // (40 vs 44 us, 104 vs 125 us).  5 = loader-wave ring on the 128 x 128 tile.
+  const int64_t cus = gemm_device_cus();
+  const int mode = force == 2 || force == 5 || force == 6 ? force
+                   : (p.K < 4 * BK || tiles > cus ? 2 : (2 * tiles <= cus ? 6 : 5));
+  if (mode == 6) return launch_stages<EPI, OUT_F32, 5, 1>(p, s);
+  if (mode == 5) return launch_stages<EPI, OUT_F32, 5, 2>(p, s);
+  return launch_stages<EPI, OUT_F32, 2, 2>(p, s);
 }
 
 }  // namespace
