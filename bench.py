@@ -522,7 +522,7 @@ def main():
             search_grouped = search_leg(eng, cfg, args, rank, group=True)
         except Exception as exc:
             search_grouped = {"error": f"{type(exc).__name__}: {exc}"}
-    if not args.no_stream_leg and not args.no_search_leg and not args.skip_owl and not args.tiny:
+    if not args.no_stream_leg and not args.no_search_leg and not args.skip_owl and (not args.tiny or args.rccl_selfcheck):
         try:
             stream = stream_leg(eng, cfg, args, world, rank, "crops")
             if world > 1:

@@ -19,7 +19,7 @@ def test_bench_under_torchrun_one_rank_nccl(cuda):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--tiny",
-           "--batch", "4", "--search-targets", "3", "--no-cpu-baseline", "--rccl-selfcheck"]
+           "--batch", "4", "--search-targets", "3", "--no-cpu-baseline", "--rccl-selfcheck", "--stream-samples", "8"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -30,6 +30,11 @@ def test_bench_under_torchrun_one_rank_nccl(cuda):
     for leg in ("search", "search_grouped"):
         assert "error" not in line[leg], line[leg]
         assert line[leg]["crops_scored"] == 3 * 21
+    # the best-first stream leg through the same one-rank RCCL group: crop sharding with the per-step record all-gather
+    st = line["search_stream"]
+    assert "error" not in st, st
+    assert st["shard"] == "crops" and st["ranks"] == 1 and st["searches"] == 8 and st["useful_crops"] >= 8
+    assert st["stage_s"]["record_allgather_and_d2h"] > 0
 
 
 def test_device_record_gather_equals_host_records(cuda):
