@@ -930,6 +930,13 @@ int vstar_engine::generate(const lp_t* clip_pix, const int32_t* ids, int L, int 
   RC(gen.forward(1, row_off, rows.data(), &slot, &slot, &past, 1, &want, nullptr, &nxt));
   int n = 0;
   past = (int32_t)rows.size();
+  {
+    // the decode loop as a replayed hipGraph (llm_cached.hpp): same kernels, no per-token host round trip
+    bool used = false;
+    RC(gen.decode_greedy_graph(nxt, past, slot, max_new, eos_id, out_ids, &n, &used));
+    if (used) { *n_out = n; return 0; }
+    n = 0;
+  }
   for (;;) {
     out_ids[n++] = nxt;
     if (nxt == eos_id || n >= max_new) break;

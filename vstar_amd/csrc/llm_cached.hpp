@@ -42,6 +42,14 @@ struct LlmCached {
   int max_want = 256;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0;
+  // ---- greedy decode of ONE sequence as a replayed hipGraph (decode_greedy_graph) ----
+  // A decode step is ~165 launches of 10-55 us (5 per layer); their arguments never change from token to token — the token id,
+  // position and past length live in DEVICE arrays — so the step is captured once and replayed; a last kernel of the graph feeds
+  // the arg-max back as the next input and advances the position, and the host looks at the emitted tokens every few steps only.
+  hipGraphExec_t dec_exec = nullptr;
+  int dec_keys_bound = 0;                        // context bound the captured attention launch was sized for
+  int32_t* d_dec = nullptr;                      // [0] = tokens emitted so far, [1..] = the tokens
+  int dec_cap = 0;
 
   void set_error(const std::string& m) { e->set_error(m); }
   int init(EngineBase* owner, const LlmCachedCfg& c, const lp_t* embed_, const std::vector<LlmBlock>* blocks_,
@@ -50,7 +58,11 @@ struct LlmCached {
     if (ev0) hipEventDestroy(ev0);
     if (ev1) hipEventDestroy(ev1);
     ev0 = ev1 = nullptr;
+    if (dec_exec) hipGraphExecDestroy(dec_exec);
+    dec_exec = nullptr;
   }
+  int decode_step_body(int keys_bound);
+  int decode_greedy_graph(int32_t first_token, int past, int slot, int max_new, int eos_id, int32_t* out_ids, int* n_out, bool* used);
   int lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
                const lp_t* res = nullptr, int64_t ldr = 0);
   int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
@@ -263,6 +275,121 @@ inline int LlmCached::forward(int nseq, const int32_t* row_off, const int32_t* s
   float ms = 0;
   if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) last_ms = ms;
   e->collect_profile();
+  return 0;
+}
+
+namespace {
+// last node of the decode graph: the arg-max becomes the next input token, position and past length advance, the token is logged
+__global__ void decode_advance_kernel(const int32_t* __restrict__ argmax, int32_t* src, int32_t* row_pos, int32_t* seq_past, int32_t* log,
+                                      int cap) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int32_t t = argmax[0];
+  src[0] = t;
+  row_pos[0] += 1;
+  seq_past[0] += 1;
+  const int32_t n = log[0];
+  if (n < cap) log[1 + n] = t;
+  log[0] = n + 1;
+}
+}  // namespace
+
+// one decode step of ONE sequence (row 0) with every per-step value read from device memory: what the graph captures
+inline int LlmCached::decode_step_body(int keys_bound) {
+  const LlmCachedCfg& c = cfg;
+  const int H = c.hidden;
+  LCHK(embed_rows(d_src, embed, c.vocab, feats, n_feat_rows, lx, 1, H, e->stream));
+  RC(llm_layers_cached(1, 1, keys_bound, true));
+  const size_t vpad = (size_t)(c.vocab + 255) / 256 * 256;
+  LCHK(gather_rows(lx, d_want, wsel, 1, H, e->stream));
+  RC(lin_norm(wsel, final_norm, wnorm, *lm_head, logits, (int64_t)vpad, 1, VSTAR_EPI_NONE));
+  LCHK(argmax_rows_lp(logits, 1, c.vocab, (int64_t)vpad, d_argmax, e->stream));
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, e->stream, d_argmax, d_src, d_row_pos,
+                     d_seq + 2 * c.max_slots * 4, d_dec, dec_cap);
+  LCHK(hipGetLastError());
+  return 0;
+}
+
+// Greedy continuation of the sequence in `slot` whose cache holds `past` positions, starting from `first_token` (already the
+// arg-max of the prefill): emits up to max_new - 1 further tokens, stopping at eos_id.  *used = false when the graph path is
+// not available (event profiling on, capture refused): the caller then runs the stepwise loop — same kernels, same tokens.
+inline int LlmCached::decode_greedy_graph(int32_t first_token, int past, int slot, int max_new, int eos_id, int32_t* out_ids,
+                                          int* n_out, bool* used) {
+  *used = false;
+  const LlmCachedCfg& c = cfg;
+  static const bool disabled = [] { const char* v = getenv("VSTAR_DECODE_GRAPH"); return v && atoi(v) == 0; }();
+  if (disabled || e->profile || max_new < 2) return 0;
+  LCHK(hipSetDevice(e->device));
+  if (!d_dec) {
+    dec_cap = c.max_ctx;
+    RC(e->dalloc(&d_dec, (size_t)dec_cap + 1));
+  }
+  const int keys_bound = c.max_ctx;                  // sizes the attention launch's LDS (4 B per key): fixed for the graph's lifetime
+  // ---- per-call state of row 0 ----
+  std::vector<int32_t> seqmeta((size_t)3 * c.max_slots * 4, 0);
+  seqmeta[0] = slot; seqmeta[(size_t)c.max_slots * 4] = slot; seqmeta[(size_t)2 * c.max_slots * 4] = past;
+  const int32_t zero = 0, pos0 = past, slot0 = slot, tok0 = first_token;
+  LCHK(hipMemcpyAsync(d_src, &tok0, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_pos, &pos0, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_slot, &slot0, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_row_seq, &zero, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_seq, seqmeta.data(), seqmeta.size() * 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_want, &zero, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipMemcpyAsync(d_dec, &zero, 4, hipMemcpyHostToDevice, e->stream));
+  LCHK(hipStreamSynchronize(e->stream));
+  int launched = 0;
+  if (!dec_exec || dec_keys_bound != keys_bound) {
+    if (dec_exec) { hipGraphExecDestroy(dec_exec); dec_exec = nullptr; }
+    // the first step runs UNCAPTURED: it is a real decode step (its token is consumed below) and it takes every one-time
+    // hipFuncSetAttribute of the launch helpers out of the capture
+    RC(decode_step_body(keys_bound));
+    LCHK(hipStreamSynchronize(e->stream));
+    launched = 1;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    const int rc = decode_step_body(keys_bound);
+    const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+    if (rc != 0 || ce != hipSuccess || !graph) {
+      if (graph) hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      if (rc) return rc;
+    } else {
+      const hipError_t ie = hipGraphInstantiate(&dec_exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (ie != hipSuccess) { dec_exec = nullptr; (void)hipGetLastError(); }
+      else dec_keys_bound = keys_bound;
+    }
+  }
+  *used = true;                                         // from here on this function owns the sequence's state
+  int n = 0;
+  out_ids[n++] = first_token;
+  const int CHUNK = 8;                                  // tokens decoded between two looks at the emitted ids
+  std::vector<int32_t> log((size_t)max_new + 1);
+  bool done = first_token == eos_id;
+  LCHK(hipEventRecord(ev0, e->stream));
+  int timed = 0;
+  while (!done && n < max_new) {
+    int todo = std::min(CHUNK, max_new - 1 - launched);
+    if (n - 1 < launched) todo = 0;                      // tokens of the uncaptured first step are still to be read
+    else if (todo <= 0) break;
+    for (int i = 0; i < todo; ++i) {
+      if (dec_exec) LCHK(hipGraphLaunch(dec_exec, e->stream));
+      else RC(decode_step_body(keys_bound));            // capture refused: the same step, launch by launch
+    }
+    launched += todo;
+    timed += todo;
+    LCHK(hipMemcpyAsync(log.data(), d_dec, ((size_t)launched + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    LCHK(hipStreamSynchronize(e->stream));
+    while (n - 1 < launched && n < max_new) {
+      const int32_t t = log[(size_t)n];                 // log[1 + k] = k-th emitted token, out_ids[1 + k]
+      out_ids[n++] = t;
+      if (t == eos_id) { done = true; break; }
+    }
+  }
+  LCHK(hipEventRecord(ev1, e->stream));
+  LCHK(hipStreamSynchronize(e->stream));
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && timed > 0) last_ms = ms / timed;
+  *n_out = n;
   return 0;
 }
 
