@@ -522,7 +522,7 @@ class SpeculationPolicy:
     The priors are deliberately simple constants (children of the node being scored, queue entries best-first with geometric
     decay); `wasted_crop_frac` in the drivers' stats is the measured outcome."""
 
-    DEFAULT_STEP_MS = {1: 17.3, 2: 23.5, 4: 36.6, 8: 64.0, 16: 126.5, 32: 232.7}
+    DEFAULT_STEP_MS = {1: 16.8, 2: 23.5, 4: 36.5, 8: 63.7, 16: 126.5, 32: 232.7}
 
     def __init__(self, step_ms: Optional[Dict[int, float]] = None, cap: int = 32, world: int = 1, p_child: float = 0.45,
                  p_queue: float = 0.5, queue_decay: float = 0.5, max_queue_rank: int = 4, enabled: bool = True):
