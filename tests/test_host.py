@@ -425,3 +425,19 @@ def test_grouped_scoring_bookkeeping_returns_records_in_the_callers_order(mode):
     else:
         assert all(T >= 2 for _, T in eng.grouped_calls)
         assert sum(eng.plain_calls) == 3
+
+
+def test_calibrate_step_ms_feeds_the_speculation_policy():
+    """VSM.calibrate_step_ms measures t(B) on the engine at hand (here the CPU stand-in) and visual_search_stream's default policy
+    picks the table up (`step_ms_table`)."""
+    from vstar_amd.search import SpeculationPolicy
+    from vstar_amd.vsm import VSM
+    eng = _FakeEngine(max_batch=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(eng.cfg.llm_vocab), strict_template=False)
+    table = vsm.calibrate_step_ms(batches=(1, 2, 4, 8), repeats=1)
+    assert list(table) == [1, 2, 4] and all(v > 0 for v in table.values())      # 8 > max_batch is skipped
+    assert vsm.step_ms_table is table
+    pol = SpeculationPolicy(vsm.step_ms_table, cap=8)
+    assert pol.step_ms(1) == table[1] and pol.step_ms(3) == pytest.approx((table[2] + table[4]) / 2)

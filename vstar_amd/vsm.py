@@ -102,6 +102,34 @@ class VSM:
         self.fallback_log: List[dict] = []      # one entry per stepwise-decode fallback (diagnostics / tests)
         self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0}
 
+    # ---- cost model of a scoring step (vstar_amd.search.SpeculationPolicy) ----
+    step_ms_table = None    # {crops per rank: ms}; None = the policy's built-in MI355X measurements
+
+    def calibrate_step_ms(self, batches=(1, 2, 4, 8, 16, 32), repeats: int = 2) -> dict:
+        """Measures t(B) — one full scoring step of B crops on THIS engine and GPU — for the speculation cost model and stores it
+        in `step_ms_table`.  Synthetic pixels and ids of the current geometry; ~1 s at the 7B geometry."""
+        import time as _t
+        cfg = self.cfg
+        table = {}
+        g = torch.Generator().manual_seed(0)
+        ids1 = self._ids(LOCATE_QUESTION.format("object"))
+        for B in batches:
+            if B > cfg.max_batch:
+                break
+            clip = torch.randn(B, 3, cfg.clip_image_size, cfg.clip_image_size, generator=g).bfloat16()
+            owl = torch.randn(B, 3, cfg.owl_image_size, cfg.owl_image_size, generator=g).bfloat16()
+            ids = np.tile(ids1[0][None], (B, 1))
+            loc = np.full((B,), ids1[1], np.int32)
+            best = None
+            for _ in range(repeats + 1):
+                t0 = _t.perf_counter()
+                self.engine.score_batch(clip, owl, ids, loc, raw=True)
+                dt = (_t.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+            table[int(B)] = round(best, 3)
+        self.step_ms_table = table
+        return table
+
     # ---- multi-GPU plumbing ----
     shard_crops = True      # False: this process scores every crop itself even when a process group exists (sample-level DP)
 
