@@ -341,6 +341,9 @@ def test_gemm_ragged_round_split_is_bit_identical(lib, cuda, M, N, K, epi, use_b
     (1100, 512, 256, 4, False, False, False),      # SiLU(gate)*up
     (1200, 384, 128, 3, True, True, False),        # RELU + bias + residual, N tail
     (1056, 514, 768, 0, True, False, True),        # fused class-head width (N = 514)
+    (1280, 4096, 4096, 0, False, True, False),     # 320 tiles of 128^2, long K: the 128 x 256 loader-wave tile (o_proj, 2 crops)
+    (1280, 8192, 2048, 4, False, False, False),    # the same tile with SiLU(gate)*up
+    (1150, 6912, 2048, 0, True, False, True),      # ... fp32 output, bias, M tail
 ])
 def test_gemm128_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res, f32):
     """Both kernels accumulate K in the same order with the same epilogue arithmetic: forced onto the same operands they

@@ -50,13 +50,17 @@ __device__ __forceinline__ int64_t map_row(int r, int group, int64_t gstride, in
 // 32 x 64; loader-wave mode only, 72-KiB ring: TWO workgroups per CU) for under-filled grids — twice the workgroups, so every
 // CU gets work and the two co-resident workgroups of a CU pull at 88 instead of 65 KB/us (tools/probes/dma_probe.hip).  A wave
 // always owns whole 64-column spans, so the sumsq epilogue and the gate|up pairing are the same code.
+// NW = 4: a 128 x 256 tile (2 x 4 = EIGHT compute waves of 64 x 64 + the loader wave, 144-KiB ring, one workgroup per CU) for
+// the wide projections of small batches (qkv / gate|up at M = 640: 480 / 860 tiles of 128^2 on 256 CUs): three quarters of the
+// operand bytes per MFMA of the 128^2 tile, which is what bounds this regime (see launch<> below).
 template <int EPI, bool OUT_F32, int MODE, int NW = 2>
-__global__ __launch_bounds__(MODE == 5 ? 320 : 256, (MODE == 2 || NW == 1) ? 2 : 1) void gemm128_kernel(const GemmParams p) {
+__global__ __launch_bounds__(MODE == 5 ? (NW == 4 ? 576 : 320) : 256, (NW != 4 && (MODE == 2 || NW == 1)) ? 2 : 1) void gemm128_kernel(const GemmParams p) {
   constexpr bool LDR = MODE == 5;
   constexpr int STAGES = LDR ? 3 : MODE;
-  static_assert(NW == 2 || LDR, "the 128 x 64 tile exists in loader-wave mode only");
+  static_assert(NW == 2 || LDR, "the 128 x 64 and 128 x 256 tiles exist in loader-wave mode only");
   constexpr int BN = 64 * NW;                      // shadows the file-level BN (= 128)
-  constexpr int MF = NW == 2 ? 4 : 2;              // 16-row fragments per wave
+  constexpr int MF = NW == 1 ? 2 : 4;              // 16-row fragments per wave
+  constexpr int NCW = NW == 4 ? 8 : 4;             // compute waves; the loader wave is wave NCW
   constexpr int W_TILE = BN * BK * 2;
   constexpr int LDS_BUF = LDS_TILE + W_TILE;       // shadows the file-level LDS_BUF (= 32 KiB)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,25 +114,28 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, (MODE == 2 || NW == 1) ? 2 :
   };
 
   if constexpr (LDR) {
-    if (wave == 4) {
-      // ---- loader wave: all 16 A pieces + 16 W pieces of every K-tile, two K-tiles ahead of the compute waves ----
+    if (wave == NCW) {
+      // ---- loader wave: all 16 A pieces + BN / 8 W pieces of every K-tile, two K-tiles ahead of the compute waves ----
       constexpr int WP = BN / 8;                     // 1-KiB pieces of the W tile
+      constexpr int NP = WP > 16 ? WP : 16;
       const lp_t* a_all[16];
       const lp_t* w_all[WP];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < NP; ++j) {
         const int r = j * 8 + st_r;
         const int cg = st_c ^ ((r >> 1) & 7);
-        int ar = m0 + r;
-        ar = ar < p.M ? ar : p.M - 1;
-        a_all[j] = p.A + map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8;
+        if (j < 16) {
+          int ar = m0 + r;
+          ar = ar < p.M ? ar : p.M - 1;
+          a_all[j] = p.A + map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda + cg * 8;
+        }
         if (j < WP) w_all[j] = p.W + (int64_t)(n0 + r) * p.K + cg * 8;
       }
       auto issue = [&](int buf, int k0) {
         char* base = smem + buf * LDS_BUF;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          __builtin_amdgcn_global_load_lds((gptr_t)(a_all[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
+        for (int j = 0; j < NP; ++j) {
+          if (j < 16) __builtin_amdgcn_global_load_lds((gptr_t)(a_all[j] + k0), (lptr_t)(base + j * 1024), 16, 0, 0);
           if (j < WP) __builtin_amdgcn_global_load_lds((gptr_t)(w_all[j] + k0), (lptr_t)(base + LDS_TILE + j * 1024), 16, 0, 0);
         }
       };
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, (MODE == 2 || NW == 1) ? 2 :
         __builtin_amdgcn_sched_barrier(0);
         // K-tile kt has landed, the 16 + BN / 8 pieces of kt+1 may be in flight
         if (kt + 1 >= nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         else if constexpr (NW == 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
         BAR128();                 // publishes K-tile kt; every compute wave is done with slot (kt-1) % 3
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(MODE == 5 ? 320 : 256, (MODE == 2 || NW == 1) ? 2 :
   }
 
   // ---- fragment read offsets ----
-  const int wr = NW == 2 ? wave >> 1 : wave, wc = NW == 2 ? wave & 1 : 0;
+  const int wr = NW == 4 ? wave >> 2 : (NW == 2 ? wave >> 1 : wave), wc = NW == 4 ? wave & 3 : (NW == 2 ? wave & 1 : 0);
   const int fr = lane & 15, fq = lane >> 4;
   const int swz = (fr >> 1) & 7;
   int a_rd[2], w_rd[2];
@@ -283,7 +291,7 @@ hipError_t launch_stages(const GemmParams& p, hipStream_t s) {
     attr_done = true;
   }
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + bn - 1) / bn);
-  hipLaunchKernelGGL(kern, dim3(tiles), dim3(MODE == 5 ? 320 : 256), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles), dim3(MODE == 5 ? (NW == 4 ? 576 : 320) : 256), lds, s, p);
   return hipGetLastError();
 }
 
@@ -303,8 +311,17 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
   // and all CUs (LLaMA o_proj / down_proj at M = 640: 160 tiles, K up to 11008) the 128 x 128 tile moves fewer bytes and wins
   // (40 vs 44 us, 104 vs 125 us).  5 = loader-wave ring on the 128 x 128 tile.
   const int64_t cus = gemm_device_cus();
-  const int mode = force == 2 || force == 5 || force == 6 ? force
-                   : (p.K < 4 * BK || tiles > cus ? 2 : (2 * tiles <= cus ? 6 : 5));
+  // 7 = loader-wave ring on the 128 x 256 tile (W is padded to 256 rows by contract).
+  // More 128^2 tiles than CUs and a long K (the LLaMA linears of 1 - 3 crops: qkv / gate|up at M = 640, o / down at M = 1280 and
+  // 1920): whole rounds of 128 x 256 tiles at 1.05 us per K-tile against whole rounds of two co-resident 128^2 tiles at 1.28 us
+  // (profiles/r03_gemm_small_batch.txt: qkv 79 -> 68 us, gate|up 144 -> 126 us at M = 640; o 75 -> 65 us, down 183 -> 171 us at
+  // M = 1280).  Short-K shapes (the ViT towers) lose on the wide tile's prologue and direct-store epilogue and keep mode 2.
+  const int64_t tiles7 = (int64_t)((p.M + BM - 1) / BM) * ((p.N + 255) / 256);
+  const bool wide = p.K >= 2048 && tiles > cus &&
+                    1.05 * (double)((tiles7 + cus - 1) / cus) <= 1.28 * (double)((tiles + 2 * cus - 1) / (2 * cus));
+  const int mode = force == 2 || force == 5 || force == 6 || force == 7 ? force
+                   : (p.K < 4 * BK ? 2 : (wide ? 7 : (tiles > cus ? 2 : (2 * tiles <= cus ? 6 : 5))));
+  if (mode == 7) return launch_stages<EPI, OUT_F32, 5, 4>(p, s);
   if (mode == 6) return launch_stages<EPI, OUT_F32, 5, 1>(p, s);
   if (mode == 5) return launch_stages<EPI, OUT_F32, 5, 2>(p, s);
   return launch_stages<EPI, OUT_F32, 2, 2>(p, s);
