@@ -339,8 +339,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     bool rope_tile = false;
     if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
     const char* slab_partner = smem + TILE_BYTES + (wave ^ 1) * (32 * (128 + 16));
+    // Residual (VSTAR_EPI_NONE, whole tiles in N): added in stage 1, in the accumulator layout — the quarter's eight 8-byte loads
+    // are in flight together.  Added after the transpose (gemm_epilogue_store_row8) the load sits in the rolled row loop, one
+    // memory round trip per 8 rows, 16 in series per tile (OWL-ViT out-proj 145 -> 130 us, fc2 336 -> 322, LLaMA o_proj 531 -> 518;
+    // a further quarter of lookahead, or the whole tile's residual requested before the epilogue, measured the same / spilled).
+    // Same arithmetic either way: rlp(rlp(acc + bias) + res).
+    bool res1 = false;
+    if constexpr (EPI == VSTAR_EPI_NONE)
+      res1 = p.res != nullptr && !rope_tile && en0 + BN <= n_out && (((uintptr_t)p.res & 7) == 0) && (p.ldr % 4 == 0);
     auto quarter_pass = [&](auto qc) {
       constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
+      lpx4 rv[2][NF];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int row = em0 + wr * 128 + (qp * 2 + m) * 16 + fr;
+        const lp_t* rp = p.res + gemm_map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off) * p.ldr + colbase + fq * 4;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) rv[m][f] = res1 ? *(const lpx4*)(rp + f * 16) : (lpx4){0, 0, 0, 0};
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -353,6 +369,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           } else {   // stage 1 = bf16(acc + bias); the activation is applied after the transpose
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (short)f2lp(acc[qp * 2 + m][f][e] + bias_v[f][e]);
+            if constexpr (EPI == VSTAR_EPI_NONE) {
+              if (res1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (short)f2lp(lp2f((lp_t)v[e]) + lp2f((lp_t)rv[m][f][e]));
+              }
+            }
           }
           *(lpx4*)(slab + (m * 16 + fr) * RSTRIDE + (f * 16 + fq * 4) * 2) = v;
         }
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           }
         }
         const int64_t crow = gemm_map_row(row < p.M ? row : p.M - 1, p.c_group, p.c_gstride, p.c_off);
-        if (row < p.M && !(p.debug_flags & 1)) gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v);
+        if (row < p.M && !(p.debug_flags & 1)) gemm_epilogue_store_row8<EPI>(p, crow, colbase + ch * 8, n_out, v, res1);
         if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
           if (p.sumsq_out) {          // tile-uniform: statistics of the next RMSNorm from the values just stored (8 lanes = this row's 64 columns)
             const float ss = gemm_sumsq_span64_chunks(v);

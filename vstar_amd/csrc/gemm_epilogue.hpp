@@ -103,8 +103,10 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 // (or the finished SiLU*up product) -> activation -> + residual -> one 16-byte store.  Whole 128-byte lines per 8 lanes
 // instead of 32-byte fragments.  The transcendental activations live here (static 8-element bodies) so that the
 // accumulator-indexed stage-1 loops stay small enough to unroll (a runtime-indexed acc[] would go to scratch).
+// `res_done`: the caller has already added the residual (gemm256 adds it in the accumulator layout, see there).
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8& v) {
+__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8& v,
+                                                         bool res_done = false) {
   if (col >= n_out) return;
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
@@ -118,7 +120,7 @@ __device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, in
   }
   lp_t* c = (lp_t*)p.C + crow * p.ldc + col;
   const bool full = (col + 7 < n_out) && ((((uintptr_t)c) & 15) == 0);
-  if (p.res) {
+  if (p.res && !res_done) {
     const lp_t* rp = p.res + crow * p.ldr + col;
     if (full && ((((uintptr_t)rp) & 15) == 0)) {
       const lpx8 rv = *(const lpx8*)rp;
