@@ -204,6 +204,40 @@ def test_weight_streaming_gemm(cuda, lib, M, N, K, epi):
     assert float((outs[0] - outs[1]).abs().max()) <= 1e-3 * scale + 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,epi,norm,use_res", [
+    (1, 4096, 4096, 0, False, True),       # o_proj + residual, batch 1
+    (1, 12288, 4096, 0, True, False),      # qkv with the fused RMSNorm
+    (1, 22016, 4096, 4, True, False),      # gate|up, SiLU(gate)*up, fused RMSNorm
+    (1, 4096, 11008, 0, False, True),      # down_proj: 172 double steps = 21.5 per wave
+    (4, 1024, 512, 0, False, False),       # one double step per wave
+    (16, 1000, 1088, 0, True, True),       # 17 double steps: some waves 3, some 2; N tail
+    (7, 512, 1536, 4, False, False),       # 3 per wave, NT = 2 (ring depth 2)
+    (3, 256, 6144, 0, True, False),        # 12 per wave: three steady rounds
+])
+def test_weight_streaming_ring_kernel_is_bit_identical(cuda, lib, M, N, K, epi, norm, use_res):
+    """gemm_skinny_ring_kernel (weights through per-wave LDS rings, M <= 16: every decode step) against gemm_skinny_kernel
+    (weights through registers) on the same operands: the same MFMA operands in the same order -> the same bits."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    Npad = (N + 255) // 256 * 256
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g) * 1.5).half().cuda()
+    W = torch.zeros(Npad, K, dtype=torch.float16)
+    W[:N] = (torch.randn(N, K, generator=g) / K ** 0.5).half()
+    W = W.cuda()
+    gain = (1 + 0.1 * torch.randn(K, generator=g)).half().cuda() if norm else None
+    bias = (torch.randn(Npad, generator=g) * 0.1).half().cuda() if epi != 4 and not norm else None
+    res = (torch.randn(M, n_out, generator=g) * 0.5).half().cuda() if use_res else None
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    outs = []
+    for kernel in (1, 3):
+        C = torch.full((M, n_out), float("nan"), dtype=torch.float16, device="cuda")
+        rc = lib.vstar_vqa_op_gemm(P(A), P(W), P(bias), P(res), P(C), M, N, K, epi, kernel, P(gain), 1e-5)
+        assert rc == 0, lib.vstar_vqa_last_error(None)
+        outs.append(C)
+    assert not torch.isnan(outs[0].float()).any()
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(1, 768, 4096, 0), (9, 512, 1024, 0), (32, 2048, 4096, 4)])
 def test_weight_streaming_gemm_with_fused_rmsnorm(cuda, lib, M, N, K, epi):
     """LlamaRMSNorm fused into the operand load == HF's two-step form (fp32 statistics, fp16 rounding points) + GEMM."""

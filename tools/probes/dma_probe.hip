@@ -30,6 +30,10 @@ __global__ __launch_bounds__(WAVES * 64) void probe(const char* src, long pitch,
       const char* g = base + (long)row * pitch + k0 + st_c * 16;
       if (MODE == 0) {
         __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(lbase + piece * 1024), 16, 0, 0);
+      } else if (MODE == 2) {      // output side: 16-byte non-temporal row stores, as the GEMM epilogue writes C
+        __builtin_nontemporal_store(acc, (i32x4*)g);
+      } else if (MODE == 3) {
+        *(i32x4*)g = acc;
       } else {
         const i32x4 v = *(const i32x4*)g;
         acc += v;
@@ -65,12 +69,21 @@ void run(const char* name, const char* buf, long pitch, int rows_span, int nwg, 
          ms * 1e3, bytes / ms / 1e9, 32.768 * iters / (ms * 1e3));
 }
 
-int main() {
+int main(int argc, char** argv) {
   const size_t total = (size_t)3 << 30;
   char* buf; int* sink;
   hipMalloc(&buf, total); hipMalloc(&sink, 64);
   hipMemset(buf, 1, total);
   const int iters = 2048;
+  if (argc > 1 && argv[1][0] == 's') {      // store-side probe: how fast can one CU WRITE (the GEMM epilogue: 128 KiB per 256^2 tile)
+    for (int nwg : {64, 256, 512}) {
+      run<2, 8>("nt-store stream 2MiB/WG pitch 8K", buf, 8192, 256, nwg, sink, (long)2 << 20, 256);
+      run<3, 8>("store    stream 2MiB/WG pitch 8K", buf, 8192, 256, nwg, sink, (long)2 << 20, 256);
+      run<2, 4>("nt-store stream 2MiB/WG pitch 8K", buf, 8192, 256, nwg, sink, (long)2 << 20, 256);
+      run<2, 8>("nt-store rows of 512 B (N=256 tile)", buf, 512, 4096, nwg, sink, (long)2 << 20, 256);
+    }
+    return 0;
+  }
   for (int nwg : {160, 256, 512}) {
     // (a) tiny footprint: 256 rows x 128 B pitch = 32 KiB per WG (L1/L2 hits)
     run<0, 4>("dma  L2-resident 32KiB/WG", buf, 128, 256, nwg, sink, 65536, iters);

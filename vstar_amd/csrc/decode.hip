@@ -13,6 +13,8 @@
 //   perceiver_attn       32 latents x (256 media + 32 latent) keys, 16 heads x 96 dims: one wave per (image, head, latent).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
@@ -26,6 +28,7 @@ namespace {
 // the B operand (16 rows x 32 k); lane (fr = lane%16, g = lane/16) loads 16 bytes at k = ks*32 + g*8 of W row / A row fr.
 // The accumulator lane then owns output row fr, columns 4g..4g+3 — the layout gemm_epilogue_store expects.
 constexpr int SK_WAVES = 8;
+constexpr int SKR_WAVE_BYTES = 10240;      // gemm_skinny_ring_kernel: LDS ring per wave
 
 template <int EPI, bool OUT_F32, int MT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmParams p) {
@@ -154,11 +157,201 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(const GemmPa
   else gemm_epilogue_store<EPI, OUT_F32>(p, row, n0 + g * 4, n_out, s[0], s[0]);
 }
 
+// ------------------------------------------------ skinny GEMM, M <= 8, operands through LDS rings ------------------------
+// The same arithmetic as gemm_skinny_kernel<EPI, OUT_F32, 1> — the same MFMA operands in the same order per wave (wave w owns
+// the 64-element double steps ds = w, w + 8, ...), the same fixed-order cross-wave reduction: BIT-IDENTICAL results — but no
+// operand passes through registers on its way in.  Every wave owns a private ring of RD stages in LDS; a stage is one double
+// step: the workgroup's 16 (x NT) weight rows (2 KiB each, two LDS-DMA requests of 8 rows x 128 B: whole cache lines, where
+// the register loads above touch 16 rows x 64 B per request) plus ONE 1-KiB request for the activation side — rows 0..6 = the
+// (up to 7) activation rows, row 7 = the RMSNorm weight slice when the norm is fused.  Requests cost no registers, so
+// RD stages (9 - 10 KiB per wave, 72 - 80 KiB per workgroup, two workgroups per CU) are in flight instead of 16 KiB per
+// workgroup: a decode step at batch 1 has one workgroup per CU in o_proj / down_proj, and 16 KiB in flight per CU is a third of
+// what 6 TB/s x ~2 us of latency needs.  No barrier in the K loop (private rings, counted vmcnt).  Everything in the queue is an
+// LDS-DMA request on purpose: register loads mixed into the counted waits returned out of order with the DMA requests
+// (wrong results under load), requests of one kind retire in order.
+template <int EPI, bool OUT_F32, bool NORM>
+__global__ __launch_bounds__(SK_WAVES * 64, 2) void gemm_skinny_ring_kernel(const GemmParams p) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
+  constexpr int RD = NT == 1 ? 3 : 2;                 // ring depth (stages)
+  constexpr int STAGE = NT * 2048 + 1024;             // bytes per stage: W tiles | activation piece
+  constexpr int SOPS = 2 * NT + 1;                    // DMA requests per stage and wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // [8 waves][10 KiB]; reused for the reduction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16 * NT;
+  char* ring = smem + wave * SKR_WAVE_BYTES;
+
+  // DMA sources of this lane: a request moves 8 rows x 128 B, lane -> row lane/8, LDS slot lane%8 <- global chunk slot ^ ((row>>1)&7)
+  const int st_r = lane >> 3, st_c = lane & 7;
+  const lp_t* wsrc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = h * 8 + st_r;
+      wsrc[t][h] = p.W + (int64_t)(n0 + t * 16 + row) * p.K + (st_c ^ ((row >> 1) & 7)) * 8;
+    }
+  const lp_t* asrc;
+  {
+    const int cg = (st_c ^ ((st_r >> 1) & 7)) * 8;
+    const int ar = st_r < p.M ? st_r : p.M - 1;
+    asrc = (NORM && st_r == 7) ? p.norm_w + cg : p.A + (int64_t)ar * p.lda + cg;
+  }
+  // fragment reads: W row fr, chunk (u*4 + g) ^ ((fr>>1)&7); activation row min(fr, M-1) (< 8); norm weights = row 7
+  const int arow = fr < p.M ? fr : p.M - 1;
+  int w_rd[2], a_rd[2], n_rd[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    w_rd[u] = fr * 128 + (((u * 4 + g) ^ ((fr >> 1) & 7)) * 16);
+    a_rd[u] = NT * 2048 + arow * 128 + (((u * 4 + g) ^ ((arow >> 1) & 7)) * 16);
+    n_rd[u] = NT * 2048 + 7 * 128 + (((u * 4 + g) ^ 3) * 16);
+  }
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nd = p.K >> 6;
+  const int n = (nd - wave + SK_WAVES - 1) / SK_WAVES;          // this wave's double steps: ds = wave + 8 i
+  auto issue = [&](int slot, int i) {
+    const int k = (wave + i * SK_WAVES) * 64;
+    char* st = ring + slot * STAGE;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[t][h] + k), (lptr_t)(st + t * 2048 + h * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)(asrc + k), (lptr_t)(st + NT * 2048), 16, 0, 0);
+  };
+  // the first RD stages go out before anything else: neither the weights nor the raw activation rows depend on the statistics
+  // (with the fused norm the last wave's last slot carries the row statistics first and is filled after them: two workgroups
+  // of 80 KiB are all the LDS a CU has)
+  const bool hold_last = NORM && wave == SK_WAVES - 1;
+#pragma unroll
+  for (int j = 0; j < RD; ++j)
+    if (j < n && !(hold_last && j == RD - 1)) issue(j, j);
+  // ---- optional fused RMSNorm: row statistics exactly as gemm_skinny_kernel computes them ----
+  float rstd = 1.f;
+  if (NORM) {
+    float* rs_sh = (float*)(smem + (SK_WAVES - 1) * SKR_WAVE_BYTES + (RD - 1) * STAGE);
+    for (int row = wave; row < p.M; row += SK_WAVES) {
+      const lp_t* xr = p.A + (int64_t)row * p.lda;
+      float sum = 0.f;
+      for (int vi = lane; vi * 8 < p.K; vi += 64) {
+        const lpx8 t = *(const lpx8*)(xr + vi * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = lp2f((lp_t)t[e]);
+          sum += v * v;
+        }
+      }
+      sum = wave_sum(sum);
+      if (lane == 0) rs_sh[row] = rsqrtf(sum / (float)p.K + p.norm_eps);
+    }
+    __syncthreads();
+    rstd = rs_sh[arow];
+    __syncthreads();
+    if (hold_last && RD - 1 < n) issue(RD - 1, RD - 1);
+  }
+  auto normed = [&](lpx8 x, lpx8 w, float rs) {
+    lpx8 y;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[e] = (short)f2lp(lp2f((lp_t)w[e]) * rlp(lp2f((lp_t)x[e]) * rs));
+    return y;
+  };
+
+  auto consume = [&](int slot) {
+    const char* st = ring + slot * STAGE;
+    lpx8 wf[2][NT], a[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wf[u][t] = *(const lpx8*)(st + t * 2048 + w_rd[u]);
+      a[u] = *(const lpx8*)(st + a_rd[u]);
+      if (NORM) a[u] = normed(a[u], *(const lpx8*)(st + n_rd[u]), rstd);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma_16x16x32(wf[u][t], a[u], acc[t]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the slot is re-filled next: its reads must have returned
+  };
+  int i0 = 0;
+  for (; i0 + 2 * RD <= n; i0 += RD) {
+    // stages i0 .. i0+RD-1 are in flight; stage i0 + j has landed once at most the RD - 1 younger stages are outstanding
+#pragma unroll
+    for (int j = 0; j < RD; ++j) {
+      static_assert(SOPS * (RD - 1) == 6 || SOPS * (RD - 1) == 5, "add the literal below");
+      if constexpr (SOPS * (RD - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      consume(j);
+      issue(j, i0 + RD + j);
+    }
+  }
+  // tail: fewer than 2 RD stages left, the first RD of them (those that exist) are in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < RD; ++j)
+    if (i0 + j < n) consume(j);
+#pragma unroll
+  for (int j = 0; j < RD; ++j)
+    if (i0 + RD + j < n) issue(j, i0 + RD + j);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < RD; ++j)
+    if (i0 + RD + j < n) consume(j);
+
+  // ---- cross-wave reduction in gemm_skinny_kernel's order; wave 0 finishes the (single) row tile ----
+  __syncthreads();                                   // every wave is done with its ring
+  float (*red)[64][4] = (float (*)[64][4])smem;       // [SK_WAVES][64][4]
+  f32x4 s[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (t) __syncthreads();
+    *(f32x4*)red[wave][lane] = acc[t];
+    __syncthreads();
+    if (wave == 0) {
+      s[t] = *(const f32x4*)red[0][lane];
+#pragma unroll
+      for (int w = 1; w < SK_WAVES; ++w) s[t] += *(const f32x4*)red[w][lane];
+    }
+  }
+  if (wave != 0) return;
+  const int n_out = (EPI == VSTAR_EPI_SILU_MUL) ? p.N / 2 : p.N;
+  if (fr >= p.M) return;
+  if (EPI == VSTAR_EPI_SILU_MUL) gemm_epilogue_store<EPI, OUT_F32>(p, fr, n0 / 2 + g * 4, n_out, s[0], s[NT - 1]);
+  else gemm_epilogue_store<EPI, OUT_F32>(p, fr, n0 + g * 4, n_out, s[0], s[0]);
+}
+
+template <int EPI, bool OUT_F32>
+hipError_t launch_skinny_ring(const GemmParams& p, hipStream_t s) {
+  constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
+  constexpr int lds = SK_WAVES * SKR_WAVE_BYTES;
+  const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
+  static bool attr_done[2] = {false, false};
+  const int nm = p.norm_w ? 1 : 0;
+  if (!attr_done[nm]) {
+    const void* k = nm ? (const void*)gemm_skinny_ring_kernel<EPI, OUT_F32, true> : (const void*)gemm_skinny_ring_kernel<EPI, OUT_F32, false>;
+    hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done[nm] = true;
+  }
+  if (nm) hipLaunchKernelGGL((gemm_skinny_ring_kernel<EPI, OUT_F32, true>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, p);
+  else hipLaunchKernelGGL((gemm_skinny_ring_kernel<EPI, OUT_F32, false>), dim3(blocks), dim3(SK_WAVES * 64), lds, s, p);
+  return hipGetLastError();
+}
+
 template <int EPI, bool OUT_F32>
 hipError_t launch_skinny(const GemmParams& p, hipStream_t s) {
   constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
   const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
   const int mt = (p.M + 15) / 16;
+  // M <= 8 (decode steps of up to 8 sequences; 7 with the fused norm): the LDS-ring variant, bit-identical (VSTAR_SKINNY_RING=0: the register-streaming kernel, A/B and tests);
+  // the W rows it reads are padded to 256, so whole 16-row tiles exist for every workgroup
+  static const bool ring = [] { const char* e = getenv("VSTAR_SKINNY_RING"); return !e || atoi(e) != 0; }();
+  if (ring && p.M <= (p.norm_w ? 7 : 8) && p.K >= 512 && p.tile_force != -1) return launch_skinny_ring<EPI, OUT_F32>(p, s);   // tile_force -1: tests
   switch (mt) {
     case 1: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 1>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;
     case 2: hipLaunchKernelGGL((gemm_skinny_kernel<EPI, OUT_F32, 2>), dim3(blocks), dim3(SK_WAVES * 64), 0, s, p); break;

@@ -282,7 +282,8 @@ int vstar_vqa_op_gemm(const void* A, const void* W, const void* bias, const void
   p.C = C; p.ldc = n_out; p.M = M; p.N = N; p.K = K;
   p.norm_w = (const lp_t*)norm_w; p.norm_eps = norm_eps;
   hipError_t e;
-  if (kernel == 1 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
+  if (kernel == 3) p.tile_force = -1;      // the register-streaming skinny kernel even where the LDS-ring variant would run
+  if (kernel == 1 || kernel == 3 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
   else e = gemm_lp(p, epilogue, false, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { tls_error() = std::string("vstar_vqa_op_gemm: ") + hipGetErrorString(e); return VSTAR_ERR_HIP; }
