@@ -347,6 +347,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     bool res1 = false;
     if constexpr (EPI == VSTAR_EPI_NONE)
       res1 = p.res != nullptr && !rope_tile && en0 + BN <= n_out && (((uintptr_t)p.res & 7) == 0) && (p.ldr % 4 == 0);
+    constexpr int NIT = 32 / RPI;
+    const bool fast_tile = !rope_tile && em0 + BM <= p.M && en0 + BN <= p.N && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) &&
+                           (p.ldc % 8 == 0) && !p.debug_flags && (p.res == nullptr || res1);
     auto quarter_pass = [&](auto qc) {
       constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
       lpx4 rv[2][NF];
@@ -380,6 +383,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (fast_tile) {
+        // interior tile, identity row map, aligned C, no RoPE: the rolled loop below spends ~100 instructions per row group on
+        // 64-bit addresses, row maps and tail predicates (the epilogue is VALU-bound: 8 us per tile) — here one base pointer per
+        // quarter pass, NIT unrolled {LDS read, activation, 16-byte store (+ the sum of squares of the stored values)}
+        const int64_t row0 = em0 + wr * 128 + qp * 32 + rl0;
+        lp_t* cq = (lp_t*)p.C + row0 * p.ldc + colbase + ch * 8;
+        const int64_t cstep = (int64_t)RPI * p.ldc;
+        lpx8 fv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fv[it] = *(const lpx8*)(slab + (it * RPI + rl0) * RSTRIDE + ch * 16);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          gemm_epilogue_act8<EPI>(fv[it]);
+          if (p.sumsq_out) *(lpx8*)(cq + it * cstep) = fv[it];
+          else __builtin_nontemporal_store(fv[it], (lpx8*)(cq + it * cstep));
+        }
+        if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
+          if (p.sumsq_out) {
+            float* sq = p.sumsq_out + row0 * p.sumsq_ld + colbase / 64;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+              const float ss = gemm_sumsq_span64_chunks(fv[it]);
+              if (ch == 0) sq[(int64_t)it * RPI * p.sumsq_ld] = ss;
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return;
+      }
       if (EPI == VSTAR_EPI_NONE && rope_tile) BAR();
 #pragma unroll 1
       for (int it = 0; it < 32 / RPI; ++it) {

@@ -103,11 +103,9 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 // (or the finished SiLU*up product) -> activation -> + residual -> one 16-byte store.  Whole 128-byte lines per 8 lanes
 // instead of 32-byte fragments.  The transcendental activations live here (static 8-element bodies) so that the
 // accumulator-indexed stage-1 loops stay small enough to unroll (a runtime-indexed acc[] would go to scratch).
-// `res_done`: the caller has already added the residual (gemm256 adds it in the accumulator layout, see there).
+// the activation of 8 packed values after the transpose (QUICK_GELU / GELU / RELU; NONE and SILU_MUL have nothing left to do here)
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8& v,
-                                                         bool res_done = false) {
-  if (col >= n_out) return;
+__device__ __forceinline__ void gemm_epilogue_act8(lpx8& v) {
   if (EPI == VSTAR_EPI_QUICK_GELU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(act_quick_gelu_bf16(lp2f((lp_t)v[e])));
@@ -118,6 +116,14 @@ __device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, in
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(fmaxf(lp2f((lp_t)v[e]), 0.f));
   }
+}
+
+// `res_done`: the caller has already added the residual (gemm256 adds it in the accumulator layout, see there).
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue_store_row8(const GemmParams& p, int64_t crow, int col, int n_out, lpx8& v,
+                                                         bool res_done = false) {
+  if (col >= n_out) return;
+  gemm_epilogue_act8<EPI>(v);
   lp_t* c = (lp_t*)p.C + crow * p.ldc + col;
   const bool full = (col + 7 < n_out) && ((((uintptr_t)c) & 15) == 0);
   if (p.res && !res_done) {
