@@ -345,10 +345,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     // a further quarter of lookahead, or the whole tile's residual requested before the epilogue, measured the same / spilled).
     // Same arithmetic either way: rlp(rlp(acc + bias) + res).
     bool res1 = false;
-    if constexpr (EPI == VSTAR_EPI_NONE)
+    if constexpr (EPI == VSTAR_EPI_NONE && !F8)      // the fp8 kernels already spill: the extra registers cost them 10 % of the step
       res1 = p.res != nullptr && !rope_tile && en0 + BN <= n_out && (((uintptr_t)p.res & 7) == 0) && (p.ldr % 4 == 0);
     constexpr int NIT = 32 / RPI;
-    const bool fast_tile = !rope_tile && em0 + BM <= p.M && en0 + BN <= p.N && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) &&
+    const bool fast_tile = !F8 && !rope_tile && em0 + BM <= p.M && en0 + BN <= p.N && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) &&
                            (p.ldc % 8 == 0) && !p.debug_flags && (p.res == nullptr || res1);
     auto quarter_pass = [&](auto qc) {
       constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
