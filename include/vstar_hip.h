@@ -274,6 +274,12 @@ int vstar_op_rms_rstd(void* stream, const uint16_t* dev_x, const float* dev_part
  * rounds of 256x256 tiles over the leading rows and the ragged last round's rows as 128x128 tiles — bit-identical to either
  * kernel alone), or 0 (nothing launched).  Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */
 int vstar_op_gemm_last_tile(void);
+/* Dispatcher dry run (host only, no GPU needed, nothing is launched): which kernel vstar_op_gemm / the engine would pick for
+ * C[M,N] = A[M,K] · W^T with this epilogue (+ residual, + the fused-RoPE epilogue of the LLaMA qkv projection) on a device with
+ * `cus` compute units.  Returns 10 * tile + variant: tile as vstar_op_gemm_last_tile (128, 256, 384 = split launch, 2560 = the
+ * opt-in hand-scheduled kernel), variant of the 128-row family 2 = double buffer, 5 / 6 / 7 = loader-wave ring on the 128 x 128 /
+ * 128 x 64 / 128 x 256 tile (0 for the 256^2 kernel; for 384 the variant of the trailing 128-row part); negative = error code. */
+int vstar_op_gemm_plan(int M, int N, int K, int epilogue, int has_residual, int fused_rope, int cus);
 /* W8A8 GEMM (BASELINE config 5: fp8 weights on the CDNA4 fp8 MFMA), op level, all pointers DEVICE pointers: quantises the
  * rows of A [M,K] (per token) and of W [ceil(N/256)*256, K] (per output channel) to OCP fp8 e4m3 with scale = absmax/448,
  * then C[M,N] = epilogue((A_q . W_q^T) * a_scale[m] * w_scale[n] + bias) (+ residual) with fp32 accumulation on

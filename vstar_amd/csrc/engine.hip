@@ -1263,6 +1263,24 @@ int vstar_op_rms_rstd(void* stream, const uint16_t* x, const float* partials, in
   return op_rc(e);
 }
 int vstar_op_gemm_last_tile(void) { return gemm_last_tile(); }
+int vstar_op_gemm_plan(int M, int N, int K, int epilogue, int has_residual, int fused_rope, int cus) {
+  if (M <= 0 || N <= 0 || K <= 0 || cus <= 0) { tls_error() = "vstar_op_gemm_plan: bad argument"; return VSTAR_ERR_INVALID; }
+  // nothing is dereferenced in a dry run: the pointers only have to look aligned and non-null
+  static const uintptr_t fake = 0x10000;
+  GemmParams p{};
+  p.A = (const lp_t*)fake; p.lda = K; p.W = (const lp_t*)fake; p.C = (void*)fake;
+  p.M = M; p.N = N; p.K = K;
+  const int n_out = (epilogue & 0xff) == VSTAR_EPI_SILU_MUL ? N / 2 : N;
+  p.ldc = n_out;
+  if (has_residual) { p.res = (const lp_t*)fake; p.ldr = n_out; }
+  if (fused_rope) { p.rope_cs = (const lp_t*)fake; p.rope_S = 640; p.rope_cols = N * 2 / 3; }
+  p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
+  gemm_set_plan(true, cus);
+  const hipError_t e = gemm_lp(p, epilogue & 0xff, false, nullptr);
+  gemm_set_plan(false, 0);
+  if (e != hipSuccess) { tls_error() = std::string("vstar_op_gemm_plan: ") + hipGetErrorString(e); return VSTAR_ERR_INVALID; }
+  return gemm_last_tile() * 10 + gemm_last_mode();
+}
 int vstar_op_layernorm(void* stream, const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y, int rows,
                        int cols, float eps) {
   hipError_t e = layernorm_lp(x, g, b, y, rows, cols, eps, nullptr, 0, (hipStream_t)stream);

@@ -22,6 +22,13 @@
 
 namespace VS_NS {
 
+static thread_local bool t_plan_only = false;
+static thread_local int t_plan_cus = 0;
+static thread_local int t_last_mode = 0;
+void gemm_set_plan(bool on, int cus) { t_plan_only = on; t_plan_cus = on ? cus : 0; }
+bool gemm_plan_only() { return t_plan_only; }
+int gemm_last_mode() { return t_last_mode; }
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -281,6 +288,8 @@ namespace {
 
 template <int EPI, bool OUT_F32, int MODE, int NW = 2>
 hipError_t launch_stages(const GemmParams& p, hipStream_t s) {
+  t_last_mode = MODE == 5 ? (NW == 4 ? 7 : (NW == 1 ? 6 : 5)) : MODE;
+  if (t_plan_only) return hipSuccess;
   static bool attr_done = false;
   auto kern = gemm128_kernel<EPI, OUT_F32, MODE, NW>;
   constexpr int bn = 64 * NW;
@@ -338,6 +347,7 @@ static thread_local int t_last_tile = 0;
 int gemm_last_tile() { return t_last_tile; }
 
 int gemm_device_cus() {
+  if (t_plan_only && t_plan_cus > 0) return t_plan_cus;
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0;
@@ -351,6 +361,7 @@ int gemm_device_cus() {
 
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
   t_last_tile = 0;
+  t_last_mode = 0;
   if (p.M <= 0 || p.N <= 0) return hipSuccess;
   if (p.K % BK != 0 || p.K <= 0 || p.norm_w) return hipErrorInvalidValue;   // fused RMSNorm: skinny kernel only
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;

@@ -456,6 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
 template <int EPI, bool OUT_F32, bool F8 = false>
 hipError_t launch(const GemmParams& p, hipStream_t s) {
+  if (gemm_plan_only()) return hipSuccess;
   static bool attr_done = false;
   auto kern = gemm256_kernel<EPI, OUT_F32, F8>;
   if (!attr_done) {

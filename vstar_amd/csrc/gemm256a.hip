@@ -149,6 +149,7 @@ bool gemm256a_eligible(const GemmParams& p, int epilogue, bool out_f32) {
 }
 
 hipError_t gemm256a_lp(const GemmParams& p, hipStream_t s) {
+  if (gemm_plan_only()) return hipSuccess;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm256a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);

@@ -51,6 +51,14 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
 int gemm_last_tile();
 // compute units of the current device, rounded down to a multiple of 8 (>= 8); cached per process
 int gemm_device_cus();
+// Dispatcher dry run (vstar_op_gemm_plan: host-only tests of the kernel choice).  While `on`, gemm_lp takes every decision as
+// usual — with `cus` compute units instead of the device's — but launches nothing; gemm_last_tile() / gemm_last_mode() then
+// tell what it would have launched.  Thread-local, like gemm_last_tile().
+void gemm_set_plan(bool on, int cus);
+bool gemm_plan_only();
+// 128-family variant of the last gemm_lp call of this thread: 2 = double buffer, 5 / 6 / 7 = loader-wave ring on the 128 x 128 /
+// 128 x 64 / 128 x 256 tile; 0 when the last call did not reach that family
+int gemm_last_mode();
 bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 kernel (the only one that honours rope_cs)
 
 // decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp
