@@ -145,7 +145,7 @@ def tile(buf, next_reads=True, next_dma=True):
     return out
 
 
-def main():
+def main(out_path=None):
     # ablation switches (tools/build_variant.sh): G256A_NO_DMA=1 drops the loop's DMA, G256A_NO_READS=1 its fragment reads
     no_dma, no_reads = os.environ.get("G256A_NO_DMA") == "1", os.environ.get("G256A_NO_READS") == "1"
     L = []
@@ -188,13 +188,17 @@ def main():
     body = "".join('  "%s\\n\\t"\n' % x for x in L if not x.startswith(";"))
     clob = ", ".join(f'"v{i}"' for i in range(158)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vstar_amd", "csrc", "gemm256a_loop.inc")
+    if out_path:
+        path = out_path
     with open(path, "w") as f:
         f.write("// GENERATED by tools/gen_gemm256a_asm.py — do not edit.  The hand-scheduled K loop of gemm256a.hip.\n")
         f.write("#define GEMM256A_LOOP_ASM \\\n" + body.replace("\n", " \\\n").rstrip(" \\\n") + "\n\n")
         f.write("#define GEMM256A_CLOBBERS " + clob + ', "memory", "scc"\n')
     n_mfma = sum("v_mfma" in x for x in L)
     print(path, len(L), "instructions,", n_mfma, "MFMAs in the text")
+    return L
 
 
 if __name__ == "__main__":
-    main()
+    import sys
+    main(sys.argv[1] if len(sys.argv) > 1 else None)
