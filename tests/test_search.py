@@ -448,3 +448,51 @@ def test_stream_speculates_for_a_lone_search_but_not_in_a_full_window():
     search.visual_search_stream(v6, samples, window=6, stats=st6, **kw)
     assert st6["wasted_crop_frac"] == 0.0                    # six live searches: only crops the order visits
     assert st6["useful_crops"] == st6["crops_scored"]
+
+
+@pytest.mark.parametrize("prefetch", [0, 1, 3])
+def test_stream_prefetches_image_loaders_without_changing_anything(prefetch):
+    """Lazy loaders (what visual_search.py / vstar_bench_eval.py hand over: open + decode a file) run ahead of the window on a worker
+    thread when prefetch > 0: each exactly once, results and upload order identical to loading on entry."""
+    import threading
+    base = _stream_samples(n_images=6, per_image=(1, 2))
+    calls, threads = [], set()
+
+    class Loader:
+        def __init__(self, k, img):
+            self.key, self.img = ("file", k), img
+
+        def __call__(self):
+            calls.append(self.key)
+            threads.add(threading.current_thread().name)
+            return self.img
+
+    by_img, samples = {}, []
+    for img, name, gt, sm in base:
+        ld = by_img.setdefault(id(img), Loader(len(by_img), img))
+        samples.append((ld, name, gt, sm))
+    kw = dict(confidence_high=0.9, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    want = search.visual_search_stream(_SlotVSM(max_batch=8), base, window=3, **kw)
+    vsm = _SlotVSM(max_batch=8)
+    vsm.max_image_slots = 3
+    got = search.visual_search_stream(vsm, samples, window=3, prefetch=prefetch, **kw)
+    for a, b in zip(want, got):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+    assert sorted(calls) == sorted(ld.key for ld in by_img.values())          # every file opened once
+    if prefetch:
+        assert any(t.startswith("vstar-image-prefetch") for t in threads)      # ... and not all of them on the search thread
+    else:
+        assert threads == {threading.current_thread().name}
+
+
+def test_stream_prefetch_propagates_loader_errors():
+    base = _stream_samples(n_images=3, per_image=(1,))
+
+    def broken():
+        raise OSError("cannot identify image file")
+
+    samples = [(lambda img=img: img, n, gt, sm) for img, n, gt, sm in base]
+    samples[2] = (broken, "thing", None, 64)
+    kw = dict(confidence_high=0.9, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    with pytest.raises(OSError):
+        search.visual_search_stream(_SlotVSM(max_batch=8), samples, window=1, prefetch=2, **kw)

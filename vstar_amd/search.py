@@ -558,8 +558,18 @@ class SpeculationPolicy:
         return chosen
 
 
+def _run_loader(loader):
+    """A sample's image loader on the prefetch thread: the file is opened AND decoded there (PIL opens lazily; the decode of a 4K JPEG
+    is ~60 ms that the search thread would otherwise spend between two engine steps)."""
+    image = loader()
+    load = getattr(image, "load", None)
+    if callable(load):
+        load()
+    return image
+
+
 def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: Optional[SpeculationPolicy] = None,
-                         stats: Optional[dict] = None, **kw):
+                         stats: Optional[dict] = None, prefetch: int = 2, **kw):
     """Cross-image lock-step search: `samples` = iterable of (image, target_object_name, target_bbox, smallest_size) — `image` a
     PIL image or a zero-argument loader returning one (called when the sample enters the window; loaders with the same `.key`, or
     the same loader object, share an image slot; `smallest_size` may then be a callable of the loaded image); returns the
@@ -573,6 +583,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     full of crops the reference's order really visits.  Images are uploaded once per sample window (samples that share an image
     object share its slot).  Per (image, target) the decisions are exactly those of `visual_search`: with batch-invariant records
     (plain batches, or group_prompts = "always") the results are bit-identical to the per-sample loop.
+
+    prefetch: how many of the upcoming samples' image loaders run ahead of the window on a worker thread (host work only — open +
+    decode; the upload stays on the calling thread, in sample order) while the engine is busy; 0 = load when the sample enters.
+    Every loader is still called exactly once and nothing about the results depends on it.
 
     stats (optional dict) receives: searches, crops_scored (engine records), useful_crops (nodes the best-first order visited),
     wasted_crop_frac, engine_steps, per_search = [{crops_scored, path_visited, ...}]."""
@@ -612,6 +626,24 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     engine_steps = 0
 
     loaded: Dict[object, object] = {}             # slot key -> the PIL image living in that slot
+    pending: Dict[object, object] = {}            # slot key -> Future of a loader running ahead (prefetch)
+    pool = None
+    if prefetch > 0 and any(callable(smp[0]) for smp in samples):
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vstar-image-prefetch")
+
+    def prefetch_ahead():
+        # loaders of the next samples that are not in the window yet, in sample order, at most `prefetch` in flight or waiting
+        if pool is None:
+            return
+        i = next_sample
+        while i < n and len(pending) < prefetch:
+            image = samples[i][0]
+            if callable(image):
+                key = getattr(image, "key", id(image))
+                if key not in slot_of and key not in pending:
+                    pending[key] = pool.submit(_run_loader, image)
+            i += 1
 
     def start(i):
         image, name, gt, smallest = samples[i]
@@ -619,7 +651,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         if key not in slot_of:
             if not free_slots:
                 return False
-            loaded[key] = image() if callable(image) else image
+            if key in pending:
+                loaded[key] = pending.pop(key).result()
+            else:
+                loaded[key] = image() if callable(image) else image
             slot_of[key] = free_slots.pop()
             slot_refs[slot_of[key]] = 0
             vsm.set_image(loaded[key]) if slot_of[key] == 0 else vsm.set_image(loaded[key], slot_of[key])
@@ -667,6 +702,7 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
             if not start(next_sample):
                 break                               # every image slot is in use: wait for a search to end
             next_sample += 1
+        prefetch_ahead()
 
     def drain_stats():
         nonlocal want_stats
@@ -744,6 +780,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
             vsm.group_prompts = grouping
         for g in list(gens.values()):
             g.close()
+        if pool is not None:
+            for f in pending.values():
+                f.cancel()
+            pool.shutdown(wait=True)
     _fill_stream_stats(stats, per_stats, engine_steps)
     return results
 
