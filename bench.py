@@ -304,7 +304,6 @@ def fake_engine_run(args, world, rank, dist):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
     B = args.batch
     rec = torch.full((B, _lib.RESULT_FLOATS), float(rank), dtype=torch.float32)
 
@@ -386,9 +385,14 @@ def main():
             args.batch = 64
         if args.search_targets == 16:
             args.search_targets = 2            # 2 x 341 = 682 crops
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return _self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks "
+                         f"(use --nproc-per-node {args.gpus}, or run plain `python bench.py --gpus {args.gpus}`)")
     import torch.distributed as dist
     if args.fake_engine:
         return fake_engine_run(args, world, rank, dist)
@@ -401,7 +405,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus or world == 1 and args.gpus == 1, (world, args.gpus)
 
     B, T = args.batch, args.text_tokens
     L = T + 1
@@ -597,6 +600,24 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         _print_last(json.dumps(line))
+
+
+def _self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves — the same
+    `torch.distributed.run --nnodes=1 --nproc-per-node N` command the driver uses, rendezvous on 127.0.0.1 and a free port — and
+    pass its exit code on.  The children inherit stdout, so rank 0's JSON line is still the last line (every rank flushes its C
+    stdio and passes a barrier before rank 0 prints)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def _print_last(text: str) -> None:

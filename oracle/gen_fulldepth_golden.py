@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_shim  # noqa: E402
 from vstar_amd.config import VSMConfig  # noqa: E402
 from vstar_amd.synthetic import bench_inputs  # noqa: E402
-from vstar_amd.weights import random_state_dict  # noqa: E402
+from vstar_amd.weights import random_state_dict, template_chain, trained_like_state_dict  # noqa: E402
 
 GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 CROPS = (0, 4, 9, 13, 17, 22, 26, 31)          # indices into the bench batch (0 and 17 were the round-2 pair)
@@ -103,16 +103,28 @@ def main():
     ap.add_argument("--image-size", type=int, default=336, choices=(224, 336))
     ap.add_argument("--crops", type=str, default=None)
     ap.add_argument("--threads", type=int, default=len(os.sched_getaffinity(0)))
+    ap.add_argument("--weights", choices=("random", "trained_like"), default="random",
+                    help="trained_like (round 4, VERDICT r3 missing #2): vstar_amd.weights.trained_like_state_dict — outlier residual "
+                         "channels, a massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the "
+                         "answer template for SyntheticTokenizer prompts; written to full7b_tl_{336,224}.npz")
     a = ap.parse_args()
-    crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else CROPS
-    out_path = os.path.join(GOLDEN, f"full7b_{a.image_size}.npz")
+    tl = a.weights == "trained_like"
+    crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else ((0, 9, 17, 31) if tl else CROPS)
+    out_path = os.path.join(GOLDEN, f"full7b_{'tl_' if tl else ''}{a.image_size}.npz")
     assert ref_shim.available(), "reference tree not found"
     torch.set_num_threads(a.threads)
     cfg = VSMConfig.seal_7b(a.image_size, max_batch=B, max_text_len=T + 1)
     loc_id = cfg.llm_vocab - 1
     clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
     t0 = time.time()
-    sd = {k: v.float() for k, v in random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True).items()}
+    if tl:
+        from vstar_amd.preprocess import SyntheticTokenizer
+        sd16 = trained_like_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True,
+                                       chain=template_chain(SyntheticTokenizer(cfg.llm_vocab)))
+    else:
+        sd16 = random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True)
+    sd = {k: v.float() for k, v in sd16.items()}
+    del sd16
     model = build_reference(cfg, loc_id, sd)
     del sd
     print(f"reference built + loaded in {time.time() - t0:.0f}s", flush=True)
@@ -122,6 +134,7 @@ def main():
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))  # noqa: E731
     print("reference-bf16 vs reference-fp32 rel-L2:", {k: "%.2e" % rel(b16[k], f32[k]) for k in f32 if k.startswith(("pred", "low", "llm", "embed", "sam"))})
     np.savez_compressed(out_path, crops=np.asarray(crops), batch=B, text_tokens=T, weight_seed=0, image_size=a.image_size,
+                        weights=a.weights,
                         **{k: v for k, v in f32.items()}, **{"bf16_" + k: v for k, v in b16.items()})
     print("->", out_path, os.path.getsize(out_path) // 1024, "KiB")
 

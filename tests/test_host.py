@@ -228,6 +228,28 @@ def test_bench_multiprocess_launch_path_on_cpu():
     assert d["search_stream"]["per_rank_crops_per_step"] <= d["search_stream"]["mean_crops_per_step"] / 2 + 1e-9
 
 
+def test_bench_plain_launch_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT a launcher (the form of the driver's N = 1 command) used to die
+    on an assertion.  It must start its own two ranks (torch.distributed.run on 127.0.0.1) and still print ONE JSON line, last on
+    stdout, with n_gpus = 2; a launcher whose world size contradicts --gpus is refused with a message, not an AssertionError."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--fake-engine"],
+                         capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    nonempty = [l for l in out.stdout.splitlines() if l.strip()]
+    assert nonempty[-1].startswith("{") and sum(l.startswith("{") for l in nonempty) == 1, out.stdout[-2000:]
+    d = json.loads(nonempty[-1])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["search_stream"]["ranks"] == 2 and d["search_stream_shard_samples"]["ranks"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--fake-engine"], capture_output=True, text=True,
+                         timeout=120, cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "--gpus 4" in bad.stderr and "AssertionError" not in bad.stderr
+
+
 def _make_bench_folder(root):
     """A miniature V*Bench tree (two splits, image + JSON annotation with bbox / target_object lists, vstar_bench layout)."""
     import json

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import math
 import os
+import zlib
 from collections import OrderedDict
 from typing import Dict, Iterable, Tuple
 
@@ -232,6 +233,114 @@ def random_state_dict(cfg, seed: int = 0, dtype: torch.dtype = torch.bfloat16,
             t = torch.randn(shp, generator=g) / math.sqrt(fan_in)
         out[k] = t.to(dtype)
     return out
+
+
+def template_chain(tokenizer, question: str = "Please locate the object in this image.", conv_type: str = "llava_v1",
+                   use_mm_start_end: bool = True):
+    """(token, next_token) pairs that make greedy decoding continue a locate prompt with "Sure, [LOC]." and then EOS:
+    the last prompt token -> "Sure" -> "," -> "[LOC]" -> "." -> </s> for `tokenizer`'s ids (input of trained_like_state_dict)."""
+    from .preprocess import ANSWER_TEMPLATE, build_prompt, tokenizer_image_token
+    ids_p = tokenizer_image_token(build_prompt(question, use_mm_start_end, conv_type=conv_type), tokenizer)
+    ids_f = tokenizer_image_token(build_prompt(question, use_mm_start_end, answer=ANSWER_TEMPLATE, conv_type=conv_type), tokenizer)
+    if ids_f[:len(ids_p)] != ids_p:
+        ids_f = ids_p + list(tokenizer(" " + ANSWER_TEMPLATE, add_special_tokens=False).input_ids)
+    ids_f = list(ids_f) + [int(getattr(tokenizer, "eos_token_id", 2))]
+    chain = [(int(ids_f[c - 1]), int(ids_f[c])) for c in range(len(ids_p), len(ids_f))]
+    assert len({t for t, _ in chain}) == len(chain), "the answer template repeats a token: a bigram chain cannot encode it"
+    return chain
+
+
+def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16, share_layers: bool = True,
+                            chain=None) -> Dict[str, torch.Tensor]:
+    """Seeded weights with the STATISTICS of a trained checkpoint rather than i.i.d. N(0, s) (VERDICT r3 "missing" #2): the
+    structures that decide where bf16 / fp8 rounding bites in a real LLaMA-7B / CLIP-L, which random_state_dict lacks.
+
+      * outlier residual channels: a handful of output rows of every o_proj / down_proj (and out_proj / fc2 of the ViTs) are
+        6 - 40 x stronger (25 x in the ViTs), so those channels of the residual stream run at tens to hundreds of times the rms of the rest;
+      * a massive-activation token: BOS carries +-60 (120 x the embedding rms) in two of those channels (attention sink);
+      * norm gains with a per-channel spread (log-normal around 0.4) and SMALL gains on the outlier channels, as trained
+        LLaMA / CLIP norms have; LayerNorm biases of the ViTs with a heavier spread;
+      * correlated q / k projections (k = 0.7 q + noise, q scaled x 3): attention is peaked instead of near-uniform;
+      * `chain` [(token, next)]: the embeddings of the chain tokens are 8 x stronger (delimiter-like tokens) and lm_head rows
+        are aligned with their predecessors' embeddings, so that greedy decoding emits the chain — with the pairs of
+        `template_chain(tokenizer)` the model answers "Sure, [LOC]." like the trained VSM does and the DEFAULT
+        strict_template=True path of VSM.inference runs at real widths.  The transformer layers stay
+        non-trivial (unlike the zeroed-o/down bigram model of tests/test_template_fallback_gpu.py).
+
+    Derived from random_state_dict(seed) tensor by tensor, so the key set / shapes / reproducibility rules are the same."""
+    sd = random_state_dict(cfg, seed=seed, dtype=torch.float32, share_layers=share_layers)
+    g = torch.Generator().manual_seed(seed * 7919 + 17)
+    done = set()
+
+    def once(key):
+        t = sd[key]
+        if id(t) in done:
+            return None
+        done.add(id(t))
+        return t
+
+    def outliers(hidden, n, lo, hi):
+        ch = torch.randperm(hidden, generator=g)[:n]
+        amp = torch.logspace(math.log10(lo), math.log10(hi), n)
+        return ch, amp
+
+    def spread_gain(key, ch, centre, sigma, small):
+        t = once(key)
+        if t is not None:
+            gk = torch.Generator().manual_seed(seed * 31 + (zlib.crc32(key.encode()) & 0xFFFFF))
+            t.copy_(centre * torch.exp(sigma * torch.randn(t.shape, generator=gk)))
+            t[ch] = small
+
+    # ---- LLaMA ----
+    H = cfg.llm_hidden
+    ch, amp = outliers(H, max(2, H // 683), 6.0, 40.0)
+    for i in range(cfg.llm_layers):
+        lp = f"model.layers.{i}."
+        for nm in ("self_attn.o_proj.weight", "mlp.down_proj.weight"):
+            t = once(lp + nm)
+            if t is not None:
+                t[ch] *= amp[:, None]
+        q, k = once(lp + "self_attn.q_proj.weight"), once(lp + "self_attn.k_proj.weight")
+        if q is not None and k is not None:
+            k.copy_(0.7 * q + math.sqrt(1 - 0.49) * k)
+            q *= 3.0
+        spread_gain(lp + "input_layernorm.weight", ch, 0.4, 0.5, 0.05)
+        spread_gain(lp + "post_attention_layernorm.weight", ch, 0.4, 0.5, 0.05)
+    spread_gain("model.norm.weight", ch, 1.0, 0.3, 0.05)
+    E = sd["model.embed_tokens.weight"]
+    E[1, ch[:2]] = torch.tensor([60.0, -60.0])[: len(ch[:2])]
+    if chain:
+        W = sd["lm_head.weight"]
+        for t, _ in chain:
+            E[t] *= 8.0
+            E[t, ch] = 0.0
+        for t, nxt in chain:
+            W[nxt] += 6.0 * E[t] / E[t].norm()
+    # ---- ViT towers ----
+    for prefix, pre, hidden, layers in ((CLIP_PREFIX + "vision_model.", "pre_layrnorm", cfg.clip_hidden, cfg.clip_layers),
+                                        ("model.owlvit.vision_model.", "pre_layernorm", cfg.owl_hidden, cfg.owl_layers)):
+        vch, vamp = outliers(hidden, max(2, hidden // 256), 8.0, 25.0)
+        spread_gain(prefix + pre + ".weight", vch, 1.0, 0.4, 0.3)
+        for i in range(layers):
+            lp = f"{prefix}encoder.layers.{i}."
+            for nm in ("self_attn.out_proj", "mlp.fc2"):
+                t = once(lp + nm + ".weight")
+                if t is not None:
+                    t[vch] *= vamp[:, None]
+                    sd[lp + nm + ".bias"][vch] = 1.5 * torch.sign(torch.randn(len(vch), generator=g))
+            q, k = once(lp + "self_attn.q_proj.weight"), once(lp + "self_attn.k_proj.weight")
+            if q is not None and k is not None:
+                k.copy_(0.7 * q + math.sqrt(1 - 0.49) * k)
+                q *= 2.0
+            for nm in ("layer_norm1", "layer_norm2"):
+                spread_gain(lp + nm + ".weight", vch, 0.7, 0.4, 0.1)
+                b = once(lp + nm + ".bias")
+                if b is not None:
+                    b *= 5.0
+    if dtype == torch.float32:
+        return sd
+    conv: Dict[int, torch.Tensor] = {}          # keep share_layers' aliasing: one converted tensor per distinct host tensor
+    return {k: conv.setdefault(id(v), v.to(dtype)) for k, v in sd.items()}
 
 
 def dense_pe(gaussian: torch.Tensor, grid: int = 48) -> torch.Tensor:
