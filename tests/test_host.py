@@ -449,6 +449,30 @@ def test_grouped_scoring_bookkeeping_returns_records_in_the_callers_order(mode):
         assert sum(eng.plain_calls) == 3
 
 
+def test_grouped_always_batches_crops_with_different_single_prompts_into_one_call():
+    """visual_search_stream switches a grouping VSM to group_prompts = "always"; a window of searches for
+    DIFFERENT objects on different crops must then still share engine calls (crops are bucketed by their number of prompts, the
+    suffix ids are per crop) — round 3 made one call per distinct prompt."""
+    from vstar_amd.vsm import VSM
+    eng = _GroupedFakeEngine(max_batch=4)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        vsm = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(eng.cfg.llm_vocab), strict_template=False)
+        vsm.set_image(synthetic_image(400, 300, 1))
+        vsm.group_prompts = "always"
+        names = ["kite", "red umbrella", "dog", "boat", "traffic light", "cup"]
+        boxes = [[10 * k, 5 * k, 100 + k, 80 + k] for k in range(6)]
+        out = vsm.inference_boxes(boxes, [pp.LOCATE_QUESTION.format(n) for n in names], mode="detection", upsample=False)
+    # two calls (the activation-row budget of this tiny configuration admits 3 one-prompt crops per call), not six
+    assert eng.grouped_calls == [(3, 1), (3, 1)] and eng.plain_calls == []
+    assert vsm.timers["engine_calls"] == 2 and vsm.timers["crops"] == 6
+    for k, o in enumerate(out):
+        x, y, w, h = boxes[k]
+        want = _GroupedFakeEngine._rec([x, y, x + w, y + h], vsm._ids(pp.LOCATE_QUESTION.format(names[k]))[0])
+        from vstar_amd.engine import VstarEngine
+        assert np.array_equal(o[0].numpy().ravel(), VstarEngine.unpack(want[None], 0)["pred_boxes"].ravel())
+
+
 def test_calibrate_step_ms_feeds_the_speculation_policy():
     """VSM.calibrate_step_ms measures t(B) on the engine at hand (here the CPU stand-in) and visual_search_stream's default policy
     picks the table up (`step_ms_table`)."""

@@ -298,6 +298,34 @@ def test_heatmap_stats_survives_image_regrow(vsm):
         assert np.array_equal(clip_gpu[0], ref)                           # the resident image was not overwritten
 
 
+def test_stream_with_default_vsm_settings_batches_across_targets(vsm):
+    """the SHIPPED default (group_prompts = True; visual_search.py / vstar_bench_eval.py never change it) under
+    visual_search_stream: searches for different objects on different images share engine calls (one call per scoring round while
+    the round fits the batch), and every result is bit-identical to the per-sample loop run through the same (grouped) entry
+    point."""
+    from vstar_amd.search import visual_search_stream
+    sizes = [(1280, 720), (900, 1100), (1500, 640)]
+    imgs = [synthetic_image(w, h, 80 + k) for k, (w, h) in enumerate(sizes)]
+    names = ["kite", "dog", "small red umbrella", "boat", "traffic light", "cup"]
+    samples = [(imgs[k % 3], n, None, smallest_size_for(*sizes[k % 3])) for k, n in enumerate(names)]
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    assert vsm.group_prompts is True
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = {}
+        got = visual_search_stream(vsm, samples, window=6, stats=st, **kw)
+        vsm.group_prompts = "always"
+        try:
+            loop = [visual_search(vsm, im, n, gt, sm, speculate=False, **kw) for im, n, gt, sm in samples]
+        finally:
+            vsm.group_prompts = True
+    for x, y in zip(loop, got):
+        assert x[1] == y[1] and x[2] == y[2] and x[0]["bbox"] == y[0]["bbox"]
+        assert torch.equal(x[0]["detection_result"], y[0]["detection_result"])
+    assert st["engine_calls"] == st["engine_steps"] < st["useful_crops"]       # no per-prompt fragmentation
+    assert st["crops_scored"] / st["engine_calls"] > 3.0
+
+
 def test_search_with_device_reductions_equals_host_path(vsm):
     img = synthetic_image(1280, 720, 33)
     smallest = smallest_size_for(1280, 720)

@@ -718,7 +718,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
 
     grouping = getattr(vsm, "group_prompts", False)
     if grouping:
-        vsm.group_prompts = "always"              # a (crop, prompt) record must not depend on its batch companions
+        # a (crop, prompt) record must not depend on its batch companions.  Crops are batched by their NUMBER of prompts
+        # (VSM._score_boxes_grouped), so a window of searches for different objects on different images is still one engine call
+        vsm.group_prompts = "always"
+    calls0 = int(getattr(vsm, "timers", {}).get("engine_calls", 0)) if isinstance(getattr(vsm, "timers", None), dict) else None
     dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
     try:
         refill()
@@ -785,6 +788,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
                 f.cancel()
             pool.shutdown(wait=True)
     _fill_stream_stats(stats, per_stats, engine_steps)
+    if stats is not None and calls0 is not None:
+        # launches of an engine scoring entry point (a step can take several: batch cap, prompt-count buckets); engine_steps counts
+        # the driver's scoring rounds
+        stats["engine_calls"] = int(vsm.timers.get("engine_calls", 0)) - calls0
     return results
 
 

@@ -100,7 +100,7 @@ class VSM:
         self.strict_template = real if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
         self.fallback_log: List[dict] = []      # one entry per stepwise-decode fallback (diagnostics / tests)
-        self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0}
+        self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0, "engine_calls": 0}
 
     # ---- cost model of a scoring step (vstar_amd.search.SpeculationPolicy) ----
     step_ms_table = None    # {crops per rank: ms}; None = the policy's built-in MI355X measurements
@@ -166,6 +166,7 @@ class VSM:
                 local[s0:s0 + len(sel)] = score_chunk(sel, None)
             self.timers["engine_s"] += time.perf_counter() - t1
             self.timers["crops"] += len(sel)
+            self.timers["engine_calls"] = self.timers.get("engine_calls", 0) + 1
         t2 = time.perf_counter()
         if on_device and getattr(self.engine, "comm_world", 0) == world and getattr(self, "use_engine_comm", True):
             # the C-ABI's own collective (vstar_allgather_results: ncclAllGather on the engine's stream, queued behind the kernels
@@ -389,41 +390,43 @@ class VSM:
                 by_box.setdefault(b, {}).setdefault(q, []).append(i)
             else:
                 single.append(i)
-        by_tuple: dict = {}
+        # crops are batched by HOW MANY prompts they carry, not by which ones: the suffix ids are per (crop, prompt), so crops of
+        # different images with different targets share one call.  (Round 3 grouped by the exact prompt tuple: a window of 32
+        # searches for 32 different objects became 32 one-crop calls — ADVICE r3.)
+        by_T: dict = {}
         for b, d in by_box.items():
-            by_tuple.setdefault(tuple(d), []).append(b)
-        if not always and all(len(t) < 2 for t in by_tuple):
+            by_T.setdefault(len(d), []).append(b)
+        if not always and all(T < 2 for T in by_T):
             return None
         records = np.zeros((len(qs), RESULT_FLOATS), np.float32)
         prefix = np.asarray(tpl, np.int32)
         mb = self.cfg.max_batch
         rows_cap = mb * (self.cfg.max_text_len - 1 + P)             # activation rows the engine holds
         R0 = (Lc + 127) // 128 * 128
-        for qt, boxes in by_tuple.items():
-            T = len(qt)
+        for T, boxes in by_T.items():
             if (T < 2 and not always) or T > mb or R0 + 32 * T > rows_cap:
-                single += [i for b in boxes for q in qt for i in by_box[b][q]]
+                single += [i for b in boxes for q in by_box[b] for i in by_box[b][q]]
                 continue
             per_call = max(1, min(mb // T, rows_cap // (R0 + 32 * T)))
-            suf = np.asarray([info[q][0] for q in qt], np.int32)
-            loc_in = np.asarray([info[q][1] for q in qt], np.int32)
-            ver_in = np.asarray([info[q][2] for q in qt], np.int32).reshape(T, nv)
             for c0 in range(0, len(boxes), per_call):
                 chunk = boxes[c0:c0 + per_call]
                 G = len(chunk)
+                suf = np.asarray([[info[q][0] for q in by_box[b]] for b in chunk], np.int32).reshape(G, T, Ls)
+                loc_in = np.asarray([[info[q][1] for q in by_box[b]] for b in chunk], np.int32).reshape(G, T)
+                ver_in = np.asarray([[info[q][2] for q in by_box[b]] for b in chunk], np.int32).reshape(G, T, nv)
                 t1 = time.perf_counter()
                 _lib_boxes = np.asarray([c[:4] for c in chunk], np.int32)
                 if slot_arr is None:
                     self.engine.preprocess_boxes(_lib_boxes)
                 else:
                     self.engine.preprocess_boxes(_lib_boxes, np.asarray([c[4] for c in chunk], np.int32))
-                rec = self.engine.score_grouped(None, None, prefix, np.tile(suf[None], (G, 1, 1)), np.tile(loc_in[None], (G, 1)),
-                                                np.tile(ver_in[None], (G, 1, 1)) if nv else None, raw=True, internal_pixels=True)
+                rec = self.engine.score_grouped(None, None, prefix, suf, loc_in, ver_in if nv else None, raw=True, internal_pixels=True)
                 self.timers["engine_s"] += time.perf_counter() - t1
                 self.timers["crops"] += G * T
+                self.timers["engine_calls"] = self.timers.get("engine_calls", 0) + 1
                 self.timers["grouped_records"] = self.timers.get("grouped_records", 0) + G * T
                 for gi, b in enumerate(chunk):
-                    for t, q in enumerate(qt):
+                    for t, q in enumerate(by_box[b]):
                         for i in by_box[b][q]:
                             records[i] = rec[gi * T + t]
         if single:
@@ -442,6 +445,7 @@ class VSM:
                                                        verify_pos=np.asarray([per_q[qs[i]][2][-nv:] for i in idx], np.int32), raw=True, **skw)
                 self.timers["engine_s"] += time.perf_counter() - t1
                 self.timers["crops"] += len(idx)
+                self.timers["engine_calls"] = self.timers.get("engine_calls", 0) + 1
         return records
 
     def heatmap_stats(self, low_res, h: int, w: int, rects_xywh=None) -> np.ndarray:
