@@ -298,6 +298,41 @@ def test_visual_search_entry_point_under_torchrun_world2(tmp_path, shard):
     assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"] and len(a["hits"]) == 4
 
 
+def test_visual_search_entry_point_visualization_writes_the_references_file_set(tmp_path):
+    """--visualization (visual_search.py:339-376, 531-548): one directory <output_path>/<split>/<image stem>_<k> per (image, target)
+    with whole_image.jpg, step_k.jpg, step_k_heatmap.jpg for expanded nodes, final_patch_image.jpg + search_result.jpg for the node
+    that carries the detection, context_cue.txt — rendered with PIL (cv2/matplotlib are absent); metrics unchanged by rendering."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    folder = str(tmp_path / "bench")
+    _make_bench_folder(folder)
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "tests") + os.pathsep + root)
+    common = ["--benchmark-folder", folder, "--vsm-factory", "_fake_vsm:make", "--confidence_high", "2.0", "--confidence_low", "0.0",
+              "--target_cue_threshold", "-1", "--target_cue_threshold_minimum", "-1"]
+    plain = subprocess.run([sys.executable, os.path.join(root, "visual_search.py"), *common, "--output_path", str(tmp_path / "p.json")],
+                           capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    out_dir = str(tmp_path / "vis")
+    vis = subprocess.run([sys.executable, os.path.join(root, "visual_search.py"), *common, "--visualization", "--output_path", out_dir],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert vis.returncode == 0, vis.stderr[-2000:]
+    a, b = json.load(open(tmp_path / "p.json")), json.load(open(os.path.join(out_dir, "results.json")))
+    assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"]
+    dirs = {"direct_attributes": ["img0_0", "img1_0"], "relative_position": ["img0_0", "img0_1"]}
+    from PIL import Image
+    for split, names in dirs.items():
+        assert sorted(os.listdir(os.path.join(out_dir, split))) == names
+        for nm in names:
+            files = set(os.listdir(os.path.join(out_dir, split, nm)))
+            assert {"whole_image.jpg", "step_1.jpg", "context_cue.txt", "final_patch_image.jpg", "search_result.jpg"} <= files, files
+            assert "step_1_heatmap.jpg" in files                   # the root is larger than smallest_size: it was expanded
+            im = Image.open(os.path.join(out_dir, split, nm, "step_1_heatmap.jpg"))
+            whole = Image.open(os.path.join(out_dir, split, nm, "whole_image.jpg"))
+            assert im.size == whole.size                           # the root patch is the whole image
+
+
 def test_scores_keep_the_references_bf16_sigmoid_ties():
     """visual_search.py:225 returns det_result['pred_logits'][0].sigmoid() of a BF16 tensor: the rounding makes distinct logits
     tie, and the scheduler's argmax() (first maximum) / `> confidence` comparisons act on the rounded values.  The drop-in keeps

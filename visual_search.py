@@ -61,6 +61,9 @@ def parse_args(argv):
     p.add_argument("--shard", default="crops", choices=["crops", "samples"], help="what is dealt over the ranks under torchrun")
     p.add_argument("--window", default=0, type=int, help="concurrent (image, target) searches per process; 0 = one engine batch "
                    "(x world size when crops are sharded); 1 = the reference's one-sample-at-a-time schedule")
+    p.add_argument("--engine-comm", action="store_true", help="world > 1 on GPUs: gather the per-step records with the C-ABI's own "
+                   "RCCL communicator on the engine stream (vstar_allgather_results) instead of torch.distributed (EXPERIMENTAL: "
+                   "exercised on one rank only; falls back to torch.distributed if the communicator cannot be set up)")
     p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) returning an object with the VSM interface "
                    "(tests substitute a CPU stand-in for the engine)")
     return p.parse_args(argv)
@@ -73,8 +76,8 @@ def iter_samples(folder):
             if name.endswith(".json"):
                 continue
             ann = json.load(open(os.path.join(d, os.path.splitext(name)[0] + ".json")))
-            for gt_bbox, target in zip(ann["bbox"], ann["target_object"]):
-                yield split, os.path.join(d, name), gt_bbox, target
+            for k, (gt_bbox, target) in enumerate(zip(ann["bbox"], ann["target_object"])):
+                yield split, os.path.join(d, name), gt_bbox, target, k
 
 
 def make_vsm(args, device):
@@ -88,14 +91,17 @@ def make_vsm(args, device):
 
 def main(argv):
     args = parse_args(argv)
-    if args.visualization:
-        raise SystemExit("--visualization (cv2/matplotlib rendering) is out of scope of this engine")
+    if args.visualization and not args.output_path:
+        raise SystemExit("--visualization needs --output_path (the directories are written beneath it, visual_search.py:531-548)")
     world, rank, local_rank = init_from_env()
     finished = False
     try:
         vsm = make_vsm(args, local_rank if world > 1 else args.device)
         if args.shard == "samples":
             vsm.shard_crops = False                      # each search stays on its own GPU
+        elif args.engine_comm:
+            from vstar_amd.dist import maybe_engine_comm
+            maybe_engine_comm(vsm)
         class _Loader:                                   # lazy image load when the sample enters the window; one slot per file
             def __init__(self, path):
                 self.key = path
@@ -104,18 +110,30 @@ def main(argv):
                 return Image.open(self.key).convert("RGB")
 
         mine, loaders = [], {}
-        for i, (_, path, gt_bbox, target) in enumerate(iter_samples(args.benchmark_folder)):
+        vis_dirs = {}
+        for i, (split, path, gt_bbox, target, k) in enumerate(iter_samples(args.benchmark_folder)):
             if args.shard == "samples" and i % world != rank:
                 continue
+            if args.visualization:                       # visual_search.py:531-548: <output_path>/<split>/<image stem>_<k>/
+                vis_dirs[i] = os.path.join(args.output_path, split, "{}_{}".format(os.path.basename(path).split(".")[0], k))
             ld = loaders.setdefault(path, _Loader(path))
             mine.append((i, gt_bbox, (ld, target, gt_bbox,
                                       lambda im: smallest_size_for(im.width, im.height, args.minimum_size_scale, args.minimum_size))))
         stats = {}
-        outs = visual_search_stream(
-            vsm, [m[2] for m in mine], window=args.window or None, stats=stats, confidence_high=args.confidence_high,
-            confidence_low=args.confidence_low, target_cue_threshold=args.target_cue_threshold,
-            target_cue_threshold_decay=args.target_cue_threshold_decay,
-            target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+        skw = dict(confidence_high=args.confidence_high, confidence_low=args.confidence_low,
+                   target_cue_threshold=args.target_cue_threshold, target_cue_threshold_decay=args.target_cue_threshold_decay,
+                   target_cue_threshold_minimum=args.target_cue_threshold_minimum)
+        if args.visualization:
+            # the reference's one-sample-at-a-time loop (visual_search.py:536-550): every search renders its own directory; the
+            # full-resolution heat maps are materialised on the host for it (no device reductions)
+            from vstar_amd.search import visual_search
+            outs = []
+            for i, _, (ld, target, gt_bbox, small_of) in mine:
+                im = ld()
+                outs.append(visual_search(vsm, im, target, gt_bbox, small_of(im), visualize=rank == 0 or args.shard == "samples",
+                                          save_path=vis_dirs[i], **skw))
+        else:
+            outs = visual_search_stream(vsm, [m[2] for m in mine], window=args.window or None, stats=stats, **skw)
         results = []                                     # (sample index, hit, path length)
         for (i, gt_bbox, _), (step, n_steps, ok, _) in zip(mine, outs):
             if not ok:
@@ -134,7 +152,7 @@ def main(argv):
             if args.output_path:
                 json.dump({"world_size": world, "shard": args.shard, "hits": hits, "path_lengths": lengths,
                            "rank0_search_stats": {k: v for k, v in stats.items() if k != "per_search"}},
-                          open(args.output_path, "w"))
+                          open(os.path.join(args.output_path, "results.json") if args.visualization else args.output_path, "w"))
         finished = True
     finally:
         finalize(finished)

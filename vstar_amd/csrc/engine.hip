@@ -590,6 +590,15 @@ int vstar_engine::owl_heads_sam(const lp_t* opix, int Bimg, int nrec, int img_di
   return owl_finish(Bimg, nrec, img_div);
 }
 
+// Armed after fork_owl has queued work on stream2: whichever way the scoring call leaves (an RC() failure of the main path included),
+// stream2 is drained first, so the next call's stage_pixels / preprocessing cannot overwrite d_owl_pix or the OWL scratch while the
+// side stream still reads them.  The success path disarms it after its own event wait.
+struct OwlJoinGuard {
+  hipStream_t s2;
+  bool armed;
+  ~OwlJoinGuard() { if (armed && s2) (void)hipStreamSynchronize(s2); }
+};
+
 bool vstar_engine::fork_owl(const lp_t* opix, int Bimg, int* rc) {
   *rc = 0;
   const bool want = owl_overlap >= 0 ? owl_overlap != 0 : Bimg <= 8;
@@ -747,6 +756,7 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   RC(stage_pixels(B, clip_pix, owl_pix, flags, skip_owl, &cpix, &opix));
   int frc_owl = 0;
   const bool forked = !skip_owl && fork_owl(opix, B, &frc_owl);       // OWL-ViT side of the graph on stream2 (small batches)
+  OwlJoinGuard join_guard{stream2, forked || frc_owl != 0};
   RC(frc_owl);
   last_B = B; last_S = S;
   grp_R0 = grp_Lc = 0;
@@ -781,6 +791,7 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   if (!skip_owl) {
     if (forked) {
       HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+      join_guard.armed = false;
       RC(owl_finish(B, B, 1));
     } else {
       RC(owl_heads_sam(opix, B, B, 1));
@@ -856,6 +867,7 @@ int vstar_engine::score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* 
   RC(stage_pixels(G, clip_pix, owl_pix, flags, false, &cpix, &opix));
   int frc_owl = 0;
   const bool forked = fork_owl(opix, G, &frc_owl);
+  OwlJoinGuard join_guard{stream2, forked || frc_owl != 0};
   RC(frc_owl);
   last_B = nrec; last_S = S;
   // ---- a2 + a3: CLIP tower and projector for the G crops -> feature table; a4: splice by row sources ----
@@ -874,6 +886,7 @@ int vstar_engine::score_grouped(int G, int T, const lp_t* clip_pix, const lp_t* 
   RC(llm_heads(nrec, n_verify));
   if (forked) {
     HIPCHK(hipStreamWaitEvent(stream, ev_join, 0));
+    join_guard.armed = false;
     RC(owl_finish(G, nrec, T));
   } else {
     RC(owl_heads_sam(opix, G, nrec, T));

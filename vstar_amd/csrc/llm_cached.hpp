@@ -48,7 +48,7 @@ struct LlmCached {
   // the arg-max back as the next input and advances the position, and the host looks at the emitted tokens every few steps only.
   hipGraphExec_t dec_exec = nullptr;
   int dec_keys_bound = 0;                        // context bound the captured attention launch was sized for
-  int32_t* d_dec = nullptr;                      // [0] = tokens emitted so far, [1..] = the tokens
+  int32_t* d_dec = nullptr;                      // coherent HOST memory: [0] = tokens emitted so far, [1..] = the tokens
   int dec_cap = 0;
 
   void set_error(const std::string& m) { e->set_error(m); }
@@ -60,6 +60,8 @@ struct LlmCached {
     ev0 = ev1 = nullptr;
     if (dec_exec) hipGraphExecDestroy(dec_exec);
     dec_exec = nullptr;
+    if (d_dec) hipHostFree(d_dec);
+    d_dec = nullptr;
   }
   int decode_step_body(int keys_bound);
   int decode_greedy_graph(int32_t first_token, int past, int slot, int max_new, int eos_id, int32_t* out_ids, int* n_out, bool* used);
@@ -279,7 +281,9 @@ inline int LlmCached::forward(int nseq, const int32_t* row_off, const int32_t* s
 }
 
 namespace {
-// last node of the decode graph: the arg-max becomes the next input token, position and past length advance, the token is logged
+// last node of the decode graph: the arg-max becomes the next input token, position and past length advance, the token is logged.
+// `log` is coherent HOST memory (hipHostMallocCoherent): the host polls log[0] instead of synchronising the stream, so the next
+// step's graph is already queued while it looks at this step's token.  Token first, counter last, system-scope release.
 __global__ void decode_advance_kernel(const int32_t* __restrict__ argmax, int32_t* src, int32_t* row_pos, int32_t* seq_past, int32_t* log,
                                       int cap) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -289,7 +293,8 @@ __global__ void decode_advance_kernel(const int32_t* __restrict__ argmax, int32_
   seq_past[0] += 1;
   const int32_t n = log[0];
   if (n < cap) log[1 + n] = t;
-  log[0] = n + 1;
+  __threadfence_system();
+  __hip_atomic_store(&log[0], n + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 }  // namespace
 
@@ -311,18 +316,34 @@ inline int LlmCached::decode_step_body(int keys_bound) {
 
 // Greedy continuation of the sequence in `slot` whose cache holds `past` positions, starting from `first_token` (already the
 // arg-max of the prefill): emits up to max_new - 1 further tokens, stopping at eos_id.  *used = false when the graph path is
-// not available (event profiling on, capture refused): the caller then runs the stepwise loop — same kernels, same tokens.
+// not available (event profiling on, a launch of the warm-up step failed): the caller then runs the stepwise loop — same kernels,
+// same tokens (re-running a step rewrites the same K/V rows of the cache, so a half-finished warm-up step does no harm).
+// Round 4: nothing is launched when the prefill's arg-max already is EOS; a failing warm-up step or a refused capture
+// degrades to the stepwise path instead of failing generate(); the emitted tokens are read from coherent host memory with ONE
+// step in flight ahead, so at most one decode step (not up to seven) runs past EOS and the stream is never drained between steps.
 inline int LlmCached::decode_greedy_graph(int32_t first_token, int past, int slot, int max_new, int eos_id, int32_t* out_ids,
                                           int* n_out, bool* used) {
   *used = false;
   const LlmCachedCfg& c = cfg;
   static const bool disabled = [] { const char* v = getenv("VSTAR_DECODE_GRAPH"); return v && atoi(v) == 0; }();
-  if (disabled || e->profile || max_new < 2) return 0;
+  if (disabled || e->profile || max_new < 1) return 0;
+  if (first_token == eos_id || max_new < 2) {          // the answer is the prefill's arg-max alone: no decode step at all
+    out_ids[0] = first_token;
+    *n_out = 1;
+    *used = true;
+    return 0;
+  }
   LCHK(hipSetDevice(e->device));
   if (!d_dec) {
     dec_cap = c.max_ctx;
-    RC(e->dalloc(&d_dec, (size_t)dec_cap + 1));
+    void* hp = nullptr;
+    if (hipHostMalloc(&hp, ((size_t)dec_cap + 1) * 4, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;                                         // no pinned memory: the stepwise loop
+    }
+    d_dec = (int32_t*)hp;
   }
+  volatile int32_t* log = d_dec;
   const int keys_bound = c.max_ctx;                  // sizes the attention launch's LDS (4 B per key): fixed for the graph's lifetime
   // ---- per-call state of row 0 ----
   std::vector<int32_t> seqmeta((size_t)3 * c.max_slots * 4, 0);
@@ -334,60 +355,74 @@ inline int LlmCached::decode_greedy_graph(int32_t first_token, int past, int slo
   LCHK(hipMemcpyAsync(d_row_seq, &zero, 4, hipMemcpyHostToDevice, e->stream));
   LCHK(hipMemcpyAsync(d_seq, seqmeta.data(), seqmeta.size() * 4, hipMemcpyHostToDevice, e->stream));
   LCHK(hipMemcpyAsync(d_want, &zero, 4, hipMemcpyHostToDevice, e->stream));
-  LCHK(hipMemcpyAsync(d_dec, &zero, 4, hipMemcpyHostToDevice, e->stream));
   LCHK(hipStreamSynchronize(e->stream));
+  d_dec[0] = 0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   int launched = 0;
   if (!dec_exec || dec_keys_bound != keys_bound) {
     if (dec_exec) { hipGraphExecDestroy(dec_exec); dec_exec = nullptr; }
     // the first step runs UNCAPTURED: it is a real decode step (its token is consumed below) and it takes every one-time
     // hipFuncSetAttribute of the launch helpers out of the capture
-    RC(decode_step_body(keys_bound));
-    LCHK(hipStreamSynchronize(e->stream));
+    if (decode_step_body(keys_bound) != 0 || hipStreamSynchronize(e->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      e->set_error("");                                // not an error of generate(): the stepwise loop takes over
+      return 0;
+    }
     launched = 1;
     hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    const int rc = decode_step_body(keys_bound);
-    const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
-    if (rc != 0 || ce != hipSuccess || !graph) {
-      if (graph) hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      if (rc) return rc;
+    if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      const int rc = decode_step_body(keys_bound);
+      const hipError_t ce = hipStreamEndCapture(e->stream, &graph);
+      if (rc != 0 || ce != hipSuccess || !graph) {
+        if (graph) hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        e->set_error("");
+      } else {
+        const hipError_t ie = hipGraphInstantiate(&dec_exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ie != hipSuccess) { dec_exec = nullptr; (void)hipGetLastError(); }
+        else dec_keys_bound = keys_bound;
+      }
     } else {
-      const hipError_t ie = hipGraphInstantiate(&dec_exec, graph, nullptr, nullptr, 0);
-      hipGraphDestroy(graph);
-      if (ie != hipSuccess) { dec_exec = nullptr; (void)hipGetLastError(); }
-      else dec_keys_bound = keys_bound;
+      (void)hipGetLastError();                          // capture refused: the loop below launches the same step kernel by kernel
     }
   }
   *used = true;                                         // from here on this function owns the sequence's state
   int n = 0;
   out_ids[n++] = first_token;
-  const int CHUNK = 8;                                  // tokens decoded between two looks at the emitted ids
-  std::vector<int32_t> log((size_t)max_new + 1);
-  bool done = first_token == eos_id;
+  const int DEPTH = 2;                                  // decode steps queued ahead of the token the host is waiting for
+  bool done = false;
   LCHK(hipEventRecord(ev0, e->stream));
-  int timed = 0;
+  const int launched0 = launched;
   while (!done && n < max_new) {
-    int todo = std::min(CHUNK, max_new - 1 - launched);
-    if (n - 1 < launched) todo = 0;                      // tokens of the uncaptured first step are still to be read
-    else if (todo <= 0) break;
-    for (int i = 0; i < todo; ++i) {
+    // out_ids[k] (k >= 1) = log[k], produced by decode step k; keep steps n .. n + DEPTH - 1 queued
+    while (launched < std::min(max_new - 1, n - 1 + DEPTH)) {
       if (dec_exec) LCHK(hipGraphLaunch(dec_exec, e->stream));
-      else RC(decode_step_body(keys_bound));            // capture refused: the same step, launch by launch
+      else RC(decode_step_body(keys_bound));
+      ++launched;
     }
-    launched += todo;
-    timed += todo;
-    LCHK(hipMemcpyAsync(log.data(), d_dec, ((size_t)launched + 1) * 4, hipMemcpyDeviceToHost, e->stream));
-    LCHK(hipStreamSynchronize(e->stream));
-    while (n - 1 < launched && n < max_new) {
-      const int32_t t = log[(size_t)n];                 // log[1 + k] = k-th emitted token, out_ids[1 + k]
-      out_ids[n++] = t;
-      if (t == eos_id) { done = true; break; }
+    if (launched < n) break;                            // max_new reached
+    unsigned spins = 0;
+    while (__atomic_load_n(&d_dec[0], __ATOMIC_ACQUIRE) < n) {
+      if ((++spins & 4095u) == 0) {
+        const hipError_t q = hipStreamQuery(e->stream);
+        if (q == hipSuccess) {
+          if (__atomic_load_n(&d_dec[0], __ATOMIC_ACQUIRE) >= n) break;
+          set_error("decode graph: a step completed without emitting its token");
+          return VSTAR_ERR_HIP;
+        }
+        if (q != hipErrorNotReady) { set_error(std::string("decode graph: ") + hipGetErrorString(q)); return VSTAR_ERR_HIP; }
+      }
+      __builtin_ia32_pause();
     }
+    const int32_t t = log[n];
+    out_ids[n++] = t;
+    if (t == eos_id) done = true;
   }
   LCHK(hipEventRecord(ev1, e->stream));
   LCHK(hipStreamSynchronize(e->stream));
   float ms = 0;
+  const int timed = launched - launched0;
   if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess && timed > 0) last_ms = ms / timed;
   *n_out = n;
   return 0;

@@ -48,6 +48,29 @@ def engine_comm_init(engine, group=None) -> None:
     engine.comm_init(box[0], world, rank)
 
 
+def maybe_engine_comm(vsm, group=None) -> bool:
+    """Opt-in wiring of the C-ABI collective for the entry points (`--engine-comm`): with a multi-rank nccl group and an engine that
+    has the comm entry points, give the engine its communicator; any failure leaves the torch.distributed gather in place (every
+    rank takes the same decision: the outcome is agreed on with an all-reduce).  EXPERIMENTAL — the multi-rank path has only been
+    exercised with one rank (tests/test_rccl_selfcheck_gpu.py); torch.distributed stays the default data-path collective."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"):
+        return False
+    eng = getattr(vsm, "engine", None)
+    ok = 1
+    try:
+        if eng is None or not hasattr(eng, "comm_init"):
+            raise RuntimeError("engine has no comm entry points")
+        engine_comm_init(eng, group)
+    except Exception as exc:            # noqa: BLE001 — fall back, but on EVERY rank
+        import warnings
+        warnings.warn(f"engine communicator not available ({type(exc).__name__}: {exc}); using torch.distributed")
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{torch.cuda.current_device()}")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    vsm.use_engine_comm = bool(int(flag.item()))
+    return vsm.use_engine_comm
+
+
 def reorder_gathered(gathered: torch.Tensor, world: int, n_items: int) -> torch.Tensor:
     """[world * per, R] rank-major (what an all-gather of round-robin shards returns) -> [n_items, R] in item order."""
     per = gathered.shape[0] // world

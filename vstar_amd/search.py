@@ -320,7 +320,8 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
     and is sent one statistics vector per item; its return value is visual_search's.  `visual_search` drives one such generator, `visual_search_many` several in lock
     step.  Everything else — the decision math of visual_search.py:390-516 — is unchanged."""
     if visualize:
-        raise NotImplementedError("search-path visualisation (cv2/matplotlib, visual_search.py:285-376) is out of scope")
+        assert save_path is not None                         # visual_search.py:485-486
+        device_reductions = False                            # the rendered heat maps need the full-resolution maps on the host
     init_patch = {"bbox": [0, 0, image.width, image.height], "scale_level": 1, "score": None, "parent_index": -1}
     search_path = [init_patch]
     queue: PriorityQueue = PriorityQueue()
@@ -500,6 +501,10 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
     if stats is not None:
         stats.update(crops_scored=scorer.n_scored, engine_batches=scorer.n_batches, path_visited=len(search_path),
                      search_path=search_path)
+    if visualize:                                            # visual_search.py:512-514
+        from .visualize import visualize_search_path
+        vis_path_length = path_length if search_successful else len(search_path)
+        visualize_search_path(image, search_path, vis_path_length, target_bbox, target_object_name, save_path)
     return final_step, path_length, search_successful, all_valid_boxes
 
 
@@ -586,7 +591,9 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
 
     prefetch: how many of the upcoming samples' image loaders run ahead of the window on a worker thread (host work only — open +
     decode; the upload stays on the calling thread, in sample order) while the engine is busy; 0 = load when the sample enters.
-    Every loader is still called exactly once and nothing about the results depends on it.
+    A loader is called once per residency of its image: samples that are live together share one slot and one call; when the
+    last of them has ended the slot (and the host copy) is released, and a LATER sample with the same key loads the image again.
+    Nothing about the results depends on it.
 
     stats (optional dict) receives: searches, crops_scored (engine records), useful_crops (nodes the best-first order visited),
     wasted_crop_frac, engine_steps, per_search = [{crops_scored, path_visited, ...}]."""
@@ -684,6 +691,9 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
             del slot_of[key]
             loaded.pop(key, None)
             free_slots.append(sl)
+            rel = getattr(vsm, "release_image", None)
+            if rel is not None:
+                rel(sl)
         gens.pop(i).close()
 
     def advance(i, value=None, first=False):

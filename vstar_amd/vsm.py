@@ -127,6 +127,14 @@ class VSM:
                 dt = (_t.perf_counter() - t0) * 1e3
                 best = dt if best is None else min(best, dt)
             table[int(B)] = round(best, 3)
+        # crop-sharded ranks must plan IDENTICAL batches (VSM._score_sharded deals crop i to rank i % world): a per-rank measured
+        # table would let timing noise pick different speculative crops on different ranks and the all-gather would mismatch or
+        # hang.  Every rank takes rank 0's table.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            box = [table]
+            dist.broadcast_object_list(box, src=0)
+            table = {int(k): float(v) for k, v in box[0].items()}
         self.step_ms_table = table
         return table
 
@@ -271,6 +279,15 @@ class VSM:
             self.engine.set_image(image)
         else:
             self.engine.set_image(image, int(slot))
+
+    def release_image(self, slot: int = 0) -> None:
+        """The stream driver recycled `slot`: drop the host-side PIL image kept for the decode fallback (a 4K RGB image is 25 MB;
+        64 slots of them were never released).  The device copy is simply overwritten by the next set_image."""
+        imgs = getattr(self, "_images", None)
+        if imgs is not None:
+            imgs.pop(int(slot), None)
+        if slot == 0:
+            self._image = None
 
     @torch.inference_mode()
     def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question, mode: str = "detection",
