@@ -28,7 +28,7 @@ if ROOT not in sys.path:
 from vstar_amd import _lib  # noqa: E402
 from vstar_amd.config import VSMConfig  # noqa: E402
 from vstar_amd.engine import VstarEngine  # noqa: E402
-from vstar_amd.weights import random_state_dict  # noqa: E402
+from vstar_amd.weights import random_state_dict, template_chain, trained_like_state_dict  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -76,6 +76,20 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
                       f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
 
 
+def _strict(args) -> bool:
+    """trained_like weights decode "Sure, [LOC]." (vstar_amd.weights.template_chain): the search legs then run VSM's DEFAULT
+    strict_template=True — a crop whose teacher-forced arg-max check failed would take the stepwise-decode fallback."""
+    return getattr(args, "weights", "random") == "trained_like" and not getattr(args, "fake_engine", False)
+
+
+def _bench_state_dict(cfg, args):
+    if getattr(args, "weights", "random") == "trained_like":
+        from vstar_amd.preprocess import SyntheticTokenizer
+        return trained_like_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True,
+                                       chain=template_chain(SyntheticTokenizer(cfg.llm_vocab)))
+    return random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True)
+
+
 def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
     """BASELINE config 2 LITERALLY (SURVEY §8d "searched crops/s"): one synthetic 3840x2160 image, `--search-targets` targets,
     exhaustive depth-3 search tree (smallest_size = 540: 1 + 4 + 16 = 21 nodes per target), crops scored in 32-crop engine
@@ -94,7 +108,7 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
     scale = 16.0 if args.config5 else 4.0
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+        vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=_strict(args))
         # each rank searches its own image (weak scaling, no collective in this leg); --rccl-selfcheck turns the product's
         # device-record all-gather on (VSM._score_sharded over the one-rank nccl group)
         vsm.shard_crops = bool(getattr(args, "rccl_selfcheck", False))
@@ -153,7 +167,7 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
     n_img = max(args.stream_samples // args.stream_targets_per_image, 1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+        vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=_strict(args))
         vsm.shard_crops = (shard == "crops") and (world > 1 or bool(getattr(args, "rccl_selfcheck", False)))
         vsm.group_prompts = False                     # plain batches: records bit-identical to the per-sample loop
         smallest = smallest_size_for(W, H, 4.0)
@@ -375,6 +389,10 @@ def main():
                     "search leg on an 8K synthetic image with --minimum_size_scale 16 (depth-5 tree); separate line, not the headline")
     ap.add_argument("--rccl-selfcheck", action="store_true", help="N = 1 only: join a ONE-rank nccl (= RCCL) process group and run the N > 1 "
                     "code path — per-step all_gather_into_tensor of the device records, barrier, max-over-ranks — on the single GPU")
+    ap.add_argument("--weights", choices=("random", "trained_like"), default="random",
+                    help="seeded synthetic weights: i.i.d. random (rounds 1-3) or vstar_amd.weights.trained_like_state_dict — outlier "
+                         "channels, massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the answer "
+                         "template, so the search legs run the default strict_template=True path")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
@@ -416,7 +434,7 @@ def main():
     S = P + T
     t0 = time.perf_counter()
     eng = VstarEngine(cfg, local_rank)
-    eng.load_state_dict(random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True))
+    eng.load_state_dict(_bench_state_dict(cfg, args))
     t_load = time.perf_counter() - t0
 
     # synthetic crop batch (vstar_amd.synthetic.bench_inputs: the same batch the full-depth reference golden was recorded on,
@@ -544,7 +562,7 @@ def main():
         try:
             cfg8 = VSMConfig.seal_7b(args.image_size, max_batch=B, max_text_len=L, llm_w8a8=1)
             eng8 = VstarEngine(cfg8, local_rank)
-            eng8.load_state_dict(random_state_dict(cfg8, seed=0, dtype=torch.bfloat16, share_layers=True))
+            eng8.load_state_dict(_bench_state_dict(cfg8, args))
             rec8 = torch.empty((B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
 
             def step8():
@@ -581,7 +599,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8 e4m3 W8A8 for the LLaMA linears (per-token / per-channel scales), bf16 elsewhere" if args.fp8 else "bf16",
-            "data": "synthetic (seeded random weights of the real architecture, N(0,1) pixels, random ids)",
+            "data": "synthetic (seeded " + ("trained-like" if args.weights == "trained_like" else "random") +
+                    " weights of the real architecture, N(0,1) pixels, random ids)",
             "config": {"workload": ("TINY-plumbing " if args.tiny else "") + ("[config-5 precision] " if args.fp8 else "") +
                        f"BASELINE config {5 if args.config5 else 2}: {B}-crop batches/GPU, CLIP-ViT-L/14@{cfg.clip_image_size} (P={P}) + LLaMA-7B prefill "
                        f"S={S} + " + ("(core only)" if args.skip_owl else "OWL-ViT-B/16@768 + det/SAM heads") +

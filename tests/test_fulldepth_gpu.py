@@ -20,20 +20,40 @@ from test_engine_gpu import margin_aware_topk_equal
 from vstar_amd.config import VSMConfig
 from vstar_amd.engine import VstarEngine
 from vstar_amd.synthetic import bench_inputs
-from vstar_amd.weights import random_state_dict
+from vstar_amd.preprocess import SyntheticTokenizer
+from vstar_amd.weights import random_state_dict, template_chain, trained_like_state_dict
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-@pytest.mark.parametrize("image_size", [336, 224])
-def test_bench_batch_matches_full_depth_reference(cuda, image_size):
-    z = np.load(os.path.join(GOLD, f"full7b_{image_size}.npz"))
+def _state_dict(cfg, z):
+    """The state dict a golden file was recorded with: i.i.d. random (rounds 2/3) or the trained-like statistics of round 4 —
+    outlier residual channels (|x|_inf / rms 9 -> 32 across the depth, 48 at the worst token), a massive-activation BOS, spread
+    norm gains, peaked attention (vstar_amd.weights.trained_like_state_dict; oracle/gen_fulldepth_golden.py --weights trained_like)."""
+    if "weights" in z.files and str(z["weights"]) == "trained_like":
+        return trained_like_state_dict(cfg, seed=int(z["weight_seed"]), dtype=torch.bfloat16, share_layers=True,
+                                       chain=template_chain(SyntheticTokenizer(cfg.llm_vocab)))
+    return random_state_dict(cfg, seed=int(z["weight_seed"]), dtype=torch.bfloat16, share_layers=True)
+
+
+@pytest.mark.parametrize("image_size,weights,fold", [(336, "random", None), (224, "random", None),
+                                                     (336, "trained_like", "1"), (336, "trained_like", "0"),
+                                                     (224, "trained_like", "1"), (224, "trained_like", "0")])
+def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fold, monkeypatch):
+    """weights = trained_like (VERDICT r3 missing #2): the same gates on weights with the statistics of a trained checkpoint, pushed
+    through the reference's own model_forward in fp32 and bf16, for BOTH norm formulations of the engine (VSTAR_FOLD_NORMS = 1: rstd
+    applied to the fp32 accumulators of the raw residual stream — the variant whose headroom outlier channels could eat — and = 0:
+    the reference's rounding points)."""
+    tag = "tl_" if weights == "trained_like" else ""
+    z = np.load(os.path.join(GOLD, f"full7b_{tag}{image_size}.npz"))
     B, T = int(z["batch"]), int(z["text_tokens"])
-    assert len(z["crops"]) >= (8 if image_size == 336 else 4)
+    assert len(z["crops"]) >= (4 if image_size == 224 or tag else 8)
+    if fold is not None:
+        monkeypatch.setenv("VSTAR_FOLD_NORMS", fold)
     cfg = VSMConfig.seal_7b(image_size, max_batch=B, max_text_len=T + 1)
     eng = VstarEngine(cfg, 0)
-    eng.load_state_dict(random_state_dict(cfg, seed=int(z["weight_seed"]), dtype=torch.bfloat16, share_layers=True))
+    eng.load_state_dict(_state_dict(cfg, z))
     clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
     out = eng.score_batch(clip.to(cuda), owl.to(cuda), ids, loc, verify_pos=verify)
     H = cfg.llm_hidden

@@ -45,11 +45,12 @@ def test_device_record_gather_equals_host_records(cuda):
     from vstar_amd.engine import VstarEngine
     from vstar_amd.synthetic import synthetic_image
     from vstar_amd.vsm import VSM
-    from vstar_amd.weights import random_state_dict
+    from vstar_amd.weights import template_chain, trained_like_state_dict
     cfg = VSMConfig.tiny(max_batch=4, max_text_len=96)
     eng = VstarEngine(cfg, 0)
-    eng.load_state_dict(random_state_dict(cfg, seed=5, dtype=torch.bfloat16))
-    vsm = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+    tok = pp.SyntheticTokenizer(cfg.llm_vocab)
+    eng.load_state_dict(trained_like_state_dict(cfg, seed=5, dtype=torch.bfloat16, share_layers=False, chain=template_chain(tok)))
+    vsm = VSM(None, engine=eng, tokenizer=tok, strict_template=True)
     img = synthetic_image(900, 600, 4)
     vsm.set_image(img)
     boxes = [[0, 0, 900, 600], [0, 0, 450, 300], [450, 0, 450, 300], [0, 300, 450, 300], [450, 300, 450, 300]]

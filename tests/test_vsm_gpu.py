@@ -14,9 +14,17 @@ from vstar_amd.config import VSMConfig
 from vstar_amd.engine import VstarEngine
 from vstar_amd.search import smallest_size_for, visual_search, visual_search_many
 from vstar_amd.vsm import VSM
-from vstar_amd.weights import random_state_dict
+from vstar_amd.weights import template_chain, trained_like_state_dict
 
 pytestmark = pytest.mark.gpu
+
+
+def random_state_dict(cfg, seed, dtype):
+    """Round 4: the module's weights have a trained checkpoint's statistics AND answer locate prompts with "Sure, [LOC]." under
+    greedy decoding (vstar_amd.weights.trained_like_state_dict), so every test below runs the DEFAULT strict_template=True path:
+    a crop whose teacher-forced arg-max check failed would take the stepwise-decode fallback and appear in vsm.fallback_log."""
+    return trained_like_state_dict(cfg, seed=seed, dtype=dtype, share_layers=False,
+                                   chain=template_chain(pp.SyntheticTokenizer(cfg.llm_vocab)))
 
 
 @pytest.fixture(scope="module")
@@ -25,8 +33,10 @@ def vsm(cuda):
     eng = VstarEngine(cfg, 0)
     eng.load_state_dict(random_state_dict(cfg, seed=5, dtype=torch.bfloat16))
     with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        yield VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(cfg.llm_vocab), strict_template=False)
+        warnings.simplefilter("error")                  # a "tolerated template mismatch" warning would fail the module
+        v = VSM(None, engine=eng, tokenizer=pp.SyntheticTokenizer(cfg.llm_vocab), strict_template=True)
+    yield v
+    assert v.fallback_log == [], v.fallback_log[:2]     # no crop of any test needed the fallback: the template was always emitted
 
 
 def rel_l2(a, b):
@@ -42,6 +52,7 @@ def test_inference_conventions_and_oracle(vsm):
         boxes, scores, heat = vsm.inference(img, q, mode="detection")
         seg = vsm.inference(img, q, mode="segmentation")
     assert boxes.shape == (2304, 4) and scores.shape == (2304, 1) and heat.shape == (300, 500)
+    assert vsm.strict_template and vsm.last_template_ok.all()
     assert heat.dtype == torch.float32 and float(heat.min()) >= 0 and 0 < float(scores.min()) and float(scores.max()) < 1
     assert scores.dtype == torch.bfloat16 and boxes.dtype == torch.float32
     assert torch.equal(seg, heat)
