@@ -180,6 +180,14 @@ int vstar_preprocess_crops(vstar_handle* h, int B, const int32_t* boxes_xyxy);
 #define VSTAR_MAX_IMAGE_SLOTS 64
 int vstar_image_set_slot(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width);
 int vstar_preprocess_crops_slots(vstar_handle* h, int B, const int32_t* boxes_xyxy, const int32_t* slots);
+/* Round 4: the same upload WITHOUT stalling the scoring stream — `rgb` is copied into a pinned staging buffer before the call
+ * returns (the caller may free it), the DMA runs on a copy stream of its own, and the next vstar_preprocess_crops* that reads the
+ * slot waits for it on the device.  Meant to be called from a second host thread while another thread is inside a scoring call:
+ * the stream search uploads the images of the samples that enter the window NEXT while the current step is on the GPU (in the
+ * reference the equivalent host work — Image.open + processors, visual_search.py:541-550 — sits between two forward passes).
+ * Contract: no crop of the slot's previous image may still be waiting to be launched (crops already launched are ordered before
+ * the copy). */
+int vstar_image_set_slot_async(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width);
 
 /* Greedy free-text decode of ONE crop with a KV cache — VSMForCausalLM.inference for mode='vqa' (VSM.py:438-462 ->
  * generate(max_new_tokens, greedy); called from VSM.inference at visual_search.py:198-219 for the contextual-cue branch,

@@ -62,6 +62,14 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
     seg = eng.debug_read("embed_seg", B * 256).reshape(B, 256)
     hyper = eng.debug_read("sam_hyper", B * 32).reshape(B, 32)
     dec = {"engine": [], "fp32": [], "bf16": []}
+    fails = []                                # every tap of every crop is evaluated before the verdict: one run shows the whole picture
+
+    def gate(fn, *a, **k):
+        try:
+            fn(*a, **k)
+        except AssertionError as exc:
+            fails.append(str(exc).splitlines()[0])
+
     for j, ci in enumerate(z["crops"]):
         ci = int(ci)
         rep = {}
@@ -69,12 +77,11 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
                "pred_logits": out["pred_logits"][ci, :, 0], "pred_boxes": out["pred_boxes"][ci]}
         for k, v in got.items():
             assert np.isfinite(v).all(), k
-            assert_within_bf16_noise(k, v, z[k][j], z["bf16_" + k][j], report=rep)
+            gate(assert_within_bf16_noise, f"crop {ci} {k}", v, z[k][j], z["bf16_" + k][j], report=rep)
         upmean = eng.debug_read("sam_c2", (ci + 1) * 192 * 192 * 32)[ci * 192 * 192 * 32:].reshape(-1, 32).astype(np.float64).mean(axis=0)
-        assert_within_bf16_noise("sam_upscaled_mean", upmean, z["sam_upscaled_mean"][j], z["bf16_sam_upscaled_mean"][j], report=rep)
-        assert_mask_within_bf16_noise(out["low_res_masks"][ci, 0], z["low_res_masks"][j], z["bf16_low_res_masks"][j],
-                                      z["sam_hyper"][j], z["bf16_sam_hyper"][j], z["sam_upscaled_mean"][j],
-                                      z["bf16_sam_upscaled_mean"][j], report=rep)
+        gate(assert_within_bf16_noise, f"crop {ci} sam_upscaled_mean", upmean, z["sam_upscaled_mean"][j], z["bf16_sam_upscaled_mean"][j], report=rep)
+        gate(assert_mask_within_bf16_noise, out["low_res_masks"][ci, 0], z["low_res_masks"][j], z["bf16_low_res_masks"][j],
+             z["sam_hyper"][j], z["bf16_sam_hyper"][j], z["sam_upscaled_mean"][j], z["bf16_sam_upscaled_mean"][j], report=rep)
         print(f"\ncrop {ci}: engine / reference-bf16 noise (rel-L2 vs the reference's fp32 output): {fmt(rep)}")
         assert np.abs(out["pred_boxes"][ci] - z["pred_boxes"][j]).max() < 1e-2
         noise_abs = 2.0 * float(np.abs(z["bf16_pred_logits"][j] - z["pred_logits"][j]).max())
@@ -88,6 +95,7 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
         dec["engine"].append(decisions(out["pred_logits"][ci, :, 0], out["pred_boxes"][ci], out["low_res_masks"][ci, 0]))
         dec["fp32"].append(decisions(z["pred_logits"][j], z["pred_boxes"][j], z["low_res_masks"][j]))
         dec["bf16"].append(decisions(z["bf16_pred_logits"][j], z["bf16_pred_boxes"][j], z["bf16_low_res_masks"][j]))
+    assert not fails, "\n".join(fails)
     # ---- pooled over the recorded crops: un-centred mask error and the scheduler's decisions, next to the reference's bf16 run ----
     sel = [int(c) for c in z["crops"]]
     e_mask, n_mask = rel_l2(out["low_res_masks"][sel, 0], z["low_res_masks"]), rel_l2(z["bf16_low_res_masks"], z["low_res_masks"])

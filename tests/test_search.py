@@ -110,6 +110,36 @@ def test_device_reductions_path_matches_reference(gold):
         assert n_exact <= 2 * len(dev["search_path"])          # and that ordinary searches almost never pay for it
 
 
+class SparseFake(BatchedFake):
+    """Heat maps like a trained segmentation head's: negative (clamped to zero) on the background, positive in one small blob — so
+    most children of a node carry EXACTLY zero mass, in the reference's float32 arithmetic and in the device statistics alike."""
+
+    def _low(self, g, scale):
+        low = torch.full((1, 1, 12, 12), -3.0)
+        i, j = (int(v) for v in torch.randint(0, 6, (2,), generator=g))
+        low[0, 0, i, j] = float(torch.rand(1, generator=g)) * scale + 1.0
+        return low
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_exact_zero_children_tie_without_the_float32_fallback(seed):
+    """Round 4: children whose heat mass is exactly zero (every pixel of the clamped map inside them is 0) tie EXACTLY in the
+    reference's arithmetic too, so ordering them must not materialise heat maps (160 of 336 queue pushes of the config-2 search leg
+    did on trained-like weights).  The visit order still equals the float32 host path's."""
+    img = synthetic_image(1920, 1080, 10 + seed)
+    kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    dev, host = {}, {}
+    search.LazyExactPrioritize.n_exact = 0
+    search.visual_search(SparseFake(32, seed=seed, conf_shift=-6.0), img, "o", None, 270, stats=dev, **kw)
+    n_exact = search.LazyExactPrioritize.n_exact
+    search.visual_search(SparseFake(32, seed=seed, conf_shift=-6.0), img, "o", None, 270, stats=host, device_reductions=False, **kw)
+    assert [p["bbox"] for p in dev["search_path"]] == [p["bbox"] for p in host["search_path"]]
+    assert len(dev["search_path"]) == 21
+    zeros = sum(1 for p in dev["search_path"][1:] if float(p["score"]) == 0.0)
+    assert zeros >= 10                                     # the regime is real: most children carry no mass at all
+    assert n_exact == 0, n_exact
+
+
 def test_device_reductions_child_scores_close_to_numpy_path():
     img = synthetic_image(1920, 1080, 1)
     a, b = {}, {}

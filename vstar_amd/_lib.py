@@ -20,7 +20,7 @@ EXPORTS = [
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
-    "vstar_image_set_slot", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
+    "vstar_image_set_slot", "vstar_image_set_slot_async", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
     "vstar_comm_destroy",
 ]
 
@@ -93,6 +93,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_preprocess_crops.restype = c_int
     lib.vstar_image_set_slot.argtypes = [H, c_int, c_void_p, c_int, c_int]
     lib.vstar_image_set_slot.restype = c_int
+    lib.vstar_image_set_slot_async.argtypes = [H, c_int, c_void_p, c_int, c_int]
+    lib.vstar_image_set_slot_async.restype = c_int
     lib.vstar_preprocess_crops_slots.argtypes = [H, c_int, c_void_p, c_void_p]
     lib.vstar_preprocess_crops_slots.restype = c_int
     lib.vstar_comm_unique_id.argtypes = [c_void_p]

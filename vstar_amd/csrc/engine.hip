@@ -3,6 +3,7 @@
 // (VisualSearch/model/VSM.py:201-364, 438-553) with the generate() loop collapsed into one teacher-forced prefill
 // (SURVEY.md §7 "hard parts"; the lm_head argmax at the verify positions lets the caller prove the collapse is exact).
 #include "llm_cached.hpp"
+#include <atomic>
 #include <cstring>
 
 namespace {
@@ -68,6 +69,20 @@ struct vstar_engine : EngineBase {
   // resident full images, one per slot (vstar_image_set_slot): crops of different images can share an engine batch
   struct ImageSlot { uint8_t* d = nullptr; size_t cap = 0; int H = 0, W = 0; };
   ImageSlot images[VSTAR_MAX_IMAGE_SLOTS];
+  // asynchronous uploads (vstar_image_set_slot_async): pinned staging ring + a copy stream of their own, so that the next samples'
+  // images travel to HBM while the engine stream is busy scoring; a preprocessing launch waits (on the device) for the uploads of
+  // the slots it reads.  May be called from another host thread than the scoring calls.
+  hipStream_t stream_up = nullptr;
+  hipEvent_t ev_up[VSTAR_MAX_IMAGE_SLOTS] = {};
+  std::atomic<int> up_pending[VSTAR_MAX_IMAGE_SLOTS] = {};
+  uint8_t* h_stage[2] = {nullptr, nullptr};
+  size_t stage_cap[2] = {0, 0};
+  hipEvent_t ev_stage[2] = {nullptr, nullptr};
+  bool stage_used[2] = {false, false};
+  int stage_next = 0;
+  hipEvent_t ev_pre = nullptr;                                     // recorded behind every preprocessing launch (engine stream)
+  std::atomic<int> pre_recorded{0};
+  int image_upload_async(int slot, const uint8_t* rgb, int height, int width);
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
   int32_t* d_tables = nullptr; size_t tables_cap = 0;
   PreJob* d_jobs = nullptr;
@@ -352,6 +367,10 @@ int vstar_engine::preprocess(int B, const int32_t* boxes, const int32_t* slots) 
   }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamSynchronize(stream));   // the staging vectors below are reused across calls
+  for (int b = 0; b < B; ++b) {           // images still on their way (vstar_image_set_slot_async): the engine stream waits for them
+    const int sl = slots ? slots[b] : 0;
+    if (up_pending[sl].exchange(0)) HIPCHK(hipStreamWaitEvent(stream, ev_up[sl], 0));
+  }
   const int I = cfg.clip_image_size, O = cfg.owl_image_size;
   h_tables.clear();
   h_jobs.assign((size_t)B * 2, PreJob{});
@@ -409,6 +428,50 @@ int vstar_engine::preprocess(int B, const int32_t* boxes, const int32_t* slots) 
   HIPCHK(hipMemcpyAsync(d_jobs, h_jobs.data(), h_jobs.size() * sizeof(PreJob), hipMemcpyHostToDevice, stream));
   KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_clip_pix, 0, B, I, max_h_clip, stream));
   KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_owl_pix, 1, B, O, max_h_owl, stream));
+  if (ev_pre) { HIPCHK(hipEventRecord(ev_pre, stream)); pre_recorded.store(1); }
+  return 0;
+}
+
+// Upload of one image into `slot` WITHOUT stalling the engine stream: host copy into a pinned staging buffer (two of them: the copy
+// into one overlaps the DMA out of the other), DMA on the upload stream, an event per slot that the next preprocessing of that
+// slot waits for on the device.  The caller guarantees that no crop of the slot's previous image is still to be LAUNCHED (the
+// stream driver recycles a slot only when its searches have ended); crops already launched are ordered in front of the DMA by
+// ev_pre.  Safe to call from a second host thread while another is inside a scoring call.
+int vstar_engine::image_upload_async(int slot, const uint8_t* rgb, int height, int width) {
+  HIPCHK(hipSetDevice(device));
+  const size_t bytes = (size_t)height * width * 3;
+  if (!stream_up) {
+    HIPCHK(hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&ev_stage[k], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
+  }
+  if (!ev_up[slot]) HIPCHK(hipEventCreateWithFlags(&ev_up[slot], hipEventDisableTiming));
+  ImageSlot& im = images[slot];
+  if (bytes > im.cap) {                     // first image of this size in the slot: allocate (grow-only)
+    if (up_pending[slot].load()) HIPCHK(hipEventSynchronize(ev_up[slot]));
+    if (im.d) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(im.d)); }
+    im.d = nullptr; im.cap = 0;
+    HIPCHK(hipMalloc((void**)&im.d, bytes));
+    im.cap = bytes;
+  }
+  const int k = stage_next;
+  stage_next ^= 1;
+  if (stage_used[k]) HIPCHK(hipEventSynchronize(ev_stage[k]));      // its previous DMA must have left the buffer
+  if (bytes > stage_cap[k]) {
+    if (h_stage[k]) HIPCHK(hipHostFree(h_stage[k]));
+    h_stage[k] = nullptr; stage_cap[k] = 0;
+    HIPCHK(hipHostMalloc((void**)&h_stage[k], bytes, hipHostMallocDefault));
+    stage_cap[k] = bytes;
+  }
+  memcpy(h_stage[k], rgb, bytes);
+  if (pre_recorded.load()) HIPCHK(hipStreamWaitEvent(stream_up, ev_pre, 0));
+  HIPCHK(hipMemcpyAsync(im.d, h_stage[k], bytes, hipMemcpyHostToDevice, stream_up));
+  HIPCHK(hipEventRecord(ev_stage[k], stream_up));
+  stage_used[k] = true;
+  HIPCHK(hipEventRecord(ev_up[slot], stream_up));
+  im.H = height;
+  im.W = width;
+  up_pending[slot].store(1);
   return 0;
 }
 
@@ -1004,6 +1067,10 @@ void vstar_destroy(vstar_handle* h) {
   if (h->d_stats) hipFree(h->d_stats);
   if (h->d_stats_batch) hipFree(h->d_stats_batch);
   if (h->d_up) hipFree(h->d_up);
+  if (h->stream_up) { hipStreamSynchronize(h->stream_up); hipStreamDestroy(h->stream_up); }
+  for (auto& ev : h->ev_up) if (ev) hipEventDestroy(ev);
+  for (int k = 0; k < 2; ++k) { if (h->ev_stage[k]) hipEventDestroy(h->ev_stage[k]); if (h->h_stage[k]) hipHostFree(h->h_stage[k]); }
+  if (h->ev_pre) hipEventDestroy(h->ev_pre);
   for (auto& im : h->images) if (im.d) hipFree(im.d);
   if (h->d_temp) hipFree(h->d_temp);
   if (h->d_tables) hipFree(h->d_tables);
@@ -1053,6 +1120,7 @@ int vstar_image_set_slot(vstar_handle* h, int slot, const uint8_t* rgb, int heig
   const size_t bytes = (size_t)height * width * 3;
   // crops of the slot's previous image may still be in flight on the stream
   if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
+  if (h->up_pending[slot].exchange(0)) hipEventSynchronize(h->ev_up[slot]);     // an asynchronous upload to this slot still in flight
   auto& im = h->images[slot];
   if (bytes > im.cap) {
     // (d_stats is a fixed-size scratch of vstar_heatmap_stats, independent of the image: it is NOT touched here)
@@ -1070,6 +1138,11 @@ int vstar_image_set_slot(vstar_handle* h, int slot, const uint8_t* rgb, int heig
 
 int vstar_image_set(vstar_handle* h, const uint8_t* rgb, int height, int width) { return vstar_image_set_slot(h, 0, rgb, height, width); }
 
+int vstar_image_set_slot_async(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width) {
+  if (!h || !rgb || height <= 0 || width <= 0 || slot < 0 || slot >= VSTAR_MAX_IMAGE_SLOTS) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  return h->image_upload_async(slot, rgb, height, width);
+}
+
 int vstar_preprocess_crops_slots(vstar_handle* h, int B, const int32_t* boxes_xyxy, const int32_t* slots) {
   if (!h) { tls_error() = "null handle"; return VSTAR_ERR_INVALID; }
   return h->preprocess(B, boxes_xyxy, slots);
@@ -1083,18 +1156,13 @@ int vstar_heatmap_stats(vstar_handle* h, const float* lowres, int h_out, int w_o
     tls_error() = "bad argument";
     return VSTAR_ERR_INVALID;
   }
-  hipSetDevice(h->device);
-  struct Scratch { float low[VSTAR_MASK_RES * VSTAR_MASK_RES]; double out[3 + 8]; int rects[32]; unsigned mm[2]; };
-  if (!h->d_stats) {
-    if (hipMalloc(&h->d_stats, sizeof(Scratch)) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats"); return VSTAR_ERR_NOMEM; }
-  }
-  Scratch* sc = (Scratch*)h->d_stats;
-  bool ok = hipMemcpyAsync(sc->low, lowres, sizeof(sc->low), hipMemcpyHostToDevice, h->stream) == hipSuccess;
-  if (ok && n_rects) ok = hipMemcpyAsync(sc->rects, rects_xywh, (size_t)n_rects * 16, hipMemcpyHostToDevice, h->stream) == hipSuccess;
-  ok = ok && heat_stats(sc->low, VSTAR_MASK_RES, VSTAR_MASK_RES, h_out, w_out, sc->rects, n_rects, sc->out, sc->mm, h->stream) == hipSuccess;
-  ok = ok && hipMemcpyAsync(out, sc->out, sizeof(double) * (3 + n_rects), hipMemcpyDeviceToHost, h->stream) == hipSuccess;
-  ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
-  if (!ok) { h->set_error("vstar_heatmap_stats: HIP failure"); return VSTAR_ERR_HIP; }
+  // the one-map form of vstar_heatmap_stats_batch: same kernel, same launch geometry per map, same numbers
+  int32_t hw[2] = {h_out, w_out}, rects[32] = {0};
+  if (n_rects) memcpy(rects, rects_xywh, (size_t)n_rects * 16);
+  double all[11];
+  const int rc = vstar_heatmap_stats_batch(h, 1, lowres, hw, &n_rects, rects, all);
+  if (rc != VSTAR_OK) return rc;
+  memcpy(out, all, sizeof(double) * (3 + n_rects));
   return VSTAR_OK;
 }
 
@@ -1102,29 +1170,38 @@ int vstar_heatmap_stats_batch(vstar_handle* h, int n, const float* lowres, const
                               const int32_t* rects_xywh, double* out) {
   if (!h || n < 0 || (n && (!lowres || !out_hw || !n_rects || !rects_xywh || !out))) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   if (n == 0) return VSTAR_OK;
-  for (int i = 0; i < n; ++i)
+  int64_t max_pixels = 0;
+  for (int i = 0; i < n; ++i) {
     if (out_hw[2 * i] <= 0 || out_hw[2 * i + 1] <= 0 || n_rects[i] < 0 || n_rects[i] > 8) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+    const int64_t px = (int64_t)out_hw[2 * i] * out_hw[2 * i + 1];
+    max_pixels = px > max_pixels ? px : max_pixels;
+  }
   hipSetDevice(h->device);
   constexpr size_t MAPF = (size_t)VSTAR_MASK_RES * VSTAR_MASK_RES;
-  // device scratch per item: [low MAPF f32][out 11 f64][rects 32 i32][mm 2 u32]; grown on demand
-  const size_t per = MAPF * 4 + 11 * 8 + 32 * 4 + 2 * 4;
+  // device scratch per item: [low MAPF f32][out 11 f64][rects 32 i32][mm 2 u32][hw 2 i32][n_rects 1 i32 (+1 pad)]; grown on demand.
+  // ONE launch scores all n maps (heat_stats_batch; round 3 queued three launches per map)
+  const size_t per = MAPF * 4 + 11 * 8 + 32 * 4 + 2 * 4 + 2 * 4 + 2 * 4;
   const size_t need = per * (size_t)n;
   if (need > h->stats_batch_cap) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess) { h->set_error("stream sync failed"); return VSTAR_ERR_HIP; }
     if (h->d_stats_batch) hipFree(h->d_stats_batch);
     h->d_stats_batch = nullptr; h->stats_batch_cap = 0;
-    if (hipMalloc(&h->d_stats_batch, need) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats_batch"); return VSTAR_ERR_NOMEM; }
-    h->stats_batch_cap = need;
+    const size_t want = need + need / 2;
+    if (hipMalloc(&h->d_stats_batch, want) != hipSuccess) { h->set_error("hipMalloc failed in vstar_heatmap_stats_batch"); return VSTAR_ERR_NOMEM; }
+    h->stats_batch_cap = want;
   }
   char* base = (char*)h->d_stats_batch;
   float* d_low = (float*)base;
   double* d_out = (double*)(base + MAPF * 4 * n);
   int* d_rects = (int*)(base + (MAPF * 4 + 11 * 8) * n);
   unsigned* d_mm = (unsigned*)(base + (MAPF * 4 + 11 * 8 + 32 * 4) * n);
+  int* d_hw = (int*)(base + (MAPF * 4 + 11 * 8 + 32 * 4 + 2 * 4) * n);
+  int* d_nr = (int*)(base + (MAPF * 4 + 11 * 8 + 32 * 4 + 2 * 4 + 2 * 4) * n);
   bool ok = hipMemcpyAsync(d_low, lowres, MAPF * 4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
   ok = ok && hipMemcpyAsync(d_rects, rects_xywh, (size_t)32 * 4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
-  for (int i = 0; ok && i < n; ++i)
-    ok = heat_stats(d_low + MAPF * i, VSTAR_MASK_RES, VSTAR_MASK_RES, out_hw[2 * i], out_hw[2 * i + 1], d_rects + 32 * i, n_rects[i],
-                    d_out + 11 * i, d_mm + 2 * i, h->stream) == hipSuccess;
+  ok = ok && hipMemcpyAsync(d_hw, out_hw, (size_t)2 * 4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  ok = ok && hipMemcpyAsync(d_nr, n_rects, (size_t)4 * n, hipMemcpyHostToDevice, h->stream) == hipSuccess;
+  ok = ok && heat_stats_batch(d_low, VSTAR_MASK_RES, VSTAR_MASK_RES, d_hw, d_rects, d_nr, n, max_pixels, d_out, d_mm, h->stream) == hipSuccess;
   ok = ok && hipMemcpyAsync(out, d_out, sizeof(double) * 11 * n, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
   ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
   if (!ok) { h->set_error("vstar_heatmap_stats_batch: HIP failure"); return VSTAR_ERR_HIP; }

@@ -135,9 +135,20 @@ __global__ void resize_bilinear_kernel(const float* __restrict__ in, int hin, in
 // H = clamp(bilinear(low_res -> hout x wout), 0); out = {min H, max H, sum H, sum H over each of n_rects rectangles}.
 // Same interpolation code as resize_bilinear_kernel; fp64 accumulation.
 constexpr int MAX_RECTS = 8;
-__global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict__ in, int hin, int win, int hout, int wout,
-                                                         float rh, float rw, const int* __restrict__ rects, int n_rects,
-                                                         double* __restrict__ out /*[3 + MAX_RECTS]*/, unsigned* __restrict__ mm) {
+// One launch for n maps (blockIdx.y = map): every map has its own output size and rectangles.  Per map `out` = 3 + MAX_RECTS doubles,
+// `mm` = 2 words (min / max as uint: H >= 0, so uint order == float order), `rects` = MAX_RECTS x 4 ints, `hw` = (hout, wout).
+// Block-level reduction through LDS, then ONE atomic per block and quantity (round 3: one per wave, and three launches per map —
+// a search step of 32 searches queued ~200 small launches whose atomics serialised on eleven addresses).
+__global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict__ in_all, int hin, int win, const int* __restrict__ hw,
+                                                         const int* __restrict__ rects_all, const int* __restrict__ n_rects_all,
+                                                         double* __restrict__ out_all, unsigned* __restrict__ mm_all) {
+  const int item = blockIdx.y;
+  const float* in = in_all + (size_t)item * hin * win;
+  const int hout = hw[2 * item], wout = hw[2 * item + 1], n_rects = n_rects_all[item];
+  const int* rects = rects_all + item * MAX_RECTS * 4;
+  double* out = out_all + item * (3 + MAX_RECTS);
+  unsigned* mm = mm_all + item * 2;
+  const float rh = (float)hin / (float)hout, rw = (float)win / (float)wout;
   const int64_t total = (int64_t)hout * wout;
   float mn = INFINITY, mx = 0.f;
   double sum = 0.0, rs[MAX_RECTS];
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict
     for (int k = 0; k < MAX_RECTS; ++k)
       if (x >= rx[k] && x < rx1[k] && y >= ry[k] && y < ry1[k]) rs[k] += hv;
   }
-  // wave reduce, then one atomic per wave
+  // wave reduce -> LDS -> one atomic per block
   for (int o = 32; o > 0; o >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, o, 64));
     mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -174,36 +185,52 @@ __global__ __launch_bounds__(256) void heat_stats_kernel(const float* __restrict
 #pragma unroll
     for (int k = 0; k < MAX_RECTS; ++k) rs[k] += __shfl_xor(rs[k], o, 64);
   }
+  __shared__ double s_sum[4][1 + MAX_RECTS];
+  __shared__ float s_mn[4], s_mx[4];
+  const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], __float_as_uint(mn));     // H >= 0: uint order == float order
-    atomicMax(&mm[1], __float_as_uint(mx));
-    atomicAdd(&out[2], sum);
-    for (int k = 0; k < n_rects; ++k) atomicAdd(&out[3 + k], rs[k]);
+    s_mn[wave] = mn; s_mx[wave] = mx; s_sum[wave][0] = sum;
+#pragma unroll
+    for (int k = 0; k < MAX_RECTS; ++k) s_sum[wave][1 + k] = rs[k];
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicMin(&mm[0], __float_as_uint(fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]))));
+    atomicMax(&mm[1], __float_as_uint(fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]))));
+  }
+  if (threadIdx.x <= n_rects)
+    atomicAdd(&out[2 + threadIdx.x], (s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x]) + (s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x]));
 }
-__global__ void heat_stats_init(double* out, unsigned* mm) {
-  if (threadIdx.x < 3 + MAX_RECTS) out[threadIdx.x] = 0.0;
-  if (threadIdx.x == 0) { mm[0] = 0x7f800000u; mm[1] = 0u; }
+__global__ void heat_stats_init(double* out, unsigned* mm, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n * (3 + MAX_RECTS)) out[i] = 0.0;
+  if (i < n) { mm[2 * i] = 0x7f800000u; mm[2 * i + 1] = 0u; }
 }
-__global__ void heat_stats_finish(double* out, const unsigned* mm) {
-  out[0] = (double)__uint_as_float(mm[0]);
-  out[1] = (double)__uint_as_float(mm[1]);
+__global__ void heat_stats_finish(double* out, const unsigned* mm, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i * (3 + MAX_RECTS)] = (double)__uint_as_float(mm[2 * i]);
+  out[i * (3 + MAX_RECTS) + 1] = (double)__uint_as_float(mm[2 * i + 1]);
 }
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,
-                      unsigned* mm_scratch, hipStream_t s) {
-  if (n_rects < 0 || n_rects > MAX_RECTS) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(heat_stats_init, dim3(1), dim3(64), 0, s, out, mm_scratch);     // zero the sums, min := +inf, max := 0
-  const int64_t total = (int64_t)hout * wout;
-  unsigned blocks = (unsigned)((total + 255) / 256);
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(heat_stats_kernel, dim3(blocks), dim3(256), 0, s, lowres, hin, win, hout, wout, (float)hin / (float)hout,
-                     (float)win / (float)wout, rects, n_rects, out, mm_scratch);
-  hipLaunchKernelGGL(heat_stats_finish, dim3(1), dim3(1), 0, s, out, mm_scratch);
+// n maps in one launch.  Device arrays: lowres [n][hin*win], hw [n][2] = (hout, wout), rects [n][MAX_RECTS*4], n_rects [n],
+// out [n][3+MAX_RECTS], mm [n][2].  max_pixels = the largest hout*wout among the maps (sizes the grid).
+hipError_t heat_stats_batch(const float* lowres, int hin, int win, const int* hw, const int* rects, const int* n_rects, int n,
+                            int64_t max_pixels, double* out, unsigned* mm_scratch, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int cells = n * (3 + MAX_RECTS);
+  hipLaunchKernelGGL(heat_stats_init, dim3((cells + 255) / 256), dim3(256), 0, s, out, mm_scratch, n);
+  // >= 8 pixels per thread, at most 256 blocks per map (one block per CU for a 4K map; the small maps of deep nodes take fewer)
+  int64_t bx = (max_pixels + 256 * 8 - 1) / (256 * 8);
+  if (bx < 1) bx = 1;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(heat_stats_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, s, lowres, hin, win, hw, rects, n_rects, out,
+                     mm_scratch);
+  hipLaunchKernelGGL(heat_stats_finish, dim3((n + 255) / 256), dim3(256), 0, s, out, mm_scratch, n);
   return hipGetLastError();
 }
 

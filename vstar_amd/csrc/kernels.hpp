@@ -156,9 +156,10 @@ hipError_t hyper_mask(const lp_t* hyper, const lp_t* up, float* out, int out_str
 // bilinear resize (align_corners=False) of fp32 [hin,win] -> [hout,wout], then clamp(min=0) unless clamp_min0 == 0
 hipError_t resize_bilinear_clamp(const float* in, int hin, int win, float* out, int hout, int wout, hipStream_t s, int clamp_min0 = 1);
 
-// min / max / total / rectangle sums of clamp(bilinear(lowres -> hout x wout), 0); out = double[3 + 8], mm_scratch = unsigned[2]
-hipError_t heat_stats(const float* lowres, int hin, int win, int hout, int wout, const int* rects, int n_rects, double* out,
-                      unsigned* mm_scratch, hipStream_t s);
+// min / max / total / rectangle sums of clamp(bilinear(lowres -> hout x wout), 0) for n maps in ONE launch (device arrays: lowres
+// [n][hin*win], hw [n][2] = (hout, wout), rects [n][32], n_rects [n], out [n][3 + 8] doubles, mm_scratch [n][2])
+hipError_t heat_stats_batch(const float* lowres, int hin, int win, const int* hw, const int* rects, const int* n_rects, int n,
+                            int64_t max_pixels, double* out, unsigned* mm_scratch, hipStream_t s);
 
 // ---- GPU-side crop preprocessing (preprocess.hip) ----
 struct PreJob {            // one (crop, target) pair; jobs are stored as [crop][0 = CLIP, 1 = OWL-ViT]

@@ -186,6 +186,17 @@ class VstarEngine:
         _lib.check(self.lib.vstar_image_set_slot(self.handle, int(slot), arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
                    self.handle)
 
+    def set_image_async(self, image, slot: int = 0) -> None:
+        """set_image without stalling the scoring stream (vstar_image_set_slot_async): the pixels are staged in pinned memory before
+        this returns and travel on a copy stream; the next preprocessing of the slot waits for them on the device.  Thread-safe
+        against a scoring call in progress on another thread — the stream search calls it from its prefetch thread."""
+        if hasattr(image, "convert") and getattr(image, "mode", None) != "RGB":
+            image = image.convert("RGB")
+        arr = np.ascontiguousarray(np.asarray(image, dtype=np.uint8))
+        assert arr.ndim == 3 and arr.shape[2] == 3
+        _lib.check(self.lib.vstar_image_set_slot_async(self.handle, int(slot), arr.ctypes.data_as(ctypes.c_void_p), arr.shape[0], arr.shape[1]),
+                   self.handle)
+
     def _preprocess(self, boxes: np.ndarray, slots) -> None:
         sp = None
         if slots is not None:

@@ -111,9 +111,15 @@ class LazyExactPrioritize(Prioritize):
     REL_TOL = 1e-4          # >= 10 x the measured disagreement between the two arithmetic paths
     n_exact = 0             # diagnostics: how often the exact path was needed
 
-    def __init__(self, priority, item, exact):
+    def __init__(self, priority, item, exact, exact_zero: bool = False):
         super().__init__(priority, item)
         self._exact_fn, self._exact = exact, None
+        # the score is 0 in the REFERENCE's float32 arithmetic too, not just nearly: every contribution was a sum over pixels that
+        # are all exactly zero (clamped heat map, min 0) or one of the reference's own "return 0" cases.  Two such entries are an
+        # exact tie in both arithmetics: no materialised heat map is needed to order them.  (A trained segmentation head is negative
+        # on the background, so clamped heat maps are zero over most children: with trained-like weights 160 of 336 pushes of the
+        # config-2 search leg took the exact path, 18 ms each, until round 4.)
+        self.exact_zero = bool(exact_zero)
 
     def exact(self):
         if self._exact is None:
@@ -122,6 +128,8 @@ class LazyExactPrioritize(Prioritize):
         return self._exact
 
     def _near(self, other):
+        if self.exact_zero and getattr(other, "exact_zero", False):
+            return False
         a, b = float(self.priority), float(other.priority)
         return abs(a - b) <= self.REL_TOL * max(abs(a), abs(b)) + 1e-12
 
@@ -398,18 +406,24 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
             def rect_scores(owner, stats):
                 hs = owner["heat_stats"]
                 mn, mx = hs["min"], hs["max"]
+                nsub = len(basic_sub_patches)
                 if not mx != mn:
-                    return [0.0] * len(basic_sub_patches)
+                    return [0.0] * nsub, [True] * nsub
                 area = owner["bbox"][2] * owner["bbox"][3]
                 total = (hs["sum"] - mn * area) / (mx - mn)
                 if not total > 0:
-                    return [0.0] * len(basic_sub_patches)
-                return [((stats[3 + k] - mn * sp[2] * sp[3]) / (mx - mn)) / total for k, sp in enumerate(basic_sub_patches)]
+                    return [0.0] * nsub, [True] * nsub
+                # a rectangle whose fp64 sum of the (non-negative) clamped map is exactly 0 holds only zeros: with min == 0 its
+                # normalised float32 sum is exactly 0 in the reference as well
+                zero = [mn == 0.0 and stats[3 + k] == 0.0 for k in range(nsub)]
+                return [((stats[3 + k] - mn * sp[2] * sp[3]) / (mx - mn)) / total for k, sp in enumerate(basic_sub_patches)], zero
 
             basic_sub_scores = [0.0] * len(basic_sub_patches)
+            sub_exact_zero = [True] * len(basic_sub_patches)
             tmp_patch, tmp_stats = current_patch, st
             while True:
-                sc = rect_scores(tmp_patch, tmp_stats)
+                sc, zr = rect_scores(tmp_patch, tmp_stats)
+                sub_exact_zero = [a and b for a, b in zip(sub_exact_zero, zr)]
                 basic_sub_scores = [basic_sub_scores[i] + sc[i] / (4 ** tmp_patch["scale_level"]) for i in range(len(sc))]
                 if tmp_patch["parent_index"] == -1:
                     break
@@ -438,7 +452,8 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
             for k, (sub_patch, sub_score) in enumerate(zip(basic_sub_patches, basic_sub_scores)):
                 info = {"bbox": sub_patch, "scale_level": level + 1, "score": np.float32(sub_score),
                         "parent_index": current_patch_index}
-                queue.put(LazyExactPrioritize(-info["score"], info, lambda k=k, f=exact_scores: f()[k]))
+                queue.put(LazyExactPrioritize(-info["score"], info, lambda k=k, f=exact_scores: f()[k],
+                                              exact_zero=sub_exact_zero[k] and float(sub_score) == 0.0))
         elif expand:
             heat = target_cue_heatmap.view(bbox[3], bbox[2], 1)
             score_max = heat.max().item()
@@ -573,8 +588,16 @@ def _run_loader(loader):
     return image
 
 
+def _run_loader_upload(vsm, image, slot):
+    """Prefetch-thread work for a sample whose image slot could be reserved ahead: load / decode AND start the upload
+    (VSM.set_image_async: pinned staging + a copy stream) while the main thread is inside an engine step."""
+    image = _run_loader(image) if callable(image) else image
+    vsm.set_image_async(image, slot)
+    return image
+
+
 def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: Optional[SpeculationPolicy] = None,
-                         stats: Optional[dict] = None, prefetch: int = 2, **kw):
+                         stats: Optional[dict] = None, prefetch: int = 8, **kw):
     """Cross-image lock-step search: `samples` = iterable of (image, target_object_name, target_bbox, smallest_size) — `image` a
     PIL image or a zero-argument loader returning one (called when the sample enters the window; loaders with the same `.key`, or
     the same loader object, share an image slot; `smallest_size` may then be a callable of the loaded image); returns the
@@ -589,8 +612,11 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     object share its slot).  Per (image, target) the decisions are exactly those of `visual_search`: with batch-invariant records
     (plain batches, or group_prompts = "always") the results are bit-identical to the per-sample loop.
 
-    prefetch: how many of the upcoming samples' image loaders run ahead of the window on a worker thread (host work only — open +
-    decode; the upload stays on the calling thread, in sample order) while the engine is busy; 0 = load when the sample enters.
+    prefetch: how many of the upcoming samples' images are prepared ahead of the window on a worker thread while the engine is
+    busy: the loader runs there (open + decode) and — with an engine that offers asynchronous uploads (VSM.supports_async_upload)
+    and a spare image slot to reserve — so does the upload (pinned staging, copy stream; the first preprocessing of the slot waits
+    for it on the device), which takes image transfer off the serial path between two engine steps (round 4: it was 7 % of the
+    one-GPU stream and would not shrink with more ranks).  0 = everything when the sample enters the window.
     A loader is called once per residency of its image: samples that are live together share one slot and one call; when the
     last of them has ended the slot (and the host copy) is released, and a LATER sample with the same key loads the image again.
     Nothing about the results depends on it.
@@ -619,7 +645,8 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     n_slots = int(getattr(vsm, "max_image_slots", 64))
     window = max(1, min(window or cap, n))
     plan_bs, plan_spec = kw.get("batch_size"), kw.get("speculate", True)
-    kw = {k: v for k, v in kw.items() if k not in ("batch_size", "speculate", "stats")}
+    want_async = bool(kw.get("async_upload", True))
+    kw = {k: v for k, v in kw.items() if k not in ("batch_size", "speculate", "stats", "async_upload")}
     own_plans = bool(getattr(policy, "per_search_plan", False))      # visual_search_many: every search plans its own step
 
     slot_of: Dict[int, int] = {}                  # id(image) -> slot
@@ -635,36 +662,50 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     loaded: Dict[object, object] = {}             # slot key -> the PIL image living in that slot
     pending: Dict[object, object] = {}            # slot key -> Future of a loader running ahead (prefetch)
     pool = None
-    if prefetch > 0 and any(callable(smp[0]) for smp in samples):
+    async_up = bool(getattr(vsm, "supports_async_upload", False)) and want_async
+    if prefetch > 0 and (async_up or any(callable(smp[0]) for smp in samples)):
         from concurrent.futures import ThreadPoolExecutor
         pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vstar-image-prefetch")
+    n_async = 0
 
     def prefetch_ahead():
-        # loaders of the next samples that are not in the window yet, in sample order, at most `prefetch` in flight or waiting
+        # images of the next samples that are not in the window yet, in sample order, at most `prefetch` in flight or waiting.
+        # pending[key] = (future, reserved slot or None)
+        nonlocal n_async
         if pool is None:
             return
         i = next_sample
         while i < n and len(pending) < prefetch:
             image = samples[i][0]
-            if callable(image):
-                key = getattr(image, "key", id(image))
-                if key not in slot_of and key not in pending:
-                    pending[key] = pool.submit(_run_loader, image)
+            key = getattr(image, "key", id(image))
+            if key not in slot_of and key not in pending:
+                if async_up and free_slots:
+                    sl = free_slots.pop()
+                    pending[key] = (pool.submit(_run_loader_upload, vsm, image, sl), sl)
+                    n_async += 1
+                elif callable(image):
+                    pending[key] = (pool.submit(_run_loader, image), None)
             i += 1
 
     def start(i):
         image, name, gt, smallest = samples[i]
         key = getattr(image, "key", id(image))
         if key not in slot_of:
-            if not free_slots:
+            fut, reserved = pending.get(key, (None, None))
+            if reserved is None and not free_slots:
                 return False
-            if key in pending:
-                loaded[key] = pending.pop(key).result()
+            if fut is not None:
+                del pending[key]
+                loaded[key] = fut.result()
             else:
                 loaded[key] = image() if callable(image) else image
-            slot_of[key] = free_slots.pop()
-            slot_refs[slot_of[key]] = 0
-            vsm.set_image(loaded[key]) if slot_of[key] == 0 else vsm.set_image(loaded[key], slot_of[key])
+            if reserved is not None:                # loaded AND already on its way to the slot (prefetch thread)
+                slot_of[key] = reserved
+                slot_refs[reserved] = 0
+            else:
+                slot_of[key] = free_slots.pop()
+                slot_refs[slot_of[key]] = 0
+                vsm.set_image(loaded[key]) if slot_of[key] == 0 else vsm.set_image(loaded[key], slot_of[key])
         image = loaded[key]
         if callable(smallest):
             smallest = smallest(image)
@@ -794,7 +835,7 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         for g in list(gens.values()):
             g.close()
         if pool is not None:
-            for f in pending.values():
+            for f, _ in pending.values():
                 f.cancel()
             pool.shutdown(wait=True)
     _fill_stream_stats(stats, per_stats, engine_steps)
@@ -802,6 +843,8 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         # launches of an engine scoring entry point (a step can take several: batch cap, prompt-count buckets); engine_steps counts
         # the driver's scoring rounds
         stats["engine_calls"] = int(vsm.timers.get("engine_calls", 0)) - calls0
+    if stats is not None:
+        stats["async_uploads"] = n_async
     return results
 
 

@@ -280,6 +280,20 @@ class VSM:
         else:
             self.engine.set_image(image, int(slot))
 
+    @property
+    def supports_async_upload(self) -> bool:
+        return hasattr(self.engine, "set_image_async")
+
+    def set_image_async(self, image: Image.Image, slot: int) -> None:
+        """set_image for a slot no live search uses yet, without stalling the scoring stream (engine.set_image_async).  Called by the
+        stream search's prefetch thread while the main thread is inside an engine step."""
+        if not hasattr(self, "_images"):
+            self._images = {}
+        self._images[int(slot)] = image
+        if slot == 0:
+            self._image = image
+        self.engine.set_image_async(image, int(slot))
+
     def release_image(self, slot: int = 0) -> None:
         """The stream driver recycled `slot`: drop the host-side PIL image kept for the decode fallback (a 4K RGB image is 25 MB;
         64 slots of them were never released).  The device copy is simply overwritten by the next set_image."""

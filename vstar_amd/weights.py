@@ -251,7 +251,7 @@ def template_chain(tokenizer, question: str = "Please locate the object in this 
 
 
 def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = torch.bfloat16, share_layers: bool = True,
-                            chain=None) -> Dict[str, torch.Tensor]:
+                            chain=None, features=("outliers", "attn", "norms")) -> Dict[str, torch.Tensor]:
     """Seeded weights with the STATISTICS of a trained checkpoint rather than i.i.d. N(0, s) (VERDICT r3 "missing" #2): the
     structures that decide where bf16 / fp8 rounding bites in a real LLaMA-7B / CLIP-L, which random_state_dict lacks.
 
@@ -267,7 +267,9 @@ def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = 
         strict_template=True path of VSM.inference runs at real widths.  The transformer layers stay
         non-trivial (unlike the zeroed-o/down bigram model of tests/test_template_fallback_gpu.py).
 
+    `features` switches the three structures individually (error-attribution probes: tools/owl_error_probe.py); the default is all.
     Derived from random_state_dict(seed) tensor by tensor, so the key set / shapes / reproducibility rules are the same."""
+    f_out, f_attn, f_norm = ("outliers" in features), ("attn" in features), ("norms" in features)
     sd = random_state_dict(cfg, seed=seed, dtype=torch.float32, share_layers=share_layers)
     g = torch.Generator().manual_seed(seed * 7919 + 17)
     done = set()
@@ -298,17 +300,20 @@ def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = 
         lp = f"model.layers.{i}."
         for nm in ("self_attn.o_proj.weight", "mlp.down_proj.weight"):
             t = once(lp + nm)
-            if t is not None:
+            if t is not None and f_out:
                 t[ch] *= amp[:, None]
         q, k = once(lp + "self_attn.q_proj.weight"), once(lp + "self_attn.k_proj.weight")
-        if q is not None and k is not None:
+        if q is not None and k is not None and f_attn:
             k.copy_(0.7 * q + math.sqrt(1 - 0.49) * k)
             q *= 3.0
-        spread_gain(lp + "input_layernorm.weight", ch, 0.4, 0.5, 0.05)
-        spread_gain(lp + "post_attention_layernorm.weight", ch, 0.4, 0.5, 0.05)
-    spread_gain("model.norm.weight", ch, 1.0, 0.3, 0.05)
+        if f_norm:
+            spread_gain(lp + "input_layernorm.weight", ch, 0.4, 0.5, 0.05)
+            spread_gain(lp + "post_attention_layernorm.weight", ch, 0.4, 0.5, 0.05)
+    if f_norm:
+        spread_gain("model.norm.weight", ch, 1.0, 0.3, 0.05)
     E = sd["model.embed_tokens.weight"]
-    E[1, ch[:2]] = torch.tensor([60.0, -60.0])[: len(ch[:2])]
+    if f_out:
+        E[1, ch[:2]] = torch.tensor([60.0, -60.0])[: len(ch[:2])]
     if chain:
         W = sd["lm_head.weight"]
         for t, _ in chain:
@@ -320,19 +325,24 @@ def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = 
     for prefix, pre, hidden, layers in ((CLIP_PREFIX + "vision_model.", "pre_layrnorm", cfg.clip_hidden, cfg.clip_layers),
                                         ("model.owlvit.vision_model.", "pre_layernorm", cfg.owl_hidden, cfg.owl_layers)):
         vch, vamp = outliers(hidden, max(2, hidden // 256), 8.0, 25.0)
-        spread_gain(prefix + pre + ".weight", vch, 1.0, 0.4, 0.3)
+        if f_norm:
+            spread_gain(prefix + pre + ".weight", vch, 1.0, 0.4, 0.3)
         for i in range(layers):
             lp = f"{prefix}encoder.layers.{i}."
             for nm in ("self_attn.out_proj", "mlp.fc2"):
                 t = once(lp + nm + ".weight")
                 if t is not None:
-                    t[vch] *= vamp[:, None]
-                    sd[lp + nm + ".bias"][vch] = 1.5 * torch.sign(torch.randn(len(vch), generator=g))
+                    sgn = torch.sign(torch.randn(len(vch), generator=g))      # (drawn whatever the switches: one stream of draws)
+                    if f_out:
+                        t[vch] *= vamp[:, None]
+                        sd[lp + nm + ".bias"][vch] = 1.5 * sgn
             q, k = once(lp + "self_attn.q_proj.weight"), once(lp + "self_attn.k_proj.weight")
-            if q is not None and k is not None:
+            if q is not None and k is not None and f_attn:
                 k.copy_(0.7 * q + math.sqrt(1 - 0.49) * k)
                 q *= 2.0
             for nm in ("layer_norm1", "layer_norm2"):
+                if not f_norm:
+                    continue
                 spread_gain(lp + nm + ".weight", vch, 0.7, 0.4, 0.1)
                 b = once(lp + nm + ".bias")
                 if b is not None:
