@@ -90,7 +90,7 @@ def _bench_state_dict(cfg, args):
     return random_state_dict(cfg, seed=0, dtype=torch.bfloat16, share_layers=True)
 
 
-def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
+def search_leg(eng, cfg, args, rank: int, group: bool = False, geometry=None, targets: int = 0, record_paths: bool = False) -> dict:
     """BASELINE config 2 LITERALLY (SURVEY §8d "searched crops/s"): one synthetic 3840x2160 image, `--search-targets` targets,
     exhaustive depth-3 search tree (smallest_size = 540: 1 + 4 + 16 = 21 nodes per target), crops scored in 32-crop engine
     batches, with EVERYTHING the search loop does inside the timed region: image upload, GPU-side crop / pad / Pillow-exact
@@ -106,6 +106,8 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
     # config 5 (--config5): 8K image, --minimum_size_scale 16 -> smallest_size 270 -> depth-5 tree (341 nodes per target)
     W, H = (7680, 4320) if args.config5 else (3840, 2160)
     scale = 16.0 if args.config5 else 4.0
+    if geometry is not None:
+        W, H, scale = geometry
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=_strict(args))
@@ -114,7 +116,7 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
         vsm.shard_crops = bool(getattr(args, "rccl_selfcheck", False))
         vsm.group_prompts = group                # False: every (crop, target) pair is a full pass, like the reference's loop
         smallest = smallest_size_for(W, H, scale)
-        names = [f"object {i}" for i in range(args.search_targets)]
+        names = [f"object {i}" for i in range(targets or args.search_targets)]
         kw = dict(confidence_high=2.0, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
         visual_search_many(vsm, synthetic_image(W, H, 1000 + rank), names[:2], None, smallest, **kw)       # warm-up (untimed)
         for k in vsm.timers:
@@ -122,8 +124,9 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
         LazyExactPrioritize.n_exact = 0
         img = synthetic_image(W, H, rank)
         torch.cuda.synchronize()
+        st_many = {"keep_paths": True} if record_paths else {}
         t0 = time.perf_counter()
-        res = visual_search_many(vsm, img, names, None, smallest, **kw)
+        res = visual_search_many(vsm, img, names, None, smallest, stats=st_many, **kw)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     crops = int(vsm.timers["crops"])
@@ -140,10 +143,24 @@ def search_leg(eng, cfg, args, rank: int, group: bool = False) -> dict:
             "stage_s": {"engine_incl_gpu_preprocess_and_record_d2h": round(t["engine_s"], 3),
                         "heatmap_statistics": round(t["post_s"], 3), "host_preprocess": round(t["preprocess_s"], 3),
                         "decisions_prompting_and_other_host": round(dt - t["engine_s"] - t["post_s"] - t["preprocess_s"] - t["gather_s"], 3)},
-            "path_lengths": [int(r[1]) for r in res]}
+            "path_lengths": [int(r[1]) for r in res],
+            **({"visit_orders": st_many.get("visit_orders", [])} if record_paths else {})}
 
 
-def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> dict:
+class _SynthLoader:
+    """A sample's image as a LOADER (what visual_search.py's loop does with Image.open): generated when the sample is about to
+    enter the window — on the stream search's prefetch thread — instead of 100+ images of 25 MB held up front by every rank."""
+
+    def __init__(self, w, h, seed):
+        self.w, self.h, self.seed, self.key = w, h, seed, ("synthetic", w, h, seed)
+
+    def __call__(self):
+        from vstar_amd.synthetic import synthetic_image
+        return synthetic_image(self.w, self.h, self.seed)
+
+
+def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops", group_prompts=False, window: int = 0, samples_cap: int = 0,
+               speculate: bool = True) -> dict:
     """BEST-FIRST searches that really stop: `--stream-samples` (image, target) samples — 4K synthetic
     images, `--stream-targets-per-image` targets each — searched by visual_search_stream in a window of concurrent searches
     (cross-image lock step, image slots, cost-aware speculation).  Seeded random weights have no notion of 'found', so the
@@ -153,7 +170,13 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
     visual_search.py:536-560 scores exactly these), engine records/s, the wasted (speculated, never visited) fraction, path lengths.
     world > 1: STRONG scaling of this fixed job — shard 'crops' (every rank walks the same searches, each engine step's crops dealt
     over the ranks, records all-gathered over RCCL: the north-star layout) or 'samples' (searches dealt over the ranks, no data-path
-    collective, results gathered at the end)."""
+    collective, results gathered at the end).
+    Round 4: the job is sized to the world (>= 2 x window x ranks samples, so the per-rank batches of a sharded run are not starved
+    by the tail of the job); images are LOADERS generated when their sample approaches the window (prefetch thread: load + upload
+    overlap the engine step); `host_serial_frac` = the share of the wall time in which no scoring step was running (uploads,
+    heat-map statistics, decisions — what every rank repeats under crop sharding); group_prompts = True is the SHIPPED default of
+    the VSM class (shared-prefix entry point for every locate prompt), False the plain batches whose records are bit-identical to
+    the per-sample loop's; window = 1 with / without speculation is the latency regime of a lone search."""
     import warnings
     import torch.distributed as dist
     from vstar_amd.preprocess import SyntheticTokenizer
@@ -164,15 +187,20 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
     on_gpu = torch.cuda.is_available() and not getattr(args, "fake_engine", False)
     red_dev = f"cuda:{eng.device}" if on_gpu else "cpu"
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
-    n_img = max(args.stream_samples // args.stream_targets_per_image, 1)
+    win = window or args.stream_window or cfg.max_batch * (world if shard == "crops" else 1)
+    n_samples = args.stream_samples if getattr(args, "fake_engine", False) else max(args.stream_samples, 2 * cfg.max_batch * world)
+    if samples_cap:
+        n_samples = min(n_samples, samples_cap)
+    n_img = max(n_samples // args.stream_targets_per_image, 1)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=_strict(args))
         vsm.shard_crops = (shard == "crops") and (world > 1 or bool(getattr(args, "rccl_selfcheck", False)))
-        vsm.group_prompts = False                     # plain batches: records bit-identical to the per-sample loop
+        vsm.group_prompts = group_prompts             # False = plain batches: records bit-identical to the per-sample loop
         smallest = smallest_size_for(W, H, 4.0)
-        images = [synthetic_image(W, H, 2000 + k) for k in range(n_img)]
-        samples = [(images[k], f"object {t}", None, smallest) for k in range(n_img) for t in range(args.stream_targets_per_image)]
+        images = [synthetic_image(W, H, 2000 + k) for k in range(min(n_img, 8))]       # calibration set; the job itself uses loaders
+        loaders = [_SynthLoader(W, H, 2000 + k) for k in range(n_img)]
+        samples = [(loaders[k], f"object {t}", None, smallest) for k in range(n_img) for t in range(args.stream_targets_per_image)]
         base = dict(confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
         # ---- calibration (untimed, every rank identically): top scores of the roots and of some first-level children ----
         vsm.set_image(images[0])
@@ -195,7 +223,8 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
         sync()
         st = {}
         t0 = time.perf_counter()
-        res = visual_search_stream(vsm, mine, window=args.stream_window or None, stats=st, confidence_high=conf_high, **base)
+        res = visual_search_stream(vsm, mine, window=win if (window or args.stream_window) else None, stats=st, confidence_high=conf_high,
+                                   speculate=speculate, **base)
         sync()
         dt = time.perf_counter() - t0
     t = dict(vsm.timers)
@@ -233,8 +262,11 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops") -> d
             "per_rank_crops_per_step": round(st["crops_scored"] / steps / (world if shard == "crops" else 1), 2),
             "mean_nodes_visited_per_search": round(float(np.mean(visited)), 2) if visited else None,
             "mean_reported_path_length": round(float(np.mean(paths)), 2),
-            "window": args.stream_window or cfg.max_batch * (world if shard == "crops" else 1), "shard": shard, "ranks": world,
-            "images": f"{n_img} x {W}x{H} synthetic, {args.stream_targets_per_image} targets each, depth-3 trees (smallest_size {smallest})",
+            "window": win, "shard": shard, "ranks": world, "group_prompts": group_prompts, "speculate": speculate,
+            "engine_calls": int(st.get("engine_calls", st["engine_steps"])), "async_image_uploads": int(st.get("async_uploads", 0)),
+            "host_serial_frac": round(max(0.0, 1.0 - float(t["engine_s"]) / dt), 4) if dt > 0 else None,
+            "images": f"{n_img} x {W}x{H} synthetic (generated by the prefetch thread as their samples approach the window), "
+                      f"{args.stream_targets_per_image} targets each, depth-3 trees (smallest_size {smallest})",
             "confidence_high_calibrated": round(conf_high, 6),
             "stage_s": {"engine_incl_gpu_preprocess": round(t["engine_s"], 3), "record_allgather_and_d2h": round(t["gather_s"], 3),
                         "heatmap_statistics": round(t["post_s"], 3),
@@ -382,6 +414,8 @@ def main():
     ap.add_argument("--stream-targets-per-image", type=int, default=2)
     ap.add_argument("--stream-window", type=int, default=0, help="concurrent searches of the stream leg (0 = one engine batch x ranks)")
     ap.add_argument("--no-stream-leg", action="store_true")
+    ap.add_argument("--no-latency-leg", action="store_true", help="skip the default-VSM stream run and the window-1 latency legs")
+    ap.add_argument("--latency-samples", type=int, default=24, help="(image, target) samples of each window-1 latency run")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1/2/4/8 crops-per-rank table")
     ap.add_argument("--no-config5-line", action="store_true", help="skip the bounded W8A8 (BASELINE config 5 precision) sub-object")
     ap.add_argument("--no-search-leg", action="store_true", help="skip the end-to-end search leg (N = 1 only by default)")
@@ -555,36 +589,94 @@ def main():
             small = small_batch_table(eng, cfg, args, dev, T)
         except Exception as exc:
             small = {"error": f"{type(exc).__name__}: {exc}"}
-    # BASELINE config 5 precision (fp8 W8A8 LLaMA linears), bounded: the same step on a second engine, a few steps — so that the
-    # driver's default command carries a config-5 number (VERDICT r2 missing #6); `bench.py --config5` is the full config-5 line
+    # the SHIPPED default of the VSM class (group_prompts = True -> every locate prompt through the shared-prefix entry point) under
+    # the stream driver, and the latency regime where the speculation policy acts (a lone search at a time: window 1), with and
+    # without speculation — N = 1 only, bounded sample counts
+    stream_default = latency = None
+    if world == 1 and stream is not None and "error" not in stream and not args.no_latency_leg:
+        try:
+            stream_default = stream_leg(eng, cfg, args, world, rank, "crops", group_prompts=True)
+        except Exception as exc:
+            stream_default = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            lat = {}
+            for name, spec in (("speculate", True), ("no_speculation", False)):
+                r = stream_leg(eng, cfg, args, world, rank, "crops", window=1, samples_cap=args.latency_samples, speculate=spec)
+                lat[name] = {"ms_per_search": round(r["wall_s"] / max(r["searches"], 1) * 1e3, 1), "searches": r["searches"],
+                             "crops_scored": r["crops_scored"], "crops_visited": r["useful_crops"],
+                             "wasted_crop_frac": r["wasted_crop_frac"], "engine_steps": r["engine_steps"],
+                             "mean_crops_per_step": r["mean_crops_per_step"], "wall_s": r["wall_s"]}
+            lat["speedup_from_speculation"] = round(lat["no_speculation"]["ms_per_search"] / max(lat["speculate"]["ms_per_search"], 1e-9), 3)
+            lat["note"] = ("window 1: one (image, target) search at a time, the reference's schedule (visual_search.py:536-560); "
+                           "SpeculationPolicy scores likely-next crops in the same engine step")
+            latency = lat
+        except Exception as exc:
+            latency = {"error": f"{type(exc).__name__}: {exc}"}
+    # BASELINE config 5 (fp8 W8A8 LLaMA linears, 64-crop batches, 8K image, depth-5 tree), bounded to a few seconds inside the default
+    # command: the batch path at 64 crops with its own roofline (fp8 MFMA GEMMs timed by HIP events, peak 5 PF), the literal search
+    # leg on ONE target (341 crops), and the same search on the bf16 engine as the decision yardstick (visit order, final node)
     config5 = None
     if world == 1 and not args.fp8 and not args.no_config5_line and not args.skip_owl and not args.tiny:
         try:
-            cfg8 = VSMConfig.seal_7b(args.image_size, max_batch=B, max_text_len=L, llm_w8a8=1)
+            B8 = 64
+            cfg8 = VSMConfig.seal_7b(args.image_size, max_batch=B8, max_text_len=L, llm_w8a8=1)
             eng8 = VstarEngine(cfg8, local_rank)
             eng8.load_state_dict(_bench_state_dict(cfg8, args))
-            rec8 = torch.empty((B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
+            clip8, owl8, ids8, loc8, verify8 = bench_inputs(cfg8, B8, T, rank)
+            clip8, owl8 = clip8.to(dev), owl8.to(dev)
+            rec8 = torch.empty((B8, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
 
             def step8():
                 _lib.check(eng8.lib.vstar_vsm_score_batch(
-                    eng8.handle, B, vp(clip.data_ptr()), vp(owl.data_ptr()), ids.ctypes.data_as(vp), L, loc.ctypes.data_as(vp),
-                    verify.ctypes.data_as(vp), nv, flags, vp(rec8.data_ptr())), eng8.handle)
+                    eng8.handle, B8, vp(clip8.data_ptr()), vp(owl8.data_ptr()), ids8.ctypes.data_as(vp), L, loc8.ctypes.data_as(vp),
+                    verify8.ctypes.data_as(vp), nv, flags, vp(rec8.data_ptr())), eng8.handle)
             for _ in range(2):
                 step8()
             torch.cuda.synchronize()
             t8 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(3):
                 step8()
             torch.cuda.synchronize()
-            ms8 = (time.perf_counter() - t8) / 5 * 1e3
-            # decision-level agreement with the bf16 engine on this batch (the reference has no fp8 path: the bf16 records just
-            # computed are the yardstick): same arg-max box / same best child per crop
-            a, b8 = rec_dev.cpu().numpy(), rec8.cpu().numpy()
-            same_box = float(np.mean(a[:, :2304].argmax(1) == b8[:, :2304].argmax(1)))
-            config5 = {"crops_per_s": round(B / ms8 * 1e3, 2), "ms_per_step": round(ms8, 2), "steps": 5, "batch": B,
+            ms8 = (time.perf_counter() - t8) / 3 * 1e3
+            eng8.profile(True)
+            step8()
+            g8_ms, g8_n, g8_flops = eng8.profile_read()
+            eng8.profile(False)
+            # decision-level agreement with the bf16 engine on the first 32 crops of this batch (the reference has no fp8 path: the
+            # bf16 engine, pinned to the reference, is the yardstick)
+            same_box = None
+            if B <= B8:
+                step()                                                  # the bf16 engine's records of the headline batch ...
+                _lib.check(eng8.lib.vstar_vsm_score_batch(             # ... and the W8A8 engine's records of the SAME crops
+                    eng8.handle, B, vp(clip.data_ptr()), vp(owl.data_ptr()), ids.ctypes.data_as(vp), L, loc.ctypes.data_as(vp),
+                    verify.ctypes.data_as(vp), nv, flags, vp(rec8.data_ptr())), eng8.handle)
+                a, b8 = rec_dev.cpu().numpy(), rec8[:B].cpu().numpy()
+                same_box = float(np.mean(a[:, :2304].argmax(1) == b8[:, :2304].argmax(1)))
+            geo = (7680, 4320, 16.0)
+            s8 = search_leg(eng8, cfg8, args, rank, group=False, geometry=geo, targets=1, record_paths=True)
+            s16 = search_leg(eng, cfg, args, rank, group=False, geometry=geo, targets=1, record_paths=True)
+            vo8, vo16 = s8.pop("visit_orders", [[]])[0], s16.pop("visit_orders", [[]])[0]
+            common = 0
+            for x, y in zip(vo8, vo16):
+                if x != y:
+                    break
+                common += 1
+            config5 = {"workload": "BASELINE config 5: W8A8 fp8 LLaMA linears, 64-crop batches; search leg = one 7680x4320 synthetic image, "
+                                   "--minimum_size_scale 16 (depth-5 tree, 341 nodes), 1 target",
+                       "crops_per_s": round(B8 / ms8 * 1e3, 2), "ms_per_step": round(ms8, 2), "steps": 3, "batch": B8,
                        "dtype": "fp8 e4m3 W8A8 LLaMA linears on v_mfma_scale_f32_16x16x128_f8f6f4, bf16 elsewhere",
-                       "argmax_box_same_as_bf16_engine": round(same_box, 4),
-                       "note": "bounded run inside the default command; full config-5 line: bench.py --config5"}
+                       "roofline": {"bound": "mfma", "achieved": round(g8_flops / (g8_ms * 1e-3) / 1e12, 1) if g8_ms > 0 else None,
+                                    "peak": 5000.0, "unit": "TFLOP/s",
+                                    "frac": round(g8_flops / (g8_ms * 1e-3) / 1e12 / 5000.0, 4) if g8_ms > 0 else None,
+                                    "note": "all GEMM launches of one 64-crop step timed by HIP events (93 % of their FLOPs run on the "
+                                            "fp8 MFMA; the ViT / head GEMMs stay bf16), against the dense fp8 peak"},
+                       "argmax_box_same_as_bf16_engine": None if same_box is None else round(same_box, 4),
+                       "search": {k: s8[k] for k in ("search_crops_per_s", "wall_s", "crops_scored", "tree", "stage_s")},
+                       "search_bf16_engine_crops_per_s": s16["search_crops_per_s"],
+                       "same_visit_order": bool(vo8 == vo16 and len(vo8) > 0),
+                       "common_visit_prefix": common, "nodes_visited": [len(vo8), len(vo16)],
+                       "same_final_box_and_path_length": s8["path_lengths"] == s16["path_lengths"],
+                       "weights": args.weights}
             eng8.close()
         except Exception as exc:
             config5 = {"error": f"{type(exc).__name__}: {exc}"}
@@ -608,7 +700,8 @@ def main():
                        "crops_per_gpu_per_step": B, "text_tokens": T, "seq_len": S, "parallelism": f"dp{world}",
                        "flops_per_crop": per_crop, "weights_load_s": round(t_load, 1)},
             "roofline": roofline, "cpu_baseline": cpu, "search": search, "search_grouped": search_grouped,
-            "search_stream": stream, "search_stream_shard_samples": stream_samples, "per_rank_shape": small, "config5": config5,
+            "search_stream": stream, "search_stream_shard_samples": stream_samples, "search_stream_default_vsm": stream_default,
+            "search_latency": latency, "per_rank_shape": small, "config5": config5,
             "world_size": world, "collective": None if not use_group else {
                 "backend": dist.get_backend() + " (RCCL over xGMI)", "op": "all_gather_into_tensor of the per-crop result records, once per step",
                 "bytes_per_rank_per_step": int(B * _lib.RESULT_FLOATS * 4), "ranks": dist.get_world_size()},

@@ -27,6 +27,10 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def _assert(cond, msg):
+    assert cond, msg
+
+
 def _state_dict(cfg, z):
     """The state dict a golden file was recorded with: i.i.d. random (rounds 2/3) or the trained-like statistics of round 4 —
     outlier residual channels (|x|_inf / rms 9 -> 32 across the depth, 48 at the worst token), a massive-activation BOS, spread
@@ -83,7 +87,10 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
         gate(assert_mask_within_bf16_noise, out["low_res_masks"][ci, 0], z["low_res_masks"][j], z["bf16_low_res_masks"][j],
              z["sam_hyper"][j], z["bf16_sam_hyper"][j], z["sam_upscaled_mean"][j], z["bf16_sam_upscaled_mean"][j], report=rep)
         print(f"\ncrop {ci}: engine / reference-bf16 noise (rel-L2 vs the reference's fp32 output): {fmt(rep)}")
-        assert np.abs(out["pred_boxes"][ci] - z["pred_boxes"][j]).max() < 1e-2
+        # largest single box error: 1e-2, or 1.5 x the largest the reference's own bf16 run shows on this fixture's crops (trained-like
+        # weights: up to 1.08e-2 for the reference itself)
+        box_cap = max(1e-2, 1.5 * float(np.abs(z["bf16_pred_boxes"] - z["pred_boxes"]).max()))
+        gate(lambda: _assert(np.abs(out["pred_boxes"][ci] - z["pred_boxes"][j]).max() < box_cap, f"crop {ci}: max box error over {box_cap:.2e}"))
         noise_abs = 2.0 * float(np.abs(z["bf16_pred_logits"][j] - z["pred_logits"][j]).max())
         ok, msg = margin_aware_topk_equal(got["pred_logits"], z["pred_logits"][j], 5, noise_abs)
         assert ok, msg

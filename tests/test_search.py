@@ -452,9 +452,10 @@ def test_speculation_policy_cost_model():
     pol = search.SpeculationPolicy({1: 20.0, 2: 26.0, 4: 40.0, 8: 68.0, 16: 126.0, 32: 236.0}, cap=32)
     assert pol.step_ms(1) == 20.0 and pol.step_ms(3) == 33.0 and pol.step_ms(32) == 236.0 and pol.step_ms(64) == 472.0
     cands = [(0.45, "c0"), (0.45, "c1"), (0.45, "c2"), (0.45, "c3"), (0.5, "q0"), (0.25, "q1"), (0.1, "far")]
-    # a lone search (latency mode): p * t(1) = 9 ms >= marginal 6-7 ms for the likely candidates, never for the unlikely ones
+    # a lone search (latency mode): p * t(1) = 9 ms >= marginal 6-7 ms for the likely candidates, never for the unlikely ones —
+    # and (round 4) never more of them than one single-crop step's worth of extra time: t(4) - t(1) = 20 ms = t(1), t(5) - t(1) = 27
     lone = pol.select(1, cands, 1)
-    assert lone[:1] == ["q0"] and set(lone) == {"q0", "c0", "c1", "c2", "c3"}
+    assert lone == ["q0", "c0", "c1"]
     # many live searches: a hit rarely shortens the schedule -> nothing is worth a crop's marginal cost
     assert pol.select(8, cands, 8) == []
     assert pol.select(2, cands, 2) == []
@@ -478,6 +479,30 @@ def test_stream_speculates_for_a_lone_search_but_not_in_a_full_window():
     search.visual_search_stream(v6, samples, window=6, stats=st6, **kw)
     assert st6["wasted_crop_frac"] == 0.0                    # six live searches: only crops the order visits
     assert st6["useful_crops"] == st6["crops_scored"]
+
+
+@pytest.mark.parametrize("conf", [0.5, 0.7, 0.9, 2.0])
+def test_speculation_never_costs_a_lone_search_more_than_one_step(conf):
+    """in the regime the policy exists for (window 1 — one search at a time) the modelled time of every search —
+    sum of t(B) over its engine steps with the MI355X step table — must not exceed the no-speculation schedule's by more than one
+    step, and the results must be the same.  Priors: measured visit frequencies (profiles/r04_speculation_priors.json)."""
+    samples = _stream_samples(n_images=8, per_image=(1, 2))
+    kw = dict(confidence_high=conf, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    pol = search.SpeculationPolicy(cap=8)
+    lose, total_spec, total_plain = 0.0, 0.0, 0.0
+    for smp in samples:
+        va, vb = _SlotVSM(max_batch=8), _SlotVSM(max_batch=8)
+        ra = search.visual_search_stream(va, [smp], window=1, policy=pol, **kw)          # one policy: it learns the regime as it goes
+        rb = search.visual_search_stream(vb, [smp], window=1, speculate=False, **kw)
+        assert ra[0][1] == rb[0][1] and ra[0][2] == rb[0][2] and ra[0][0]["bbox"] == rb[0][0]["bbox"]
+        ta = sum(pol.step_ms(len(c)) for c in va.calls)
+        tb = sum(pol.step_ms(len(c)) for c in vb.calls)
+        assert all(len(c) == 1 for c in vb.calls)
+        assert ta <= tb + pol.step_ms(1) + 1e-9, (ta, tb)
+        lose = max(lose, ta - tb)
+        total_spec += ta
+        total_plain += tb
+    assert total_spec <= 1.05 * total_plain + 2 * pol.step_ms(1)      # over the set: at worst a wash (plus what it cost to learn the regime)
 
 
 @pytest.mark.parametrize("prefetch", [0, 1, 3])

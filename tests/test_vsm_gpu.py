@@ -64,11 +64,13 @@ def test_inference_conventions_and_oracle(vsm):
     sd = {k: v.float() for k, v in random_state_dict(cfg, seed=5, dtype=torch.bfloat16).items()}
     ref = vsm_oracle.vsm_forward(sd, cfg, clip.float(), owl.float(), torch.from_numpy(ids.astype(np.int64))[None], vsm.loc_token_idx)
     assert int(ref["loc_pos"][0]) == loc_pos
-    assert np.abs(boxes.numpy() - ref["pred_boxes"][0].numpy()).max() < 1e-2
     # the same algorithm in bf16 on torch-CPU is the noise yardstick (tests/_parity.py): no fixed floors
     from _parity import assert_mask_within_bf16_noise, assert_within_bf16_noise
     sd16 = random_state_dict(cfg, seed=5, dtype=torch.bfloat16)
     r16 = vsm_oracle.vsm_forward(sd16, cfg, clip, owl, torch.from_numpy(ids.astype(np.int64))[None], vsm.loc_token_idx)
+    box_noise = float((r16["pred_boxes"][0].float() - ref["pred_boxes"][0]).abs().max())
+    assert np.abs(boxes.numpy() - ref["pred_boxes"][0].numpy()).max() < max(1e-2, 1.5 * box_noise)
+    assert_within_bf16_noise("boxes", boxes.numpy(), ref["pred_boxes"][0].numpy(), r16["pred_boxes"][0].float().numpy())
     assert_within_bf16_noise("scores", scores.float().numpy(), torch.sigmoid(ref["pred_logits"][0]).numpy(),
                              torch.sigmoid(r16["pred_logits"][0]).float().numpy())
     low = vsm.inference_batch([img], q, mode="segmentation", upsample=False)[0].numpy()
@@ -333,7 +335,9 @@ def test_stream_with_default_vsm_settings_batches_across_targets(vsm):
     for x, y in zip(loop, got):
         assert x[1] == y[1] and x[2] == y[2] and x[0]["bbox"] == y[0]["bbox"]
         assert torch.equal(x[0]["detection_result"], y[0]["detection_result"])
-    assert st["engine_calls"] == st["engine_steps"] < st["useful_crops"]       # no per-prompt fragmentation
+    # no per-prompt fragmentation: a step is one call unless its crops exceed the grouped entry point's activation-row budget
+    # (6 one-prompt crops per call in this tiny configuration); round 3 made one call per distinct prompt = one per crop here
+    assert st["engine_steps"] <= st["engine_calls"] <= st["engine_steps"] + 4 and st["engine_calls"] < st["useful_crops"] / 2
     assert st["crops_scored"] / st["engine_calls"] > 3.0
 
 

@@ -244,7 +244,7 @@ class _NodeScorer:
             pq = prior.p_queue * prior.queue_decay ** rank
             add(pq, e.item["bbox"])
             for c in self._children(e.item["bbox"]):
-                add(pq * prior.p_child, c)
+                add(pq * prior.p_child * getattr(prior, "queue_child_factor", 1.0), c)
         return out
 
     def score(self, todo: List[list]) -> List:
@@ -539,16 +539,51 @@ class SpeculationPolicy:
     one of them rarely shortens the schedule — against the marginal cost of one more crop), and never beyond `cap` crops.  With a
     window of concurrent searches that fills the batch with MUST crops the right-hand side is the full per-crop cost and nothing
     is speculated; a lone search (latency mode) speculates its children and the head of its queue while batches are small.
-    The priors are deliberately simple constants (children of the node being scored, queue entries best-first with geometric
-    decay); `wasted_crop_frac` in the drivers' stats is the measured outcome."""
+    The priors are visit FREQUENCIES measured by replaying best-first searches (tools/calibrate_speculation.py ->
+    profiles/r04_speculation_priors.json) in the regime of the reference's reported mean path (~4.65 visited nodes per search,
+    SURVEY §6): a child of the node being scored is visited later with probability 0.25, the r-th best queue entry with
+    0.75 x 0.7^r, a child of that entry with 0.45 x the product (round 3 guessed 0.45 / 0.5 x 0.5^r / the bare product: children
+    over-, the queue under-estimated).  With the MI355X step table a lone search therefore speculates the head of its queue but
+    not the four children of the node in flight (expected saving 0.25 x t(1) = 4.2 ms < 6.7 ms marginal cost); `wasted_crop_frac`
+    and bench.py's `search_latency` leg are the measured outcome."""
 
     DEFAULT_STEP_MS = {1: 16.8, 2: 23.5, 4: 36.5, 8: 63.7, 16: 126.5, 32: 232.7}
+    # (mean visited nodes per search, p_child, p_queue, queue_decay): profiles/r04_speculation_priors.json.  How often a candidate
+    # is visited depends on how soon searches end, so the priors follow the OBSERVED mean path length of the searches this policy
+    # has seen finish (`observe`), starting from the reference's regime
+    REGIMES = ((1.77, 0.109, 0.403, 0.32), (2.64, 0.170, 0.595, 0.55), (3.69, 0.219, 0.693, 0.68), (4.41, 0.250, 0.747, 0.75),
+               (6.64, 0.338, 0.835, 0.83), (11.91, 0.481, 0.929, 0.93))
+    PRIOR_NODES, PRIOR_WEIGHT = 4.65, 4.0
 
-    def __init__(self, step_ms: Optional[Dict[int, float]] = None, cap: int = 32, world: int = 1, p_child: float = 0.45,
-                 p_queue: float = 0.5, queue_decay: float = 0.5, max_queue_rank: int = 4, enabled: bool = True):
+    def __init__(self, step_ms: Optional[Dict[int, float]] = None, cap: int = 32, world: int = 1, p_child: float = 0.25,
+                 p_queue: float = 0.75, queue_decay: float = 0.7, max_queue_rank: int = 4, enabled: bool = True,
+                 queue_child_factor: float = 0.45):
         self.table = dict(sorted((step_ms or self.DEFAULT_STEP_MS).items()))
         self.cap, self.world, self.enabled = int(cap), max(int(world), 1), enabled
         self.p_child, self.p_queue, self.queue_decay, self.max_queue_rank = p_child, p_queue, queue_decay, max_queue_rank
+        self.queue_child_factor = queue_child_factor
+        self.adaptive = (p_child, p_queue, queue_decay) == (0.25, 0.75, 0.7)      # explicit priors are kept as given
+        self._nodes_sum, self._nodes_n = 0.0, 0
+
+    def observe(self, nodes_visited: int) -> None:
+        """A search ended after visiting `nodes_visited` nodes: move the priors to the regime the searches are really in.  (Under
+        crop sharding every rank sees the same searches end in the same order, so the ranks' policies stay identical.)"""
+        if not self.adaptive:
+            return
+        self._nodes_sum += float(nodes_visited)
+        self._nodes_n += 1
+        m = (self.PRIOR_NODES * self.PRIOR_WEIGHT + self._nodes_sum) / (self.PRIOR_WEIGHT + self._nodes_n)
+        R = self.REGIMES
+        if m <= R[0][0]:
+            f = max(m - 1.0, 0.0) / (R[0][0] - 1.0)            # a search that always ends at its root visits nothing else
+            self.p_child, self.p_queue, self.queue_decay = R[0][1] * f, R[0][2] * f, R[0][3]
+            return
+        for lo, hi in zip(R, R[1:]):
+            if m <= hi[0]:
+                t = (m - lo[0]) / (hi[0] - lo[0])
+                self.p_child, self.p_queue, self.queue_decay = (lo[k] + t * (hi[k] - lo[k]) for k in (1, 2, 3))
+                return
+        self.p_child, self.p_queue, self.queue_decay = R[-1][1:]
 
     def step_ms(self, n_crops: int) -> float:
         """t(B): one engine step of n_crops crops dealt over `world` ranks (piecewise linear in the per-rank batch)."""
@@ -568,10 +603,14 @@ class SpeculationPolicy:
         if not self.enabled:
             return []
         chosen, B = [], n_must
+        base = self.step_ms(n_must)
         for p, item in sorted(cands, key=lambda c: -c[0]):
             if B >= self.cap:
                 break
             if p * self.step_ms(1) / max(n_live, 1) < self.step_ms(B + 1) - self.step_ms(B):
+                break
+            # bounded downside: whatever the priors say, one step's speculation never costs more than one single-crop step
+            if self.step_ms(B + 1) - base > self.step_ms(1):
                 break
             chosen.append(item)
             B += 1
@@ -725,6 +764,8 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
 
     def finish(i, value):
         results[i] = value
+        if hasattr(policy, "observe"):
+            policy.observe(int(per_stats[i].get("path_visited", 1)))
         sl = scorers[i].slot
         slot_refs[sl] -= 1
         if slot_refs[sl] == 0:                     # last live search of that image: the slot can take another image
@@ -856,6 +897,8 @@ def _fill_stream_stats(stats: Optional[dict], per_stats: List[dict], engine_step
     stats.update(searches=len(per_stats), crops_scored=scored, useful_crops=useful,
                  wasted_crop_frac=(1.0 - useful / scored) if scored else 0.0, engine_steps=engine_steps,
                  per_search=[{k: v for k, v in p.items() if k != "search_path"} for p in per_stats])
+    if stats.get("keep_paths"):              # the visited boxes of every search, in visit order (decision-parity reports)
+        stats["visit_orders"] = [[tuple(int(v) for v in p["bbox"]) for p in ps.get("search_path", [])] for ps in per_stats]
 
 
 def visual_search_many(vsm, image, target_object_names: Sequence[str], target_bboxes=None, smallest_size: int = 224, *,

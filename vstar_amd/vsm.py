@@ -33,7 +33,7 @@ from .dist import allgather_numpy, allgather_records, pad_count, shard_indices
 from .engine import VstarEngine
 from .preprocess import (ANSWER_TEMPLATE, IMAGE_TOKEN_INDEX, LOCATE_QUESTION, SyntheticTokenizer, build_prompt, clip_preprocess,
                          owl_preprocess, tokenizer_image_token)
-from .weights import load_checkpoint_dir, random_state_dict
+from .weights import load_checkpoint_dir, random_state_dict, template_chain, trained_like_state_dict
 
 
 def _scores(logits: np.ndarray) -> torch.Tensor:
@@ -73,6 +73,7 @@ class VSM:
             raise ValueError(f"unknown conv_type {self.conv_type!r} (visual_search.py:47: llava_v1 | llava_llama_2)")
         version = getattr(args, "version", None)
         real = version is not None and os.path.isdir(str(version))
+        answers_template = False
         if engine is not None:
             self.engine = engine
             self.cfg = engine.cfg
@@ -82,7 +83,12 @@ class VSM:
             if real:
                 sd = load_checkpoint_dir(version, getattr(args, "vision_tower"))
             elif synthetic_seed is not None:
-                sd = random_state_dict(self.cfg, seed=synthetic_seed, dtype=torch.bfloat16, share_layers=True)
+                # seeded weights with a trained checkpoint's statistics whose greedy decode answers locate prompts of the
+                # SyntheticTokenizer with "Sure, [LOC]." (round 4): the default strict_template=True path runs on them
+                sd = trained_like_state_dict(self.cfg, seed=synthetic_seed, dtype=torch.bfloat16, share_layers=True,
+                                             chain=template_chain(SyntheticTokenizer(self.cfg.llm_vocab), conv_type=self.conv_type,
+                                                                  use_mm_start_end=self.use_mm_start_end))
+                answers_template = tokenizer is None
             else:
                 raise FileNotFoundError(
                     f"checkpoint directory {version!r} not found and no synthetic_seed given (there is no hub access here)")
@@ -97,7 +103,7 @@ class VSM:
         else:
             self.vsm_tokenizer = SyntheticTokenizer(self.cfg.llm_vocab)
         self.loc_token_idx = self.vsm_tokenizer("[LOC]", add_special_tokens=False).input_ids[0]
-        self.strict_template = real if strict_template is None else strict_template
+        self.strict_template = (real or answers_template) if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
         self.fallback_log: List[dict] = []      # one entry per stepwise-decode fallback (diagnostics / tests)
         self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0, "engine_calls": 0}
