@@ -187,7 +187,7 @@ def main(out_path=None):
                       not (no_reads and x.startswith("ds_read"))]
     body = "".join('  "%s\\n\\t"\n' % x for x in L if not x.startswith(";"))
     clob = ", ".join(f'"v{i}"' for i in range(158)) + ", " + ", ".join(f'"a{i}"' for i in range(256))
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vstar_amd", "csrc", "gemm256a_loop.inc")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm256a_loop.inc")
     if out_path:
         path = out_path
     with open(path, "w") as f:

@@ -568,6 +568,204 @@ __global__ __launch_bounds__(256) void cached_attn_kernel(const lp_t* __restrict
   }
 }
 
+// ------------------------------------------------ split-KV decode attention ------------------------------------------------
+// A decode step of few sequences leaves cached_attn_kernel<true> on R x 32 workgroups of 256 CUs, each pulling the whole K and V
+// of its head through one CU (17.8 us per layer at ~700 keys: 15 % of a batch-1 token).  Here the keys of a (row, head) are cut
+// into P partitions = P workgroups.  The reference's rounding points need the GLOBAL softmax statistics before a probability is
+// rounded to the storage type, so the work is two launches:
+//   scores kernel  RoPE(q) (+ RoPE(k), append k / v to the cache: last partition), this partition's scores -> workspace, its
+//                  local max and sum of exponentials
+//   pv kernel      global max / sum from the P partials (fixed order), probabilities rounded like HF, partial P.V; the LAST
+//                  partition to finish (ticket) adds the partials in partition order and writes the row — no spinning, no
+//                  co-residency requirement, deterministic summation order.
+// Same arithmetic per key as cached_attn_kernel; only the order of the fp32 sums differs.
+constexpr int SPLIT_P = 8;
+
+__device__ __forceinline__ void split_range(int nkc, int p, int* lo, int* hi) {
+  const int span = (((nkc + SPLIT_P - 1) / SPLIT_P) + 63) & ~63;
+  *lo = p * span < nkc ? p * span : nkc;
+  *hi = *lo + span < nkc ? *lo + span : nkc;
+}
+
+__global__ __launch_bounds__(256) void cached_attn_split_scores_kernel(
+    const lp_t* __restrict__ qkv, lp_t* __restrict__ kc, lp_t* __restrict__ vc, const int32_t* __restrict__ row_seq,
+    const int32_t* __restrict__ row_pos, const int32_t* __restrict__ seq_kv, const int32_t* __restrict__ seq_prefix,
+    const int32_t* __restrict__ seq_past, const lp_t* __restrict__ cos_sin, float* __restrict__ ws_scores, float* __restrict__ ws_stats,
+    int H, int ctx, int64_t slot_stride, float inv_scale) {
+  constexpr int D = 128;
+  extern __shared__ float dyn[];            // this partition's scores (span + 1)
+  __shared__ float qs[D], own_k[D], redbuf[8];
+  const int r = blockIdx.x, h = blockIdx.y, p = blockIdx.z, tid = threadIdx.x;
+  const int pos = row_pos[r];
+  if (pos < 0) return;
+  const int seq = row_seq[r];
+  const int past = seq_past[seq], nkc = pos;
+  lp_t* kown = kc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* kpre = kc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
+  lp_t* vown = vc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* rowp = qkv + (int64_t)r * (3 * H * D) + h * D;
+  const bool last = p == SPLIT_P - 1;
+  if (tid < 128) {                           // rotate-half RoPE with HF's rounding points: tid 0-63 q pairs, 64-127 k pairs
+    const int which = tid >> 6, d = tid & 63;
+    if (which == 0 || last) {
+      const lp_t* base = rowp + which * (H * D);
+      const float x1 = lp2f(base[d]), x2 = lp2f(base[d + 64]);
+      const float cs = lp2f(cos_sin[(int64_t)pos * D + d]), si = lp2f(cos_sin[(int64_t)pos * D + 64 + d]);
+      const lp_t o1 = f2lp(rlp(x1 * cs) + rlp(-x2 * si)), o2 = f2lp(rlp(x2 * cs) + rlp(x1 * si));
+      if (which == 0) {
+        qs[d] = lp2f(o1);
+        qs[d + 64] = lp2f(o2);
+      } else {
+        own_k[d] = lp2f(o1);
+        own_k[d + 64] = lp2f(o2);
+        kown[(int64_t)pos * D + d] = o1;
+        kown[(int64_t)pos * D + d + 64] = o2;
+      }
+    }
+  } else if (last) {
+    const int d = tid - 128;
+    vown[(int64_t)pos * D + d] = rowp[2 * H * D + d];
+  }
+  __syncthreads();
+  int j_lo, j_hi;
+  split_range(nkc, p, &j_lo, &j_hi);
+  float* gsc = ws_scores + ((int64_t)r * H + h) * ctx;
+  const int l16 = tid & 15, grp = tid >> 4;
+  float qv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qv[e] = qs[l16 * 8 + e];
+  float mx = -3.0e38f;
+  for (int j0 = j_lo; j0 < j_hi; j0 += 64) {
+    lpx8 kv8[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16 + grp;
+      kv8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
+      if (j < j_hi) kv8[u] = *(const lpx8*)((j < past ? kpre : kown) + (int64_t)j * D + l16 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16 + grp;
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += qv[e] * lp2f((lp_t)kv8[u][e]);
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 4, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 1, 64);
+      if (j < j_hi) {
+        const float sv = rlp(rlp(a) / inv_scale);    // HF: matmul output in the storage type, then / sqrt(head_dim)
+        if (l16 == 0) { dyn[j - j_lo] = sv; gsc[j] = sv; }
+        mx = fmaxf(mx, sv);
+      }
+    }
+  }
+  int n_loc = j_hi - j_lo;
+  if (last) {                                  // the row's own key, from LDS
+    if (grp == 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += qv[e] * own_k[l16 * 8 + e];
+      a += __shfl_xor(a, 8, 64);
+      a += __shfl_xor(a, 4, 64);
+      a += __shfl_xor(a, 2, 64);
+      a += __shfl_xor(a, 1, 64);
+      const float sv = rlp(rlp(a) / inv_scale);
+      if (l16 == 0) { dyn[n_loc] = sv; gsc[pos] = sv; }
+      mx = fmaxf(mx, sv);
+    }
+    n_loc += 1;
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) redbuf[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(redbuf[0], redbuf[1]), fmaxf(redbuf[2], redbuf[3]));
+  float sum = 0.f;
+  for (int j = tid; j < n_loc; j += 256) sum += __expf(dyn[j] - mx);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) redbuf[4 + (tid >> 6)] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    float* st = ws_stats + (((int64_t)r * H + h) * SPLIT_P + p) * 2;
+    st[0] = mx;
+    st[1] = (redbuf[4] + redbuf[5]) + (redbuf[6] + redbuf[7]);
+  }
+}
+
+__global__ __launch_bounds__(256) void cached_attn_split_pv_kernel(
+    const lp_t* __restrict__ vc, const int32_t* __restrict__ row_seq, const int32_t* __restrict__ row_pos,
+    const int32_t* __restrict__ seq_kv, const int32_t* __restrict__ seq_prefix, const int32_t* __restrict__ seq_past,
+    const float* __restrict__ ws_scores, const float* __restrict__ ws_stats, float* __restrict__ ws_opart, int* __restrict__ ws_cnt,
+    lp_t* __restrict__ out, int H, int ctx, int64_t slot_stride) {
+  constexpr int D = 128;
+  __shared__ float part[16][D];
+  __shared__ int ticket;
+  const int r = blockIdx.x, h = blockIdx.y, p = blockIdx.z, tid = threadIdx.x;
+  const int pos = row_pos[r];
+  if (pos < 0) return;
+  const int seq = row_seq[r];
+  const int past = seq_past[seq], nkc = pos;
+  const lp_t* vown = vc + (int64_t)seq_kv[seq] * slot_stride + (int64_t)h * ctx * D;
+  const lp_t* vpre = vc + (int64_t)seq_prefix[seq] * slot_stride + (int64_t)h * ctx * D;
+  const float* st = ws_stats + ((int64_t)r * H + h) * SPLIT_P * 2;
+  float M = -3.0e38f;
+#pragma unroll
+  for (int q = 0; q < SPLIT_P; ++q) M = fmaxf(M, st[2 * q]);
+  float L = 0.f;
+#pragma unroll
+  for (int q = 0; q < SPLIT_P; ++q) L += st[2 * q + 1] * __expf(st[2 * q] - M);
+  const float inv = 1.0f / L;
+  int j_lo, j_hi;
+  split_range(nkc, p, &j_lo, &j_hi);
+  if (p == SPLIT_P - 1) j_hi = (j_hi == nkc) ? nkc + 1 : j_hi;       // + the row's own key / value (appended by the scores kernel)
+  const float* gsc = ws_scores + ((int64_t)r * H + h) * ctx;
+  const int l16 = tid & 15, grp = tid >> 4;
+  float o[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  for (int j0 = j_lo + grp; j0 < j_hi; j0 += 64) {
+    lpx8 v8[4];
+    float pr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * 16;
+      v8[u] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
+      pr[u] = 0.f;
+      if (j < j_hi) {
+        v8[u] = *(const lpx8*)((j < past ? vpre : vown) + (int64_t)j * D + l16 * 8);
+        pr[u] = rlp(__expf(gsc[j] - M) * inv);     // probabilities rounded to the storage type (HF .to(query.dtype))
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += pr[u] * lp2f((lp_t)v8[u][e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[grp][l16 * 8 + e] = o[e];
+  __syncthreads();
+  float* op = ws_opart + ((int64_t)r * H + h) * SPLIT_P * D;
+  if (tid < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int g2 = 0; g2 < 16; ++g2) t += part[g2][tid];
+    op[p * D + tid] = t;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) ticket = atomicAdd(&ws_cnt[r * H + h], 1);
+  __syncthreads();
+  if (ticket != SPLIT_P - 1) return;
+  __threadfence();                                  // the other partitions' partials are visible
+  if (tid < D) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < SPLIT_P; ++q) t += __builtin_nontemporal_load(&op[q * D + tid]);
+    out[(int64_t)r * (H * D) + h * D + tid] = f2lp(t);
+  }
+  if (tid == 0) ws_cnt[r * H + h] = 0;             // ready for the next launch
+}
+
 // ------------------------------------------------ Perceiver attention ------------------------------------------------
 // q [n*L, H*DH]; kv [n*NK, 2*H*DH] = k | v; out [n*L, H*DH].  Rounding points of the fp16 reference: q*scale, sim, sim-amax,
 // softmax output and the attn·v product are each materialised in the storage type.
@@ -705,10 +903,32 @@ hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos
   return hipGetLastError();
 }
 
+size_t cached_attention_split_ws_bytes(int max_rows, int H, int ctx) {
+  const size_t rh = (size_t)max_rows * H;
+  return rh * ((size_t)ctx * 4 + SPLIT_P * 2 * 4 + SPLIT_P * 128 * 4 + 4) + 256;
+}
+
 hipError_t cached_attention(const lp_t* qkv, lp_t* kc, lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
                             const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, const lp_t* fused_cos_sin,
-                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s) {
+                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s, void* split_ws,
+                            int split_max_rows) {
   if (R <= 0) return hipSuccess;
+  static const bool split_on = [] { const char* v = getenv("VSTAR_DECODE_SPLIT_KV"); return !v || atoi(v) != 0; }();
+  // decode steps of few sequences: P partitions per (row, head) so that the K / V streams of a head run on 8 CUs instead of one
+  if (split_on && fused_cos_sin && split_ws && R <= split_max_rows && R * H <= 128 && max_keys >= 256) {
+    const size_t rh = (size_t)split_max_rows * H;
+    float* ws_scores = (float*)split_ws;
+    float* ws_stats = ws_scores + rh * ctx;
+    float* ws_opart = ws_stats + rh * SPLIT_P * 2;
+    int* ws_cnt = (int*)(ws_opart + rh * SPLIT_P * 128);
+    const int span = ((((max_keys + SPLIT_P - 1) / SPLIT_P) + 63) & ~63) + 1;
+    hipLaunchKernelGGL(cached_attn_split_scores_kernel, dim3(R, H, SPLIT_P), dim3(256), (size_t)span * sizeof(float), s, qkv, kc, vc,
+                       row_seq, row_pos, seq_kv, seq_prefix, seq_past, fused_cos_sin, ws_scores, ws_stats, H, ctx, slot_stride,
+                       sqrtf(128.0f));
+    hipLaunchKernelGGL(cached_attn_split_pv_kernel, dim3(R, H, SPLIT_P), dim3(256), 0, s, vc, row_seq, row_pos, seq_kv, seq_prefix,
+                       seq_past, ws_scores, ws_stats, ws_opart, ws_cnt, out, H, ctx, slot_stride);
+    return hipGetLastError();
+  }
   const size_t lds = (size_t)(128 + max_keys) * sizeof(float);
   if (lds > 40 * 1024) return hipErrorInvalidValue;
   if (fused_cos_sin)

@@ -340,8 +340,6 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 
 bool gemm256_eligible(const GemmParams& p);
 hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
-bool gemm256a_eligible(const GemmParams& p, int epilogue, bool out_f32);      // gemm256a.hip (experiment, VSTAR_GEMM256A=1)
-hipError_t gemm256a_lp(const GemmParams& p, hipStream_t s);
 
 static thread_local int t_last_tile = 0;
 int gemm_last_tile() { return t_last_tile; }
@@ -368,11 +366,6 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   static const int env_force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const int force = p.tile_force ? p.tile_force : env_force;
   if (force != 0 && force != 128 && force != 256) return hipErrorInvalidValue;
-  static const bool use_256a = [] { const char* e = getenv("VSTAR_GEMM256A"); return e && atoi(e) != 0; }();
-  if (use_256a && force == 0 && gemm256a_eligible(p, epilogue, out_f32)) {
-    t_last_tile = 2560;
-    return gemm256a_lp(p, s);
-  }
   const bool elig = gemm256_eligible(p);
   if (p.tile_force == 256 && !elig) return hipErrorInvalidValue;   // an explicit per-call request must not be silently re-routed
   if (force != 128 && elig) {   // W is padded to 256 rows

@@ -78,7 +78,11 @@ hipError_t rope_kv_append(lp_t* qkv, const lp_t* cos_sin, const int32_t* row_pos
 // its row (RoPE on q,k, K/V appended to the cache) — qkv then holds the raw projection.
 hipError_t cached_attention(const lp_t* qkv, lp_t* kc, lp_t* vc, const int32_t* row_seq, const int32_t* row_pos,
                             const int32_t* seq_kv, const int32_t* seq_prefix, const int32_t* seq_past, const lp_t* fused_cos_sin,
-                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s);
+                            lp_t* out, int R, int H, int ctx, int64_t slot_stride, int max_keys, hipStream_t s,
+                            void* split_ws = nullptr, int split_max_rows = 0);
+// workspace of the split-KV decode path (scores, partial statistics / outputs, tickets) for up to max_rows new rows per step;
+// must be zero-filled once
+size_t cached_attention_split_ws_bytes(int max_rows, int H, int ctx);
 // q [n*L, H*DH], kv [n*NK, 2*H*DH] (k | v) -> out [n*L, H*DH]
 hipError_t perceiver_attention(const lp_t* q, const lp_t* kv, lp_t* out, int n, int L, int NK, int H, int DH, hipStream_t s);
 hipError_t argmax_rows_lp(const lp_t* x, int rows, int cols, int64_t ld, int32_t* out, hipStream_t s);

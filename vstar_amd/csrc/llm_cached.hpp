@@ -40,6 +40,8 @@ struct LlmCached {
   int32_t *d_src = nullptr, *d_row_pos = nullptr, *d_row_slot = nullptr, *d_row_seq = nullptr, *d_seq = nullptr, *d_want = nullptr,
           *d_argmax = nullptr;
   int max_want = 256;
+  static constexpr int SPLIT_ROWS = 4;           // decode steps of up to this many sequences take the split-KV attention
+  char* split_ws = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   double last_ms = 0;
   // ---- greedy decode of ONE sequence as a replayed hipGraph (decode_greedy_graph) ----
@@ -112,6 +114,11 @@ inline int LlmCached::init(EngineBase* owner, const LlmCachedCfg& c, const lp_t*
   RC(e->dalloc(&d_seq, (size_t)3 * c.max_slots * 4));
   RC(e->dalloc(&d_want, (size_t)max_want));
   RC(e->dalloc(&d_argmax, (size_t)max_want));
+  {  // split-KV decode attention (decode.hip): scores / partials / tickets for steps of up to SPLIT_ROWS sequences, zeroed once
+    const size_t wb = cached_attention_split_ws_bytes(SPLIT_ROWS, c.heads, c.max_ctx);
+    RC(e->dalloc(&split_ws, wb));
+    if (hipMemset(split_ws, 0, wb) != hipSuccess) { set_error("split-KV workspace memset failed"); return VSTAR_ERR_HIP; }
+  }
   if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { set_error("hipEventCreate failed"); return VSTAR_ERR_HIP; }
   ready = true;
   return 0;
@@ -188,7 +195,7 @@ inline int LlmCached::llm_layers_cached(int R, int nseq, int max_keys, bool sing
     // decode steps (one new row per sequence): RoPE + cache append happen inside the attention kernel
     if (!single_rows) LCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.heads, e->stream));
     LCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, single_rows ? rope : nullptr, latt, R,
-                          c.heads, c.max_ctx, slot_stride, max_keys, e->stream));
+                          c.heads, c.max_ctx, slot_stride, max_keys, e->stream, split_ws, SPLIT_ROWS));
     RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
     RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.mlp, R, VSTAR_EPI_SILU_MUL));
     RC(lin_auto(lact, c.mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));

@@ -106,6 +106,8 @@ class VSM:
         self.strict_template = (real or answers_template) if strict_template is None else strict_template
         self.last_template_ok: Optional[np.ndarray] = None
         self.fallback_log: List[dict] = []      # one entry per stepwise-decode fallback (diagnostics / tests)
+        import threading
+        self._upload_lock = threading.Lock()
         self.timers = {"preprocess_s": 0.0, "engine_s": 0.0, "gather_s": 0.0, "post_s": 0.0, "crops": 0, "engine_calls": 0}
 
     # ---- cost model of a scoring step (vstar_amd.search.SpeculationPolicy) ----
@@ -298,7 +300,8 @@ class VSM:
         self._images[int(slot)] = image
         if slot == 0:
             self._image = image
-        self.engine.set_image_async(image, int(slot))
+        with self._upload_lock:                 # the engine's staging ring serves one upload at a time
+            self.engine.set_image_async(image, int(slot))
 
     def release_image(self, slot: int = 0) -> None:
         """The stream driver recycled `slot`: drop the host-side PIL image kept for the decode fallback (a 4K RGB image is 25 MB;
