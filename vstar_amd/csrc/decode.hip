@@ -745,25 +745,30 @@ __global__ __launch_bounds__(256) void cached_attn_split_pv_kernel(
   for (int e = 0; e < 8; ++e) part[grp][l16 * 8 + e] = o[e];
   __syncthreads();
   float* op = ws_opart + ((int64_t)r * H + h) * SPLIT_P * D;
+  // Cross-workgroup hand-over WITHOUT fences: a __threadfence() here is a whole-L2 write-back + invalidate per workgroup on this
+  // chip (first version of this kernel: 4.18 ms / token against 3.79 unsplit).  The partials are written with agent-scope atomic
+  // stores (write-through to the coherence point, nothing left dirty in this XCD's L2), the wave waits until they are performed
+  // (vmcnt(0)), then takes its ticket with an agent-scope atomic; the last workgroup reads the partials with agent-scope atomic
+  // loads (never served from a stale line of its own L2).  Per-location coherence of atomics + completion of the stores before
+  // the ticket is exactly the ordering needed.
   if (tid < D) {
     float t = 0.f;
 #pragma unroll
     for (int g2 = 0; g2 < 16; ++g2) t += part[g2][tid];
-    op[p * D + tid] = t;
+    __hip_atomic_store(&op[p * D + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) ticket = atomicAdd(&ws_cnt[r * H + h], 1);
+  if (tid == 0) ticket = __hip_atomic_fetch_add(&ws_cnt[r * H + h], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (ticket != SPLIT_P - 1) return;
-  __threadfence();                                  // the other partitions' partials are visible
   if (tid < D) {
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < SPLIT_P; ++q) t += __builtin_nontemporal_load(&op[q * D + tid]);
+    for (int q = 0; q < SPLIT_P; ++q) t += __hip_atomic_load(&op[q * D + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     out[(int64_t)r * (H * D) + h * D + tid] = f2lp(t);
   }
-  if (tid == 0) ws_cnt[r * H + h] = 0;             // ready for the next launch
+  if (tid == 0) __hip_atomic_store(&ws_cnt[r * H + h], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
 // ------------------------------------------------ Perceiver attention ------------------------------------------------
