@@ -73,7 +73,9 @@ def cpu_baseline(cfg: VSMConfig, text_tokens: int) -> dict:
     return {"value": round(1.0 / total, 5), "unit": "crops/s", "cores": cores, "kind": "port",
             "sample": f"1 crop fp32 on torch CPU: CLIP-L/14@{cfg.clip_image_size} + projector {t1 - t0:.2f}s, "
                       f"all {cfg.llm_layers} LLaMA-7B layers at S={x.shape[1]} {t2 - t1:.2f}s (nothing extrapolated), "
-                      f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s"}
+                      f"heads + OWL-ViT@768 + SAM head {t3 - t2:.2f}s.  The REFERENCE's own model_forward(inference=True) (needs "
+                      "/root/reference: absent on the GPU box) on the build container's 8 cores, fp32, same crop geometry: 14.8 - 17.8 s "
+                      "per crop = 0.056 - 0.068 crops/s (oracle/gen_fulldepth_golden.py logs; round 4 trained-like set @336: 38 - 39 s)"}
 
 
 def _strict(args) -> bool:
@@ -423,10 +425,11 @@ def main():
                     "search leg on an 8K synthetic image with --minimum_size_scale 16 (depth-5 tree); separate line, not the headline")
     ap.add_argument("--rccl-selfcheck", action="store_true", help="N = 1 only: join a ONE-rank nccl (= RCCL) process group and run the N > 1 "
                     "code path — per-step all_gather_into_tensor of the device records, barrier, max-over-ranks — on the single GPU")
-    ap.add_argument("--weights", choices=("random", "trained_like"), default="random",
-                    help="seeded synthetic weights: i.i.d. random (rounds 1-3) or vstar_amd.weights.trained_like_state_dict — outlier "
-                         "channels, massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the answer "
-                         "template, so the search legs run the default strict_template=True path")
+    ap.add_argument("--weights", choices=("random", "trained_like"), default="trained_like",
+                    help="seeded synthetic weights: vstar_amd.weights.trained_like_state_dict (default since round 4: outlier channels, "
+                         "massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the answer template, "
+                         "so the search legs run the default strict_template=True path; same step time as random weights, measured) or "
+                         "the i.i.d. random set of rounds 1-3")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()
