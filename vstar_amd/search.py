@@ -709,14 +709,15 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         pool = ThreadPoolExecutor(max_workers=2 if async_up else 1, thread_name_prefix="vstar-image-prefetch")
     n_async = 0
 
-    def prefetch_ahead():
-        # images of the next samples that are not in the window yet, in sample order, at most `prefetch` in flight or waiting.
-        # pending[key] = (future, reserved slot or None)
+    def prefetch_ahead(limit=None):
+        # images of the next samples that are not in the window yet, in sample order, at most `limit` (default: `prefetch`) in
+        # flight or waiting.  pending[key] = (future, reserved slot or None)
         nonlocal n_async
         if pool is None:
             return
+        limit = prefetch if limit is None else limit
         i = next_sample
-        while i < n and len(pending) < prefetch:
+        while i < n and len(pending) < limit:
             image = samples[i][0]
             key = getattr(image, "key", id(image))
             if key not in slot_of and key not in pending:
@@ -790,9 +791,19 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         except StopIteration as done:
             finish(i, done.value)
 
+    # One process: a sample whose image is still being prepared by the prefetch thread does not hold up the searches that are
+    # ready — the engine step runs with what is live and the sample joins a later step (start-up of a job: the first window's
+    # images are decoded and uploaded WHILE the first steps run, instead of all of them before the first step).  With crop sharding
+    # every rank must form identical batches, and "is the future done" is a matter of timing: there the refill blocks.
+    nonblocking = world == 1 and pool is not None
+
     def refill():
         nonlocal next_sample
         while next_sample < n and len(gens) < window:
+            if nonblocking and gens:
+                key = getattr(samples[next_sample][0], "key", id(samples[next_sample][0]))
+                if key not in slot_of and key in pending and not pending[key][0].done():
+                    break
             if not start(next_sample):
                 break                               # every image slot is in use: wait for a search to end
             next_sample += 1
@@ -818,6 +829,7 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     calls0 = int(getattr(vsm, "timers", {}).get("engine_calls", 0)) if isinstance(getattr(vsm, "timers", None), dict) else None
     dkw = {"defer_mismatch": True} if getattr(vsm, "supports_deferred_mismatch", False) else {}
     try:
+        prefetch_ahead(limit=max(prefetch, min(window, n_slots // 2)))      # the whole first window's images go to the workers at once
         refill()
         drain_stats()
         refill()
