@@ -337,7 +337,8 @@ def test_stream_with_default_vsm_settings_batches_across_targets(vsm):
         assert torch.equal(x[0]["detection_result"], y[0]["detection_result"])
     # no per-prompt fragmentation: a step is one call unless its crops exceed the grouped entry point's activation-row budget
     # (6 one-prompt crops per call in this tiny configuration); round 3 made one call per distinct prompt = one per crop here
-    assert st["engine_steps"] <= st["engine_calls"] <= st["engine_steps"] + 4 and st["engine_calls"] < st["useful_crops"] / 2
+    # (a step that holds more than 6 crops — its live searches plus the policy's speculation — is two calls)
+    assert st["engine_steps"] <= st["engine_calls"] <= 2 * st["engine_steps"] and st["engine_calls"] < st["crops_scored"] / 2
     assert st["crops_scored"] / st["engine_calls"] > 3.0
 
 

@@ -36,6 +36,10 @@ struct VitTower {
   std::vector<VitBlock> blocks;
   // activations
   lp_t *im2col = nullptr, *patch_out = nullptr, *x = nullptr, *h = nullptr, *qkv = nullptr, *att = nullptr, *mlp_buf = nullptr;
+  // LayerNorms folded into the q|k|v and fc1 linears (round 4; build_tower): per-row statistics of the residual stream — the
+  // epilogues that write it emit 64-column sums of squares and sums — and 1 / sqrt(var + eps) per row; no normalised copy of x
+  bool fold = false;
+  float *part = nullptr, *rstd = nullptr;
 };
 // fp8 twin of a packed Linear (W8A8 mode): e4m3 rows + per-output-channel scales, same row order/padding as Lin::W
 struct Lin8 { uint8_t* W = nullptr; float* s = nullptr; };
@@ -205,8 +209,9 @@ struct EngineBase {
     p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr;
     p.C = C; p.ldc = ldc; p.c_group = 0;
     p.M = M; p.N = L.N; p.K = L.K;
-    p.row_scale = next_row_scale; p.sumsq_out = next_sumsq; p.sumsq_ld = next_sumsq_ld;     // one-shot (folded RMSNorm, llm_forward)
-    next_row_scale = nullptr; next_sumsq = nullptr; next_sumsq_ld = 0;
+    p.row_scale = next_row_scale; p.sumsq_out = next_sumsq; p.sumsq_ld = next_sumsq_ld;     // one-shot (folded norms)
+    p.stats_sum = next_stats_sum;
+    next_row_scale = nullptr; next_sumsq = nullptr; next_sumsq_ld = 0; next_stats_sum = 0;
     if (map_group > 0) {      // row map in force (shared-prefix LLaMA pass): compact row r -> (r / group) * gstride + off + r % group
       p.a_group = p.c_group = map_group;
       p.a_gstride = p.c_gstride = map_gstride;
@@ -216,6 +221,8 @@ struct EngineBase {
   }
   int map_group = 0; int64_t map_gstride = 0, map_off = 0;
   const float* next_row_scale = nullptr; float* next_sumsq = nullptr; int next_sumsq_ld = 0;   // consumed by the next lin()
+  int next_stats_sum = 0;
+  bool fold_vit_norms = true;          // VSTAR_FOLD_NORMS=0 / VSTAR_FOLD_VIT_NORMS=0: the LayerNorm kernels (the reference's rounding points)
   void collect_profile() {
     if (!profile) return;
     for (size_t i = 0; i + 1 < ev_used; i += 2) {
@@ -294,6 +301,24 @@ inline int EngineBase::build_tower(VitTower& t, const std::string& pre, const st
     RC(make_lin({lp + "mlp.fc1.weight"}, {lp + "mlp.fc1.bias"}, &b.fc1, hidden));
     RC(make_lin({lp + "mlp.fc2.weight"}, {lp + "mlp.fc2.bias"}, &b.fc2, mlp));
   }
+  // Linear(LayerNorm(x)) = rstd(x) * (x . W'^T) + (W b_ln + c), W' = W diag(g) with every row centred over k (the mean of x then
+  // drops out of the product): one bf16 rounding of W' in place of the reference's rounding of the normalised activations, no
+  // normalised copy of x written or read, no LayerNorm launch — the ViT twin of the RMSNorm fold of llm_forward.
+  for (const char* e : {"VSTAR_FOLD_NORMS", "VSTAR_FOLD_VIT_NORMS"})
+    if (const char* v = getenv(e)) if (atoi(v) == 0) fold_vit_norms = false;
+  t.fold = fold_vit_norms && hidden % 64 == 0;
+  if (t.fold) {
+    for (auto& b : t.blocks) {
+      if (b.qkv.K != hidden || b.fc1.K != hidden || !b.qkv.b || !b.fc1.b) { t.fold = false; break; }
+    }
+  }
+  if (t.fold) {
+    for (auto& b : t.blocks) {
+      KCHK(ln_fold_weights(b.qkv.W, b.qkv.b, b.ln1_g, b.ln1_b, b.qkv.N, b.qkv.K, stream));
+      KCHK(ln_fold_weights(b.fc1.W, b.fc1.b, b.ln2_g, b.ln2_b, b.fc1.N, b.fc1.K, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+  }
   const size_t rows = (size_t)maxB * t.N;
   RC(dalloc(&t.im2col, (size_t)maxB * t.P * t.kpad));
   RC(dalloc(&t.patch_out, (size_t)maxB * t.P * hidden));
@@ -302,6 +327,10 @@ inline int EngineBase::build_tower(VitTower& t, const std::string& pre, const st
   RC(dalloc(&t.qkv, rows * 3 * hidden));
   RC(dalloc(&t.att, rows * hidden));
   RC(dalloc(&t.mlp_buf, rows * mlp));
+  if (t.fold) {
+    RC(dalloc(&t.part, rows * (size_t)(2 * (hidden / 64))));
+    RC(dalloc(&t.rstd, rows));
+  }
   return 0;
 }
 
@@ -312,6 +341,27 @@ inline int EngineBase::run_tower(VitTower& t, const lp_t* pix, int B) {
   RC(lin(t.im2col, t.kpad, t.patch_lin, t.patch_out, C, B * t.P));
   KCHK(vit_assemble_tokens(t.patch_out, t.cls, t.pos, t.h, B, t.P, C, stream));
   KCHK(layernorm_lp(t.h, t.pre_g, t.pre_b, t.x, rows, C, 1e-5f, nullptr, 0, stream));
+  if (t.fold) {
+    // folded LayerNorms: q|k|v and fc1 read the residual stream itself, scaled per row by 1 / sqrt(var + eps); the statistics come
+    // from the rows (first block: the pre-LayerNorm's output) or from the partial sums the epilogue that wrote the stream left
+    const int nsp = C / 64;
+    for (int i = 0; i < t.nblocks; ++i) {
+      VitBlock& b = t.blocks[i];
+      if (i == 0) KCHK(ln_rstd_rows(t.x, rows, C, 1e-5f, t.rstd, stream));
+      else KCHK(ln_rstd_partials(t.part, 2 * nsp, rows, C, 1e-5f, t.rstd, stream));
+      next_row_scale = t.rstd;
+      RC(lin(t.x, C, b.qkv, t.qkv, 3 * C, rows));
+      KCHK(attn_forward(t.qkv, t.att, B, t.N, t.heads, 64, 0, 0.125f, stream));
+      next_sumsq = t.part; next_sumsq_ld = 2 * nsp; next_stats_sum = nsp;
+      RC(lin(t.att, C, b.out, t.x, C, rows, VSTAR_EPI_NONE, t.x, C));
+      KCHK(ln_rstd_partials(t.part, 2 * nsp, rows, C, 1e-5f, t.rstd, stream));
+      next_row_scale = t.rstd;
+      RC(lin(t.x, C, b.fc1, t.mlp_buf, t.mlp, rows, VSTAR_EPI_QUICK_GELU));
+      if (i + 1 < t.nblocks) { next_sumsq = t.part; next_sumsq_ld = 2 * nsp; next_stats_sum = nsp; }
+      RC(lin(t.mlp_buf, t.mlp, b.fc2, t.x, C, rows, VSTAR_EPI_NONE, t.x, C));
+    }
+    return 0;
+  }
   for (int i = 0; i < t.nblocks; ++i) {
     VitBlock& b = t.blocks[i];
     KCHK(layernorm_lp(t.x, b.ln1_g, b.ln1_b, t.h, rows, C, 1e-5f, nullptr, 0, stream));

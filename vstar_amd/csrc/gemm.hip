@@ -261,6 +261,10 @@ __global__ __launch_bounds__(MODE == 5 ? (NW == 4 ? 576 : 320) : 256, (NW != 4 &
         }
         const float ss = gemm_sumsq_span64_frags(o);
         if (fq == 0 && row < p.M && n0 + wc * 64 < n_out) p.sumsq_out[crow * p.sumsq_ld + (n0 + wc * 64) / 64] = ss;
+        if (p.stats_sum) {       // launch-uniform
+          const float sm = gemm_sum_span64_frags(o);
+          if (fq == 0 && row < p.M && n0 + wc * 64 < n_out) p.sumsq_out[crow * p.sumsq_ld + p.stats_sum + (n0 + wc * 64) / 64] = sm;
+        }
       }
       return;
     }
@@ -400,7 +404,7 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
           b.C = out_f32 ? (void*)((float*)p.C + M1 * p.ldc) : (void*)((lp_t*)p.C + M1 * p.ldc);
           if (p.res) b.res = p.res + M1 * p.ldr;
           if (p.row_scale) b.row_scale = p.row_scale + M1;
-          if (p.sumsq_out) b.sumsq_out = p.sumsq_out + M1 * p.sumsq_ld;
+          if (p.sumsq_out) b.sumsq_out = p.sumsq_out + M1 * p.sumsq_ld;      // (stats_sum is an offset inside a partial row: unchanged)
           b.tile_force = 128;
           hipError_t e = gemm256_lp(a, epilogue, out_f32, s);
           if (e != hipSuccess) return e;

@@ -407,6 +407,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
               const float ss = gemm_sumsq_span64_chunks(fv[it]);
               if (ch == 0) sq[(int64_t)it * RPI * p.sumsq_ld] = ss;
             }
+            if (p.stats_sum) {          // launch-uniform: the sums too (LayerNorm folded into the consumer)
+#pragma unroll
+              for (int it = 0; it < NIT; ++it) {
+                const float sm = gemm_sum_span64_chunks(fv[it]);
+                if (ch == 0) sq[(int64_t)it * RPI * p.sumsq_ld + p.stats_sum] = sm;
+              }
+            }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -438,6 +445,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           if (p.sumsq_out) {          // tile-uniform: statistics of the next RMSNorm from the values just stored (8 lanes = this row's 64 columns)
             const float ss = gemm_sumsq_span64_chunks(v);
             if (ch == 0 && row < p.M && colbase < n_out) p.sumsq_out[crow * p.sumsq_ld + colbase / 64] = ss;
+            if (p.stats_sum) {
+              const float sm = gemm_sum_span64_chunks(v);
+              if (ch == 0 && row < p.M && colbase < n_out) p.sumsq_out[crow * p.sumsq_ld + p.stats_sum + colbase / 64] = sm;
+            }
           }
         }
       }

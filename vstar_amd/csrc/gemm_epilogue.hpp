@@ -159,6 +159,15 @@ __device__ __forceinline__ float gemm_sumsq_span64_chunks(const lpx8& v) {
   const float h1 = ((f[4] * f[4] + f[5] * f[5]) + f[6] * f[6]) + f[7] * f[7];
   return dpp_add_half_mirror(dpp_add_xor2(dpp_add_xor1(h0 + h1)));
 }
+// GemmParams::stats_sum: the plain SUM of the same span, same tree (the second statistic of a LayerNorm folded into the consumer)
+__device__ __forceinline__ float gemm_sum_span64_chunks(const lpx8& v) {
+  float f[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = lp2f((lp_t)v[e]);
+  const float h0 = ((f[0] + f[1]) + f[2]) + f[3];
+  const float h1 = ((f[4] + f[5]) + f[6]) + f[7];
+  return dpp_add_half_mirror(dpp_add_xor2(dpp_add_xor1(h0 + h1)));
+}
 // gemm128 layout (accumulator layout): lane (fr = lane & 15, fq = lane >> 4) holds columns n*16 + fq*4 + {0..3} of fragment n = 0..3
 // as o[n][0..3]; half-chunks meet across lane ^ 16, chunks of a fragment across lane ^ 32, fragments inside the lane.
 __device__ __forceinline__ float gemm_sumsq_span64_frags(const float (&o)[4][4]) {
@@ -168,6 +177,17 @@ __device__ __forceinline__ float gemm_sumsq_span64_frags(const float (&o)[4][4])
     float h = ((o[n][0] * o[n][0] + o[n][1] * o[n][1]) + o[n][2] * o[n][2]) + o[n][3] * o[n][3];
     h += __shfl_xor(h, 16, 64);      // h0 + h1 of the chunk
     h += __shfl_xor(h, 32, 64);      // the fragment's two chunks
+    pn[n] = h;
+  }
+  return (pn[0] + pn[1]) + (pn[2] + pn[3]);
+}
+__device__ __forceinline__ float gemm_sum_span64_frags(const float (&o)[4][4]) {
+  float pn[4];
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    float h = ((o[n][0] + o[n][1]) + o[n][2]) + o[n][3];
+    h += __shfl_xor(h, 16, 64);
+    h += __shfl_xor(h, 32, 64);
     pn[n] = h;
   }
   return (pn[0] + pn[1]) + (pn[2] + pn[3]);

@@ -41,6 +41,12 @@ struct GemmParams {
   // the statistics of the next RMSNorm, produced where the residual stream is written.  Both kernels add in the same fixed
   // order (4+4 columns, pairs of 8-column chunks, 16-column fragments pairwise), so the partials are bit-identical.
   const float* row_scale; float* sumsq_out; int sumsq_ld;
+  // LayerNorm folded into the ViT linears (round 4): with stats_sum != 0 the epilogue ALSO writes the plain sum of every span to
+  // sumsq_out[crow * sumsq_ld + stats_sum + col / 64] (stats_sum = the number of 64-column spans of a row), same fixed tree; the
+  // consumer's row_scale is then 1 / sqrt(var + eps) with var = E[x^2] - E[x]^2 (ln_rstd_partials), its weights are
+  // W diag(g) with every row CENTRED over k (ln_fold_weights) — sum_k x_k (w_k - mean w) = sum_k (x_k - mean x) w_k, so no shift
+  // term is needed — and its bias is W b_ln + c
+  int stats_sum;
   // kernel choice: 0 = the dispatcher decides, 128 / 256 = force that tile (256 fails with hipErrorInvalidValue when the shape
   // is not gemm256_eligible).  Process-wide default for 0 calls: environment VSTAR_GEMM_TILE (A/B runs).
   int tile_force;
@@ -102,6 +108,13 @@ hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t
 // epilogue wrote (GemmParams::sumsq_out); the two agree bit for bit (same summation tree).  cols % 64 == 0.
 hipError_t rms_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r, hipStream_t s);
 hipError_t rms_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s);
+// LayerNorm twins: r[row] = 1 / sqrt(E[x^2] - E[x]^2 + eps) from the rows themselves / from the epilogue's partials (sumsq spans
+// at [0, cols/64), sum spans at [cols/64, 2 cols/64) of each partial row); same summation trees, bit-identical to each other
+hipError_t ln_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r, hipStream_t s);
+hipError_t ln_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s);
+// Folds LayerNorm(g, b_ln) into the packed Linear (W [n_rows, K] K-contiguous, bias [n_rows] or null) that consumes it, in place:
+// bias[n] = sum_k W[n,k] b_ln[k] + bias[n] (fp32, from the unscaled W), then W[n,:] = W[n,:] * g - mean_k(W[n,:] * g)
+hipError_t ln_fold_weights(lp_t* W, lp_t* bias, const lp_t* g, const lp_t* b_ln, int n_rows, int K, hipStream_t s);
 // W[n, k] = round(W[n, k] * w[k]) for n < rows: folds a norm weight into the columns of a packed Linear; fill_lp: v[i] = value
 hipError_t scale_cols_lp(lp_t* W, const lp_t* w, int64_t rows, int K, hipStream_t s);
 hipError_t fill_lp(lp_t* v, int64_t n, float value, hipStream_t s);

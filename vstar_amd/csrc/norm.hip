@@ -158,6 +158,87 @@ __global__ __launch_bounds__(256) void rms_rstd_partials_kernel(const float* __r
   if (lane == 0) r[row] = rsqrtf(total / (float)cols + eps);
 }
 
+// ---- LayerNorm folded into the consuming linear (ViT towers, round 4): variance statistics + load-time weight folding ----
+__device__ __forceinline__ float sum_span64(const float (&v)[8]) {
+  const float h0 = ((v[0] + v[1]) + v[2]) + v[3];
+  const float h1 = ((v[4] + v[5]) + v[6]) + v[7];
+  return dpp_add_half_mirror(dpp_add_xor2(dpp_add_xor1(h0 + h1)));
+}
+
+__device__ __forceinline__ float ln_rstd_from(float total_sq, float total_s, int cols, float eps) {
+  const float mean = total_s / (float)cols;
+  const float var = fmaxf(total_sq / (float)cols - mean * mean, 0.f);
+  return rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void ln_rstd_rows_kernel(const lp_t* __restrict__ x, int rows, int cols, float eps, float* __restrict__ r) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const lp_t* xr = x + (int64_t)row * cols;
+  const int nspan = cols >> 6;
+  float total_sq = 0.f, total_s = 0.f;
+  for (int p0 = 0; p0 < nspan; p0 += 64) {
+    float mine_sq = 0.f, mine_s = 0.f;
+    for (int s0 = 0; s0 < 64; s0 += 8) {
+      const int sp = p0 + s0 + (lane >> 3);
+      float v[8];
+      if (sp < nspan) {
+        const lpx8 t = *(const lpx8*)(xr + sp * 64 + (lane & 7) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = lp2f((lp_t)t[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      const float psq = sumsq_span64(v), ps = sum_span64(v);
+      const float gsq = __shfl(psq, (lane & 7) * 8, 64), gs = __shfl(ps, (lane & 7) * 8, 64);
+      if ((lane >> 3) == (s0 >> 3)) { mine_sq = gsq; mine_s = gs; }
+    }
+    total_sq += sum_spans64(mine_sq);
+    total_s += sum_spans64(mine_s);
+  }
+  if (lane == 0) r[row] = ln_rstd_from(total_sq, total_s, cols, eps);
+}
+
+__global__ __launch_bounds__(256) void ln_rstd_partials_kernel(const float* __restrict__ partials, int ld, int rows, int cols, float eps,
+                                                               float* __restrict__ r) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* pr = partials + (int64_t)row * ld;
+  const int nspan = cols >> 6;
+  float total_sq = 0.f, total_s = 0.f;
+  for (int p0 = 0; p0 < nspan; p0 += 64) {
+    const bool on = p0 + lane < nspan;
+    total_sq += sum_spans64(on ? pr[p0 + lane] : 0.f);
+    total_s += sum_spans64(on ? pr[nspan + p0 + lane] : 0.f);
+  }
+  if (lane == 0) r[row] = ln_rstd_from(total_sq, total_s, cols, eps);
+}
+
+// one workgroup per packed weight row: bias += W . b_ln (unscaled W, fp32), then W := W * g - mean_k(W * g), rounded once
+__global__ __launch_bounds__(256) void ln_fold_kernel(lp_t* __restrict__ W, lp_t* __restrict__ bias, const lp_t* __restrict__ g,
+                                                      const lp_t* __restrict__ b_ln, int K) {
+  __shared__ float red[2][4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  lp_t* w = W + (int64_t)n * K;
+  float dot = 0.f, sum = 0.f;
+  for (int k = tid; k < K; k += 256) {
+    const float wv = lp2f(w[k]);
+    dot += wv * lp2f(b_ln[k]);
+    sum += wv * lp2f(g[k]);
+  }
+  dot = wave_sum(dot);
+  sum = wave_sum(sum);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = dot; red[1][tid >> 6] = sum; }
+  __syncthreads();
+  dot = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  const float mean = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)K;
+  for (int k = tid; k < K; k += 256) w[k] = f2lp(lp2f(w[k]) * lp2f(g[k]) - mean);
+  if (tid == 0 && bias) bias[n] = f2lp(lp2f(bias[n]) + dot);
+}
+
 __global__ void scale_cols_kernel(lp_t* __restrict__ W, const lp_t* __restrict__ w, int64_t n_vec, int kv) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_vec) return;
@@ -184,6 +265,24 @@ hipError_t rms_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r,
 hipError_t rms_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s) {
   if (cols % 64 || rows <= 0) return hipErrorInvalidValue;
   hipLaunchKernelGGL(rms_rstd_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, partials, ld, rows, cols, eps, r);
+  return hipGetLastError();
+}
+
+hipError_t ln_rstd_rows(const lp_t* x, int rows, int cols, float eps, float* r, hipStream_t s) {
+  if (cols % 64 || rows <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_rstd_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, rows, cols, eps, r);
+  return hipGetLastError();
+}
+
+hipError_t ln_rstd_partials(const float* partials, int ld, int rows, int cols, float eps, float* r, hipStream_t s) {
+  if (cols % 64 || rows <= 0 || ld < 2 * (cols / 64)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_rstd_partials_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, partials, ld, rows, cols, eps, r);
+  return hipGetLastError();
+}
+
+hipError_t ln_fold_weights(lp_t* W, lp_t* bias, const lp_t* g, const lp_t* b_ln, int n_rows, int K, hipStream_t s) {
+  if (n_rows <= 0 || K <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(n_rows), dim3(256), 0, s, W, bias, g, b_ln, K);
   return hipGetLastError();
 }
 
