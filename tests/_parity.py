@@ -20,7 +20,7 @@ def assert_within_bf16_noise(name, got, ref32, ref16, factor=1.5, report=None):
 
 def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32, upmean16, factor=1.5, report=None):
     """Masks [B,192,192] (or one mask): pattern (per-mask mean removed) at the `factor` rule pooled over the batch; offset
-    inside the 3-sigma band of the noise model sigma = sqrt(eps_h^2 + eps_mu^2) |h| |mu| / sqrt(32) per mask (see
+    inside the band of the noise model sigma = sqrt(eps_h^2 + eps_mu^2) |h| |mu| / sqrt(32) per mask (4 sigma each, rms pooled; see
     tests/test_engine_gpu.py::test_engine_matches_reference_golden).  hyper*/upmean*: [B,32] operands of the final product."""
     f = lambda a, nd: np.asarray(a, np.float64).reshape((-1,) + tuple(np.asarray(a).shape[-nd:]))  # noqa: E731
     got, ref32, ref16 = f(got, 2), f(ref32, 2), f(ref16, 2)
@@ -30,6 +30,12 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
     if report is not None:
         report["mask_pattern"] = (e, n)
     assert e <= factor * n, f"mask pattern: engine {e:.2e} vs bf16 noise {n:.2e}"
+    # Offsets in units of the noise model's sigma.  Round 4: the suite gates ~100 masks; a per-mask 3-sigma bound alone raises a
+    # false alarm in one run of four even for a perfect implementation (0.27 % per mask under an ideal Gaussian, more with real
+    # tails) — a change of rounding points (the folded ViT LayerNorms) moved one tiny-model mask from 2.9 to 3.08 sigma.  The bound is
+    # therefore 4 sigma per mask (6e-5 each) AND the rms over the call's n masks within 1 + 3 / sqrt(2 n) of its expectation 1
+    # (three standard deviations of the rms of n unit Gaussians: 3.1 for one mask, 2.06 for four, 1.375 for thirty-two).
+    zs = []
     for b in range(got.shape[0]):
         eps = np.hypot(rel_l2(h16[b], h32[b]), rel_l2(m16[b], m32[b]))
         sigma = eps * np.linalg.norm(h32[b]) * np.linalg.norm(m32[b]) / np.sqrt(h32.shape[-1])
@@ -37,7 +43,11 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
         off16 = abs(ref16[b].mean() - ref32[b].mean())
         if report is not None:
             report[f"mask_offset_sigma[{b}]"] = (off / sigma, off16 / sigma)
-        assert off <= 3.0 * sigma, f"mask {b}: offset {off:.4f} outside 3 sigma = {3 * sigma:.4f} of the bf16 noise model"
+        zs.append(off / sigma)
+        assert off <= 4.0 * sigma, f"mask {b}: offset {off:.4f} outside 4 sigma = {4 * sigma:.4f} of the bf16 noise model"
+    n = len(zs)
+    rms = float(np.sqrt(np.mean(np.square(zs))))
+    assert rms <= 1.0 + 3.0 / np.sqrt(2.0 * n), f"mask offsets: rms {rms:.2f} sigma over {n} masks (bound {1.0 + 3.0 / np.sqrt(2.0 * n):.2f})"
 
 
 def fmt(report):
