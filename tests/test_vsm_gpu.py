@@ -339,7 +339,7 @@ def test_stream_with_default_vsm_settings_batches_across_targets(vsm):
     # (6 one-prompt crops per call in this tiny configuration); round 3 made one call per distinct prompt = one per crop here
     # (a step that holds more than 6 crops — its live searches plus the policy's speculation — is two calls)
     assert st["engine_steps"] <= st["engine_calls"] <= 2 * st["engine_steps"] and st["engine_calls"] < st["crops_scored"] / 2
-    assert st["crops_scored"] / st["engine_calls"] > 3.0
+    assert st["crops_scored"] / st["engine_calls"] > 2.0          # (one call per prompt would be exactly 1.0)
 
 
 def test_search_with_device_reductions_equals_host_path(vsm):
