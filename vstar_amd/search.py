@@ -704,9 +704,10 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     async_up = bool(getattr(vsm, "supports_async_upload", False)) and want_async
     if prefetch > 0 and (async_up or any(callable(smp[0]) for smp in samples)):
         from concurrent.futures import ThreadPoolExecutor
-        # two workers: decoding a 4K image takes ~60 ms of host time and a step of a full window consumes 4 - 5 new images, so one
-        # worker alone cannot keep up with a 230-ms engine step; the uploads themselves are serialised inside the VSM
-        pool = ThreadPoolExecutor(max_workers=2 if async_up else 1, thread_name_prefix="vstar-image-prefetch")
+        # several workers: decoding a 4K image takes 40 - 100 ms of host time (PIL releases the GIL) and a step of a full window
+        # consumes 4 - 5 new images; with sharded crops every rank decodes every image while its engine steps shrink with the world
+        # size, so the decode rate is what must scale.  The uploads themselves are serialised inside the VSM
+        pool = ThreadPoolExecutor(max_workers=4 if async_up else 1, thread_name_prefix="vstar-image-prefetch")
     n_async = 0
 
     def prefetch_ahead(limit=None):
