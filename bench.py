@@ -412,7 +412,7 @@ def main():
     ap.add_argument("--fake-engine", action="store_true", help="CPU plumbing check of the N-process path (gloo, stub step): "
                     "exercises rank/world handling, the per-step all-gather, the barrier and the max-over-ranks timing. NOT a bench")
     ap.add_argument("--search-targets", type=int, default=16, help="targets of the config-2 search leg (>= 16 per BASELINE config 2)")
-    ap.add_argument("--stream-samples", type=int, default=256, help="(image, target) samples of the best-first stream leg")
+    ap.add_argument("--stream-samples", type=int, default=512, help="(image, target) samples of the best-first stream leg")
     ap.add_argument("--stream-targets-per-image", type=int, default=2)
     ap.add_argument("--stream-window", type=int, default=0, help="concurrent searches of the stream leg (0 = one engine batch x ranks)")
     ap.add_argument("--no-stream-leg", action="store_true")
