@@ -186,7 +186,8 @@ int vstar_preprocess_crops_slots(vstar_handle* h, int B, const int32_t* boxes_xy
  * the stream search uploads the images of the samples that enter the window NEXT while the current step is on the GPU (in the
  * reference the equivalent host work — Image.open + processors, visual_search.py:541-550 — sits between two forward passes).
  * Contract: no crop of the slot's previous image may still be waiting to be launched (crops already launched are ordered before
- * the copy). */
+ * the copy); ONE asynchronous upload at a time per handle (the staging ring is not re-entrant: `VSM.set_image_async` serialises
+ * its callers), concurrently with at most one scoring / preprocessing call on another thread. */
 int vstar_image_set_slot_async(vstar_handle* h, int slot, const uint8_t* rgb, int height, int width);
 
 /* Greedy free-text decode of ONE crop with a KV cache — VSMForCausalLM.inference for mode='vqa' (VSM.py:438-462 ->
