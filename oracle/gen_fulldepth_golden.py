@@ -109,7 +109,7 @@ def main():
                          "answer template for SyntheticTokenizer prompts; written to full7b_tl_{336,224}.npz")
     a = ap.parse_args()
     tl = a.weights == "trained_like"
-    crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else ((0, 9, 17, 31) if tl else CROPS)
+    crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else ((0, 9, 17, 31) if tl else CROPS)     # (round 4: the 336 trained-like file was recorded with --crops 0,4,9,13,17,22,26,31)
     out_path = os.path.join(GOLDEN, f"full7b_{'tl_' if tl else ''}{a.image_size}.npz")
     assert ref_shim.available(), "reference tree not found"
     torch.set_num_threads(a.threads)
