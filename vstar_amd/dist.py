@@ -93,6 +93,11 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: VSTAR_DIST_BACKEND forces the backend, VSTAR_DIST_DEVICE puts every rank on ONE device — several ranks of the REAL
+    # engine on a single GPU over gloo (RCCL refuses two ranks on one device): tests/test_two_ranks_one_gpu.py
+    backend = os.environ.get("VSTAR_DIST_BACKEND") or backend
+    if os.environ.get("VSTAR_DIST_DEVICE") is not None:
+        local_rank = int(os.environ["VSTAR_DIST_DEVICE"])
     if (world > 1 or os.environ.get("VSTAR_FORCE_PROCESS_GROUP") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
