@@ -333,6 +333,56 @@ def test_visual_search_entry_point_visualization_writes_the_references_file_set(
             assert im.size == whole.size                           # the root patch is the whole image
 
 
+def test_trained_like_weights_are_deterministic_keep_the_key_set_and_answer_the_template_on_the_oracle():
+    """vstar_amd.weights.trained_like_state_dict (round 4): same keys / shapes as the random set, reproducible, layer aliasing of
+    share_layers preserved through the dtype conversion, feature switches independent of the draw order — and, through the CPU
+    oracle at the tiny geometry, a greedy continuation of a locate prompt that IS "Sure, [LOC]." followed by EOS, with outlier
+    channels in the residual stream (max / rms of the final hidden state well above the random set's)."""
+    from oracle import vsm_oracle
+    from vstar_amd.weights import random_state_dict, template_chain, trained_like_state_dict
+    cfg = VSMConfig.tiny()
+    tok = pp.SyntheticTokenizer(cfg.llm_vocab)
+    chain = template_chain(tok)
+    assert len(chain) == 5 and chain[-1][1] == tok.eos_token_id and chain[2][1] == cfg.llm_vocab - 1
+    a = trained_like_state_dict(cfg, seed=3, chain=chain)
+    b = trained_like_state_dict(cfg, seed=3, chain=chain)
+    ref = random_state_dict(cfg, seed=3)
+    assert list(a) == list(ref) and all(a[k].shape == ref[k].shape and a[k].dtype == torch.bfloat16 for k in a)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert a["model.layers.1.mlp.down_proj.weight"] is a["model.layers.0.mlp.down_proj.weight"]        # share_layers aliasing survives
+    only_attn = trained_like_state_dict(cfg, seed=3, chain=chain, features=("attn",))
+    assert torch.equal(only_attn["model.layers.0.mlp.down_proj.weight"], ref["model.layers.0.mlp.down_proj.weight"])
+    assert not torch.equal(only_attn["model.layers.0.self_attn.k_proj.weight"], ref["model.layers.0.self_attn.k_proj.weight"])
+    # greedy decode on the oracle: prompt + teacher-forced template, arg-max at the answer positions
+    q = pp.LOCATE_QUESTION.format("green bottle")
+    ids_p = pp.tokenizer_image_token(pp.build_prompt(q), tok)
+    ids_f = pp.tokenizer_image_token(pp.build_prompt(q, answer=pp.ANSWER_TEMPLATE), tok) + [tok.eos_token_id]
+    P = cfg.n_img_tokens
+    pos = [c - 1 + (P - 1) for c in range(len(ids_p), len(ids_f))]
+    clip = torch.randn(1, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    sd32 = {k: v.float() for k, v in a.items()}
+    peaks, orig = [], vsm_oracle.rms_norm
+
+    def spy(x, w, eps):                      # the RAW residual stream as every RMSNorm sees it: worst token's max / rms
+        peaks.append(float((x.abs().amax(-1) / x.pow(2).mean(-1).sqrt()).max()))
+        return orig(x, w, eps)
+
+    vsm_oracle.rms_norm = spy
+    try:
+        with torch.no_grad():
+            out = vsm_oracle.vsm_forward(sd32, cfg, clip, None, torch.tensor([ids_f[:-1]]), cfg.llm_vocab - 1, verify_pos=torch.tensor([pos[:-1]]))
+            peak_tl = max(peaks)
+            peaks.clear()
+            vsm_oracle.vsm_forward({k: v.float() for k, v in ref.items()}, cfg, clip, None, torch.tensor([ids_f[:-1]]), cfg.llm_vocab - 1)
+            peak_rnd = max(peaks)
+    finally:
+        vsm_oracle.rms_norm = orig
+    assert out["tf_argmax"][0].tolist() == ids_f[len(ids_p):-1]
+    top2 = out["tf_logits"][0].topk(2, -1).values
+    assert float((top2[:, 0] - top2[:, 1]).min()) > 10.0                          # decided by a wide margin, not by luck
+    assert peak_tl > 2.0 * peak_rnd and peak_tl > 10.0, (peak_tl, peak_rnd)        # outlier channels / the massive-activation BOS
+
+
 def test_scores_keep_the_references_bf16_sigmoid_ties():
     """visual_search.py:225 returns det_result['pred_logits'][0].sigmoid() of a BF16 tensor: the rounding makes distinct logits
     tie, and the scheduler's argmax() (first maximum) / `> confidence` comparisons act on the rounded values.  The drop-in keeps

@@ -540,6 +540,69 @@ def test_stream_prefetches_image_loaders_without_changing_anything(prefetch):
         assert threads == {threading.current_thread().name}
 
 
+class _AsyncSlotVSM(_SlotVSM):
+    """_SlotVSM with the asynchronous upload of the real VSM (set_image_async from the prefetch threads): records who uploaded which
+    slot from which thread, and fails if a crop is scored from a slot whose upload has not been issued."""
+    supports_async_upload = True
+
+    def __init__(self, **kw):
+        import threading
+        super().__init__(**kw)
+        self.async_uploads, self.lock = [], threading.Lock()
+
+    def set_image_async(self, image, slot):
+        import threading
+        import zlib
+        with self.lock:
+            self.images[slot] = zlib.crc32(np.asarray(image.resize((16, 16))).tobytes())
+            self.async_uploads.append((slot, threading.current_thread().name))
+
+    def release_image(self, slot=0):
+        pass
+
+
+@pytest.mark.parametrize("slow_ms,window", [(0, 3), (30, 3), (30, 8)])
+def test_stream_async_uploads_from_prefetch_threads_change_nothing(slow_ms, window):
+    """Round 4: with an engine that offers asynchronous uploads the prefetch threads load AND upload the next samples' images into
+    image slots reserved ahead; in one process a sample whose image is not ready joins a later step (slow loaders: the first steps run
+    while the first window is still loading).  Results equal the synchronous path's; every image is uploaded once per residency, the
+    prefetched ones from a worker thread; no crop is ever cut from a slot before its upload was issued (the stand-in would raise)."""
+    import threading
+    import time
+    base = _stream_samples(n_images=7, per_image=(1, 2))
+    calls = []
+
+    class Loader:
+        def __init__(self, k, img):
+            self.key, self.img = ("file", k), img
+
+        def __call__(self):
+            time.sleep(slow_ms / 1e3)
+            calls.append(self.key)
+            return self.img
+
+    by_img, samples = {}, []
+    for img, name, gt, sm in base:
+        ld = by_img.setdefault(id(img), Loader(len(by_img), img))
+        samples.append((ld, name, gt, sm))
+    kw = dict(confidence_high=0.9, confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    want = search.visual_search_stream(_SlotVSM(max_batch=8), base, window=window, **kw)
+    vsm = _AsyncSlotVSM(max_batch=8)
+    st = {}
+    got = search.visual_search_stream(vsm, samples, window=window, stats=st, **kw)
+    for a, b in zip(want, got):
+        assert a[1] == b[1] and a[2] == b[2] and a[0]["bbox"] == b[0]["bbox"]
+    assert sorted(calls) == sorted(ld.key for ld in by_img.values())                      # every file opened once
+    assert len(vsm.async_uploads) + len(vsm.uploads) == len(by_img)                        # ... and uploaded once
+    assert st["async_uploads"] == len(vsm.async_uploads) >= 1
+    assert all(t.startswith("vstar-image-prefetch") for _, t in vsm.async_uploads)
+    assert threading.active_count() < 12                                                    # the pool is shut down
+    # explicit opt-out: everything on the search thread again
+    v2 = _AsyncSlotVSM(max_batch=8)
+    search.visual_search_stream(v2, samples, window=window, async_upload=False, **kw)
+    assert v2.async_uploads == [] and len(v2.uploads) == len(by_img)
+
+
 def test_stream_prefetch_propagates_loader_errors():
     base = _stream_samples(n_images=3, per_image=(1,))
 
