@@ -27,6 +27,9 @@ def parse_args(argv):
     p.add_argument("--device", default=0, type=int)
     p.add_argument("--search-window", dest="search_window", default=0, type=int, help="concurrent visual searches per engine batch "
                    "(cross-image lock step); 0 = one engine batch, 1 = one image at a time like the reference")
+    p.add_argument("--engine-comm", action="store_true", help="world > 1 on GPUs: gather the per-step records with the C-ABI's own RCCL "
+                   "communicator on the engine stream (vstar_allgather_results) instead of torch.distributed — EXPERIMENTAL, falls "
+                   "back to torch.distributed on every rank together if the communicator cannot be set up")
     return p.parse_args(argv)
 
 
@@ -54,6 +57,9 @@ def main(argv):
             vsm = getattr(importlib.import_module(mod), fn)(args, local_rank)
         elif world > 1:
             vsm = make_vsm(args, local_rank)
+        if args.engine_comm and vsm is not None and world > 1:
+            from vstar_amd.dist import maybe_engine_comm
+            maybe_engine_comm(vsm)
         eval_model(args, vqa_llm, vsm, world=world, rank=rank)
         finished = True
     finally:
