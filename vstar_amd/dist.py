@@ -60,7 +60,8 @@ def maybe_engine_comm(vsm, group=None) -> bool:
     try:
         if eng is None or not hasattr(eng, "comm_init"):
             raise RuntimeError("engine has no comm entry points")
-        engine_comm_init(eng, group)
+        if getattr(eng, "comm_world", 0) != dist.get_world_size(group):     # (an engine keeps its communicator: set up once)
+            engine_comm_init(eng, group)
     except Exception as exc:            # noqa: BLE001 — fall back, but on EVERY rank
         import warnings
         warnings.warn(f"engine communicator not available ({type(exc).__name__}: {exc}); using torch.distributed")
