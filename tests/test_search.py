@@ -505,6 +505,30 @@ def test_speculation_never_costs_a_lone_search_more_than_one_step(conf):
     assert total_spec <= 1.05 * total_plain + 2 * pol.step_ms(1)      # over the set: at worst a wash (plus what it cost to learn the regime)
 
 
+def test_speculation_priors_follow_the_observed_hit_rate():
+    """Closed loop (round 4): the policy learns from the searches that finished how many of its speculative crops were really
+    visited, and scales every candidate's probability by observed / predicted hits.  Exhaustive searches (everything speculated is
+    visited sooner or later) push the calibration above 1, searches that mostly end at their second node push it below 1 — and a
+    policy with explicit priors is left alone."""
+    samples = _stream_samples(n_images=8, per_image=(1, 2))
+    base = dict(confidence_low=0.0, target_cue_threshold=-1.0, target_cue_threshold_minimum=-1.0)
+    up, down = search.SpeculationPolicy(cap=8), search.SpeculationPolicy(cap=8)
+    for smp in samples:
+        search.visual_search_stream(_SlotVSM(max_batch=8), [smp], window=1, policy=up, confidence_high=2.0, **base)
+        search.visual_search_stream(_SlotVSM(max_batch=8), [smp], window=1, policy=down, confidence_high=0.6, **base)
+    assert up.calibration > 1.05 and up._pred > 0 and up._hits > up._pred
+    assert down.calibration < 0.95
+    fixed = search.SpeculationPolicy(cap=8, p_child=0.4)
+    search.visual_search_stream(_SlotVSM(max_batch=8), samples[:3], window=1, policy=fixed, confidence_high=2.0, **base)
+    assert fixed.calibration == 1.0 and fixed.p_child == 0.4
+    # a low calibration makes the policy pickier: fewer candidates pass the cost test
+    cands = [(0.75, "q0"), (0.525, "q1"), (0.37, "q2"), (0.25, "c0")]
+    fresh = search.SpeculationPolicy(cap=8)
+    n_before = len(fresh.select(1, cands, 1))
+    fresh.calibration = 0.5
+    assert len(fresh.select(1, cands, 1)) < n_before
+
+
 @pytest.mark.parametrize("prefetch", [0, 1, 3])
 def test_stream_prefetches_image_loaders_without_changing_anything(prefetch):
     """Lazy loaders (what visual_search.py / vstar_bench_eval.py hand over: open + decode a file) run ahead of the window on a worker

@@ -545,7 +545,8 @@ class SpeculationPolicy:
     0.75 x 0.7^r, a child of that entry with 0.45 x the product (round 3 guessed 0.45 / 0.5 x 0.5^r / the bare product: children
     over-, the queue under-estimated).  With the MI355X step table a lone search therefore speculates the head of its queue but
     not the four children of the node in flight (expected saving 0.25 x t(1) = 4.2 ms < 6.7 ms marginal cost); `wasted_crop_frac`
-    and bench.py's `search_latency` leg are the measured outcome."""
+    and bench.py's `search_latency` leg are the measured outcome.  The loop is closed on that outcome: `observe_speculation`
+    compares the hits of every finished search with what the priors had promised and scales all probabilities by the ratio."""
 
     DEFAULT_STEP_MS = {1: 16.8, 2: 23.5, 4: 36.5, 8: 63.7, 16: 126.5, 32: 232.7}
     # (mean visited nodes per search, p_child, p_queue, queue_decay): profiles/r04_speculation_priors.json.  How often a candidate
@@ -554,6 +555,7 @@ class SpeculationPolicy:
     REGIMES = ((1.77, 0.109, 0.403, 0.32), (2.64, 0.170, 0.595, 0.55), (3.69, 0.219, 0.693, 0.68), (4.41, 0.250, 0.747, 0.75),
                (6.64, 0.338, 0.835, 0.83), (11.91, 0.481, 0.929, 0.93))
     PRIOR_NODES, PRIOR_WEIGHT = 4.65, 4.0
+    CAL_WEIGHT = 6.0
 
     def __init__(self, step_ms: Optional[Dict[int, float]] = None, cap: int = 32, world: int = 1, p_child: float = 0.25,
                  p_queue: float = 0.75, queue_decay: float = 0.7, max_queue_rank: int = 4, enabled: bool = True,
@@ -564,6 +566,13 @@ class SpeculationPolicy:
         self.queue_child_factor = queue_child_factor
         self.adaptive = (p_child, p_queue, queue_decay) == (0.25, 0.75, 0.7)      # explicit priors are kept as given
         self._nodes_sum, self._nodes_n = 0.0, 0
+        # closed loop on the hit rate: `calibration` = observed hits / predicted hits over the searches that have finished
+        # (`observe_speculation`); every candidate's probability is multiplied by it before the cost test.  Starts at 1 with the
+        # weight of CAL_WEIGHT predicted hits, clamped to [0.25, 1.5]: priors replayed on a stand-in cannot know a model's
+        # detection confidence or how its heat maps rank the queue (first measurement on the engine: 44 % hits where the table
+        # promised 64 %)
+        self.calibration, self._hits, self._pred = 1.0, 0.0, 0.0
+        self.last_selected_p: List[float] = []
 
     def observe(self, nodes_visited: int) -> None:
         """A search ended after visiting `nodes_visited` nodes: move the priors to the regime the searches are really in.  (Under
@@ -585,6 +594,14 @@ class SpeculationPolicy:
                 return
         self.p_child, self.p_queue, self.queue_decay = R[-1][1:]
 
+    def observe_speculation(self, predicted_hits: float, hits: int) -> None:
+        """A search ended: of its speculative crops `hits` were visited later, the priors had promised `predicted_hits`."""
+        if not self.adaptive:
+            return
+        self._pred += float(predicted_hits)
+        self._hits += float(hits)
+        self.calibration = min(1.5, max(0.25, (self._hits + self.CAL_WEIGHT) / (self._pred + self.CAL_WEIGHT)))
+
     def step_ms(self, n_crops: int) -> float:
         """t(B): one engine step of n_crops crops dealt over `world` ranks (piecewise linear in the per-rank batch)."""
         b = -(-max(n_crops, 0) // self.world)
@@ -603,16 +620,20 @@ class SpeculationPolicy:
         if not self.enabled:
             return []
         chosen, B = [], n_must
+        self.last_selected_p = []
         base = self.step_ms(n_must)
+        cal = getattr(self, "calibration", 1.0)
         for p, item in sorted(cands, key=lambda c: -c[0]):
             if B >= self.cap:
                 break
+            p = min(p * cal, 1.0)
             if p * self.step_ms(1) / max(n_live, 1) < self.step_ms(B + 1) - self.step_ms(B):
                 break
             # bounded downside: whatever the priors say, one step's speculation never costs more than one single-crop step
             if self.step_ms(B + 1) - base > self.step_ms(1):
                 break
             chosen.append(item)
+            self.last_selected_p.append(p)
             B += 1
         return chosen
 
@@ -697,6 +718,8 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
     want_stats: Dict[int, List] = {}
     next_sample = 0
     engine_steps = 0
+    n_spec: Dict[int, int] = {}                   # search -> speculative crops scored for it
+    pred_hits: Dict[int, float] = {}              # search -> sum of the (calibrated) visit probabilities of those crops
 
     loaded: Dict[object, object] = {}             # slot key -> the PIL image living in that slot
     pending: Dict[object, object] = {}            # slot key -> Future of a loader running ahead (prefetch)
@@ -770,6 +793,9 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
         results[i] = value
         if hasattr(policy, "observe"):
             policy.observe(int(per_stats[i].get("path_visited", 1)))
+        if hasattr(policy, "observe_speculation") and n_spec.get(i):
+            wasted = int(per_stats[i].get("crops_scored", 0)) - int(per_stats[i].get("path_visited", 0))
+            policy.observe_speculation(pred_hits.get(i, 0.0), max(n_spec[i] - max(wasted, 0), 0))
         sl = scorers[i].slot
         slot_refs[sl] -= 1
         if slot_refs[sl] == 0:                     # last live search of that image: the slot can take another image
@@ -846,6 +872,9 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
             must = [(i, j, b) for i, boxes in reqs.items() for j, b in enumerate(boxes)]
             cands = [] if own_plans else [(p, (i, b)) for i in reqs for p, b in scorers[i].candidates(policy)]
             extra = policy.select(len(must), cands, len(reqs)) if cands else []
+            for (i, _), pv in zip(extra, getattr(policy, "last_selected_p", []) or [0.0] * len(extra)):
+                n_spec[i] = n_spec.get(i, 0) + 1
+                pred_hits[i] = pred_hits.get(i, 0.0) + float(pv)
             flat = [(i, j, list(b)) for i, j, b in must] + [(i, None, list(b)) for i, b in extra]
             # box-major order inside the step: requests for the same crop (same image slot, same box) next to each other so that
             # a grouping VSM scores that crop's towers once for all its prompts
