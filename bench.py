@@ -420,7 +420,7 @@ def main():
     ap.add_argument("--stream-window", type=int, default=0, help="concurrent searches of the stream leg (0 = one engine batch x ranks)")
     ap.add_argument("--no-stream-leg", action="store_true")
     ap.add_argument("--no-latency-leg", action="store_true", help="skip the default-VSM stream run and the window-1 latency legs")
-    ap.add_argument("--latency-samples", type=int, default=24, help="(image, target) samples of each window-1 latency run")
+    ap.add_argument("--latency-samples", type=int, default=48, help="(image, target) samples of each window-1 latency run")
     ap.add_argument("--no-small-batch", action="store_true", help="skip the 1/2/4/8 crops-per-rank table")
     ap.add_argument("--no-config5-line", action="store_true", help="skip the bounded W8A8 (BASELINE config 5 precision) sub-object")
     ap.add_argument("--no-search-leg", action="store_true", help="skip the end-to-end search leg (N = 1 only by default)")
