@@ -691,8 +691,12 @@ def main():
 
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline and not args.tiny:
+        if not args.no_cpu_baseline and not args.tiny:
+            # rank 0 times the CPU port at every N (the other ranks wait in the closing barrier, outside every timed region): a
+            # SCALE line without it would count as unmeasured
             cpu = cpu_baseline(cfg, T)
+            if world > 1:
+                cpu["note"] = f"timed on rank 0 while the other {world - 1} ranks idle in the closing barrier"
         line = {
             "metric": "searched crops/sec (336x336 tiles, 7B VSM " + ("W8A8 fp8" if args.fp8 else "bf16") + ")",
             "value": round(crops_per_s, 3), "unit": "crops/s",

@@ -279,6 +279,14 @@ int vstar_op_gemm_norm(void* stream, const uint16_t* dev_A, int64_t lda, const u
                        const float* dev_row_scale, float* dev_sumsq_out, int sumsq_ld);
 int vstar_op_rms_rstd(void* stream, const uint16_t* dev_x, const float* dev_partials, int ld, int rows, int cols, float eps,
                       float* dev_r);
+/* Op-level door for the weight preparation of a LayerNorm folded into its consuming linear (the ViT towers' q|k|v and fc1;
+ * engine_base.hpp::build_tower): in place, W[n,:] := round(W[n,:] * g - mean_k(W[n,:] * g)) with ZERO-SUM rounding (the rounded
+ * row sums to zero within its smallest step, so that the row mean of the activations really drops out of x . W'^T), and
+ * bias[n] += W[n,:] . b_ln.  W [n_rows, K] bf16, bias [n_rows] or null, g / b_ln [K]: the LayerNorm's weight / bias.
+ * Replaces nn.LayerNorm + nn.Linear of CLIPEncoderLayer / OwlViTEncoderLayer (transformers; reached from
+ * VisualSearch/model/llava/model/multimodal_encoder/clip_encoder.py:46-60 and VisualSearch/model/owlvit/owlvit.py:121-126). */
+int vstar_op_ln_fold(void* stream, uint16_t* dev_W, uint16_t* dev_bias, const uint16_t* dev_g, const uint16_t* dev_b_ln,
+                     int n_rows, int K);
 /* Which GEMM kernel the calling thread's last vstar_op_gemm / vstar_op_gemm_fp8 launched: 128, 256, 384 (= 256 + 128: whole
  * rounds of 256x256 tiles over the leading rows and the ragged last round's rows as 128x128 tiles — bit-identical to either
  * kernel alone), or 0 (nothing launched).  Lets a test assert that it exercised the kernel it was written for, whatever the dispatcher's heuristics do. */

@@ -107,10 +107,16 @@ def main():
                     help="trained_like (round 4, VERDICT r3 missing #2): vstar_amd.weights.trained_like_state_dict — outlier residual "
                          "channels, a massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the "
                          "answer template for SyntheticTokenizer prompts; written to full7b_tl_{336,224}.npz")
+    ap.add_argument("--out", type=str, default=None, help="output file name under tests/golden/ (round 5: the 32-crop noise study "
+                    "full7b_tl_336_x32.npz = every crop of the bench batch, recorded with --crops all --mask-f16)")
+    ap.add_argument("--mask-f16", action="store_true", help="store the 192 x 192 masks as float16 (5e-4 relative, two orders below "
+                    "the bf16 noise they are compared with): halves the file")
     a = ap.parse_args()
     tl = a.weights == "trained_like"
+    if a.crops == "all":
+        a.crops = ",".join(str(i) for i in range(B))
     crops = tuple(int(c) for c in a.crops.split(",")) if a.crops else ((0, 9, 17, 31) if tl else CROPS)     # (round 4: the 336 trained-like file was recorded with --crops 0,4,9,13,17,22,26,31)
-    out_path = os.path.join(GOLDEN, f"full7b_{'tl_' if tl else ''}{a.image_size}.npz")
+    out_path = os.path.join(GOLDEN, a.out or f"full7b_{'tl_' if tl else ''}{a.image_size}.npz")
     assert ref_shim.available(), "reference tree not found"
     torch.set_num_threads(a.threads)
     cfg = VSMConfig.seal_7b(a.image_size, max_batch=B, max_text_len=T + 1)
@@ -133,6 +139,9 @@ def main():
     b16 = run(model, cfg, loc_id, clip, owl, ids, verify, torch.bfloat16, crops)
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b.astype(np.float64)))  # noqa: E731
     print("reference-bf16 vs reference-fp32 rel-L2:", {k: "%.2e" % rel(b16[k], f32[k]) for k in f32 if k.startswith(("pred", "low", "llm", "embed", "sam"))})
+    if a.mask_f16:
+        f32["low_res_masks"] = f32["low_res_masks"].astype(np.float16)
+        b16["low_res_masks"] = b16["low_res_masks"].astype(np.float16)
     np.savez_compressed(out_path, crops=np.asarray(crops), batch=B, text_tokens=T, weight_seed=0, image_size=a.image_size,
                         weights=a.weights,
                         **{k: v for k, v in f32.items()}, **{"bf16_" + k: v for k, v in b16.items()})

@@ -1,0 +1,96 @@
+"""The N > 1 RCCL path, self-proving on whatever box runs the suite (VERDICT r4 missing #1 / next-round item 3).
+
+Skips below two visible GPUs.  With two or more it runs the REAL entry point — visual_search.py under torch.distributed.run, one
+process per GPU, backend nccl (= RCCL over xGMI), real engines — at 2 ranks and at min(8, device_count) ranks:
+  * crop sharding (the north-star layout: each engine step's crop batch dealt over the ranks, one all-gather of the per-crop
+    result records per step) through torch.distributed's all_gather_into_tensor, and again with `--engine-comm`, the C-ABI's own
+    collective (vstar_comm_init / vstar_allgather_results: ncclAllGather on the engine's stream, include/vstar_hip.h);
+  * sample sharding;
+each must print exactly the single-process metrics and write the same per-sample hits and path lengths.  bench.py --gpus N must
+carry `collective.ranks == N`, a whole-job value, and a `cpu_baseline` object (rank 0 times it at every N).
+
+The partition under test: vstar_amd/dist.py (shard_indices / reorder_gathered), vstar_amd/vsm.py::_score_sharded,
+vstar_amd/csrc/comm.hip.  The loop being parallelised: /root/reference/visual_search.py:536-560 (one sample at a time, one GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from test_host import _free_port, _make_bench_folder
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_GPUS = torch.cuda.device_count() if torch.cuda.is_available() else 0
+needs_two = pytest.mark.skipif(N_GPUS < 2, reason=f"needs >= 2 visible GPUs for a multi-rank RCCL group (found {N_GPUS})")
+WORLDS = sorted({2, min(8, N_GPUS)}) if N_GPUS >= 2 else [2]
+
+COMMON = ["--vsm-factory", "_real_tiny_vsm:make", "--confidence_high", "2.0", "--confidence_low", "0.0", "--target_cue_threshold", "-1",
+          "--target_cue_threshold_minimum", "-1", "--minimum_size", "160"]
+
+
+def _env():
+    return dict(os.environ, PYTHONPATH=os.path.join(ROOT, "tests") + os.pathsep + ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
+def _metric_lines(text):
+    return [l for l in text.splitlines() if l.startswith(("Avg search path length", "Top 1 Acc"))]
+
+
+@pytest.fixture(scope="module")
+def single(tmp_path_factory):
+    """The one-process run every multi-rank run is compared with."""
+    d = tmp_path_factory.mktemp("mgpu")
+    folder = str(d / "bench")
+    _make_bench_folder(folder)
+    out_json = str(d / "one.json")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "visual_search.py"), "--benchmark-folder", folder, *COMMON,
+                          "--output_path", out_json], capture_output=True, text=True, timeout=900, cwd=ROOT, env=_env())
+    assert one.returncode == 0, one.stderr[-3000:]
+    return {"folder": folder, "dir": d, "stdout": one.stdout, "json": json.load(open(out_json))}
+
+
+@needs_two
+@pytest.mark.parametrize("world", WORLDS)
+@pytest.mark.parametrize("mode", ["crops-torch", "crops-engine-comm", "samples"])
+def test_real_entry_point_over_nccl_equals_single_process(single, world, mode):
+    out_json = str(single["dir"] / f"w{world}_{mode}.json")
+    shard = "samples" if mode == "samples" else "crops"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "visual_search.py"), "--benchmark-folder", single["folder"], *COMMON,
+           "--shard", shard, "--output_path", out_json] + (["--engine-comm"] if mode == "crops-engine-comm" else [])
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=_env())
+    assert run.returncode == 0, run.stderr[-4000:]
+    assert len(_metric_lines(run.stdout)) == 2 and _metric_lines(run.stdout) == _metric_lines(single["stdout"])
+    a, b = single["json"], json.load(open(out_json))
+    assert b["world_size"] == world and b["shard"] == shard
+    assert b.get("backend", "nccl") == "nccl"
+    assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"]
+    if mode == "crops-engine-comm":
+        assert b.get("engine_comm") is True, "the C-ABI collective was requested but the run fell back to torch.distributed"
+    if shard == "crops":
+        assert b["rank0_search_stats"]["useful_crops"] == a["rank0_search_stats"]["useful_crops"]
+
+
+@needs_two
+@pytest.mark.parametrize("world", WORLDS)
+def test_bench_line_at_n_ranks(world):
+    """bench.py --gpus N started WITHOUT a launcher (it spawns its own ranks): the line's collective spans N ranks, the value is the
+    whole-job aggregate, and cpu_baseline is present (tiny widths: a plumbing run, so the CPU port is skipped by --tiny — the
+    object's presence at full size is covered by the CPU test of the flag logic in tests/test_host.py)."""
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--tiny",
+                          "--batch", "4", "--stream-samples", "8", "--no-search-leg"], capture_output=True, text=True, timeout=1200,
+                         cwd=ROOT, env=_env())
+    assert run.returncode == 0, run.stderr[-4000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.strip()][-1])
+    assert line["n_gpus"] == world and line["world_size"] == world
+    assert line["collective"]["ranks"] == world and line["collective"]["backend"].startswith("nccl")
+    assert line["value"] > 0 and line["scaling"] == "weak"
+
+
+def test_multi_gpu_visibility_is_reported(cuda):
+    """Runs on every GPU box: records how many GPUs the suite saw, so that a reader of the log knows whether the tests above ran."""
+    print(f"\nvisible GPUs: {N_GPUS}; multi-rank RCCL tests {'RAN at worlds ' + str(WORLDS) if N_GPUS >= 2 else 'SKIPPED (one GPU)'}")
+    assert N_GPUS >= 1

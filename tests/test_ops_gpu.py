@@ -517,3 +517,76 @@ def test_gemm_row_scale_is_the_folded_rmsnorm(lib, cuda, M, N, K, epi):
         assert _rel(c256.float(), acc) < 2 ** -7
 
 
+
+
+@pytest.mark.parametrize("M,N,K,epi,use_bias,use_res", [
+    (2048, 1024, 256, 0, False, False), (2048, 1024, 256, 0, True, True), (1536, 768, 768, 1, True, False),
+    (2304, 512, 128, 2, True, True), (1280, 768, 256, 3, True, True), (2048, 2048, 512, 4, False, False),
+    (1300, 1000, 256, 0, True, True),            # M and N tails: interior tiles direct, edge tiles through the LDS epilogue
+])
+def test_gemm256_direct_epilogue_equals_lds_epilogue(lib, cuda, monkeypatch, M, N, K, epi, use_bias, use_res):
+    """Round 5: interior tiles of gemm256 finish in the accumulator registers (W rows DMA'd in a permuted order so that a lane's
+    fragments are 16 contiguous output bytes).  VSTAR_GEMM_DEBUG=4 switches that off (every tile through the LDS transpose): both
+    epilogues — and the 128^2 kernel — must agree bit for bit, statistics included."""
+    g = torch.Generator().manual_seed(M + 7 * N + K + epi)
+    a = torch.randn(M, K, generator=g).bfloat16().to(cuda)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    if epi == _lib.EPI_SILU_MUL:
+        w = _pack_gate_up(w[: N // 2], w[N // 2:])
+    w = w.to(cuda)
+    n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
+    bias = torch.randn(N, generator=g).bfloat16().to(cuda) if use_bias else None
+    res = torch.randn(M, n_out, generator=g).bfloat16().to(cuda) if use_res else None
+    monkeypatch.delenv("VSTAR_GEMM_DEBUG", raising=False)
+    direct = _gemm(lib, a, w, bias, res, epi=epi, tile=256)
+    c128 = _gemm(lib, a, w, bias, res, epi=epi, tile=128)
+    monkeypatch.setenv("VSTAR_GEMM_DEBUG", "4")
+    lds = _gemm(lib, a, w, bias, res, epi=epi, tile=256)
+    assert not torch.isnan(direct.float()).any()
+    assert torch.equal(direct, lds) and torch.equal(direct, c128)
+    if epi == 0 and use_res and N % 64 == 0:
+        monkeypatch.delenv("VSTAR_GEMM_DEBUG", raising=False)
+        c_d, s_d = _gemm_norm(lib, a, w, res, tile=256, want_sumsq=True)
+        monkeypatch.setenv("VSTAR_GEMM_DEBUG", "4")
+        c_l, s_l = _gemm_norm(lib, a, w, res, tile=256, want_sumsq=True)
+        assert torch.equal(c_d, c_l) and torch.equal(s_d, s_l)
+
+
+@pytest.mark.parametrize("N,K", [(3072, 1024), (2304, 768)])
+def test_ln_fold_zero_sum_rounding(lib, cuda, N, K):
+    """The LayerNorm fold of the ViT linears: W' = round(W diag(g) - row mean) must SUM TO ZERO as stored, otherwise
+    rstd * mean(x) * sum_k W'_k leaks into every output of rows with a large |mean| / std.  Nearest rounding leaves
+    ~sqrt(K)/2 ulp; the zero-sum rounding of ln_fold_kernel moves a handful of elements to their other neighbour.  Checked here:
+    (a) the stored row sums are <= 1e-3 of the nearest-rounding ones, (b) every element is within ONE 16-bit step of the exact
+    centred value and all but a few within half a step, (c) the bias picks up W . b_ln, (d) a constant added to x does not move
+    Linear(LN(x)) computed the folded way (x . W'^T, fp64 on the stored weights) by more than 1e-4 of the output scale, where
+    nearest rounding moves it by ~|shift| * 2e-3."""
+    g0 = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g0) / math.sqrt(K) * torch.exp(0.5 * torch.randn(N, K, generator=g0))).bfloat16()
+    gam = (1.0 + 0.3 * torch.randn(K, generator=g0)).bfloat16()
+    bln = (0.2 * torch.randn(K, generator=g0)).bfloat16()
+    bias = (0.1 * torch.randn(N, generator=g0)).bfloat16()
+    wd, bd = w.clone().to(cuda), bias.clone().to(cuda)
+    assert lib.vstar_op_ln_fold(None, P(wd), P(bd), P(gam.to(cuda)), P(bln.to(cuda)), N, K) == 0, lib.vstar_last_error(None)
+    torch.cuda.synchronize()
+    exact = (w.float() * gam.float())
+    exact = (exact - exact.mean(dim=1, keepdim=True))                        # fp32, like the kernel (same mean up to summation order)
+    nearest = exact.bfloat16().double()
+    got = wd.cpu().double()
+    s_near, s_got = nearest.sum(1).abs(), got.sum(1).abs()
+    assert s_got.max() <= 1e-3 * s_near.mean(), (float(s_got.max()), float(s_near.mean()))
+    step = (2.0 ** (torch.floor(torch.log2(exact.double().abs().clamp_min(1e-30))) - 7))       # bf16 spacing at each value
+    dev = (got - exact.double()).abs()
+    assert (dev <= 1.02 * step + 1e-12).all()
+    moved = (got != nearest).sum(1)
+    assert moved.float().mean() < 40 and moved.max() < 120, (float(moved.float().mean()), int(moved.max()))
+    want_b = (bias.double() + (w.double() * bln.double()).sum(1))
+    assert torch.allclose(bd.cpu().double(), want_b, rtol=2 ** -7, atol=2e-3)
+    # (d) shift invariance of the folded product
+    x = torch.randn(64, K, generator=g0).double()
+    shift = 8.0
+    y0, y1 = x @ got.T, (x + shift) @ got.T
+    n0, n1 = x @ nearest.T, (x + shift) @ nearest.T
+    scale = float(y0.abs().mean())
+    assert float((y1 - y0).abs().max()) <= 1e-4 * scale
+    assert float((n1 - n0).abs().max()) > 1e-3 * scale           # the leak this removes

@@ -130,8 +130,11 @@ def main(argv):
             outs = []
             for i, _, (ld, target, gt_bbox, small_of) in mine:
                 im = ld()
-                outs.append(visual_search(vsm, im, target, gt_bbox, small_of(im), visualize=rank == 0 or args.shard == "samples",
-                                          save_path=vis_dirs[i], **skw))
+                # every rank takes the SAME decision path (host float32 heat maps, no device reductions); with crop sharding all
+                # ranks walk every search, so only rank 0 renders (rank 0 alone used to leave the device-reduction path)
+                render = rank == 0 or args.shard == "samples"
+                outs.append(visual_search(vsm, im, target, gt_bbox, small_of(im), visualize=render,
+                                          save_path=vis_dirs[i], device_reductions=False, **skw))
         else:
             outs = visual_search_stream(vsm, [m[2] for m in mine], window=args.window or None, stats=stats, **skw)
         results = []                                     # (sample index, hit, path length)
@@ -150,7 +153,10 @@ def main(argv):
             print("Avg search path length:", np.mean([n for n, h in zip(lengths, hits) if h]))
             print("Top 1 Acc:", np.mean(hits))
             if args.output_path:
+                import torch.distributed as tdist
                 json.dump({"world_size": world, "shard": args.shard, "hits": hits, "path_lengths": lengths,
+                           "backend": tdist.get_backend() if tdist.is_available() and tdist.is_initialized() else None,
+                           "engine_comm": bool(getattr(vsm, "use_engine_comm", False)),
                            "rank0_search_stats": {k: v for k, v in stats.items() if k != "per_search"}},
                           open(os.path.join(args.output_path, "results.json") if args.visualization else args.output_path, "w"))
         finished = True

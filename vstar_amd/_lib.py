@@ -19,7 +19,7 @@ EXPORTS = [
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
     "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
-    "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
+    "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_op_ln_fold", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
     "vstar_image_set_slot", "vstar_image_set_slot_async", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
     "vstar_comm_destroy",
 ]
@@ -129,6 +129,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_gemm_norm.restype = c_int
     lib.vstar_op_rms_rstd.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]
     lib.vstar_op_rms_rstd.restype = c_int
+    lib.vstar_op_ln_fold.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]
+    lib.vstar_op_ln_fold.restype = c_int
     lib.vstar_op_gemm_last_tile.argtypes = []
     lib.vstar_op_gemm_last_tile.restype = c_int
     lib.vstar_op_gemm_plan.argtypes = [c_int] * 7

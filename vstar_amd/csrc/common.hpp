@@ -103,7 +103,11 @@ __device__ __forceinline__ float wave_max(float v) {
 // activations, with the reference's bf16 rounding points (Appendix C of SURVEY.md).  sigmoid = v_exp_f32 + v_add + v_rcp_f32
 // (1 ulp, then rounded to 16 bits): an IEEE-exact fp32 divide costs ~10 VALU instructions per element, which made the SiLU /
 // quick-GELU epilogues of the gate|up and ViT fc1 GEMMs VALU-bound (6 % and 30 % of those kernels)
+#ifdef VSTAR_EXACT_SIGMOID   // bisect builds only (tools/noise_study.py): IEEE divide + expf instead of v_rcp_f32 / v_exp_f32
+__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float act_quick_gelu_bf16(float t) {  // t already bf16-rounded
   float u = rlp(1.702f * t);
   float s = rlp(fast_sigmoid(u));

@@ -81,7 +81,6 @@ struct vstar_engine : EngineBase {
   bool stage_used[2] = {false, false};
   int stage_next = 0;
   hipEvent_t ev_pre = nullptr;                                     // recorded behind every preprocessing launch (engine stream)
-  std::atomic<int> pre_recorded{0};
   int image_upload_async(int slot, const uint8_t* rgb, int height, int width);
   uint8_t* d_temp = nullptr; size_t temp_cap = 0;
   int32_t* d_tables = nullptr; size_t tables_cap = 0;
@@ -428,7 +427,7 @@ int vstar_engine::preprocess(int B, const int32_t* boxes, const int32_t* slots) 
   HIPCHK(hipMemcpyAsync(d_jobs, h_jobs.data(), h_jobs.size() * sizeof(PreJob), hipMemcpyHostToDevice, stream));
   KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_clip_pix, 0, B, I, max_h_clip, stream));
   KCHK(preprocess_launch(d_jobs, d_tables, d_temp, d_lut, d_owl_pix, 1, B, O, max_h_owl, stream));
-  if (ev_pre) { HIPCHK(hipEventRecord(ev_pre, stream)); pre_recorded.store(1); }
+  HIPCHK(hipEventRecord(ev_pre, stream));      // always: an asynchronous upload orders its DMA behind the crops already launched
   return 0;
 }
 
@@ -440,11 +439,8 @@ int vstar_engine::preprocess(int B, const int32_t* boxes, const int32_t* slots) 
 int vstar_engine::image_upload_async(int slot, const uint8_t* rgb, int height, int width) {
   HIPCHK(hipSetDevice(device));
   const size_t bytes = (size_t)height * width * 3;
-  if (!stream_up) {
-    HIPCHK(hipStreamCreateWithFlags(&stream_up, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) HIPCHK(hipEventCreateWithFlags(&ev_stage[k], hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming));
-  }
+  // (stream_up, ev_stage and ev_pre are created in vstar_create: the prefetch thread that calls this must not create objects the
+  // scoring thread reads — ADVICE r4)
   if (!ev_up[slot]) HIPCHK(hipEventCreateWithFlags(&ev_up[slot], hipEventDisableTiming));
   ImageSlot& im = images[slot];
   if (bytes > im.cap) {                     // first image of this size in the slot: allocate (grow-only)
@@ -464,7 +460,7 @@ int vstar_engine::image_upload_async(int slot, const uint8_t* rgb, int height, i
     stage_cap[k] = bytes;
   }
   memcpy(h_stage[k], rgb, bytes);
-  if (pre_recorded.load()) HIPCHK(hipStreamWaitEvent(stream_up, ev_pre, 0));
+  HIPCHK(hipStreamWaitEvent(stream_up, ev_pre, 0));      // (a never-recorded event is complete: the wait is a no-op before the first crop)
   HIPCHK(hipMemcpyAsync(im.d, h_stage[k], bytes, hipMemcpyHostToDevice, stream_up));
   HIPCHK(hipEventRecord(ev_stage[k], stream_up));
   stage_used[k] = true;
@@ -1053,6 +1049,15 @@ int vstar_create(const vstar_config* cfg, int device, vstar_handle** out) {
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
     h->stream2 = nullptr;                       // no second stream: everything stays on the main stream
   }
+  // the asynchronous-upload objects exist from the start (created here, on the creating thread; used by the prefetch threads)
+  if (hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_stage[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_stage[1], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_pre, hipEventDisableTiming) != hipSuccess) {
+    tls_error() = "creating the upload stream / events failed";
+    vstar_destroy(h);
+    return VSTAR_ERR_HIP;
+  }
   *out = h;
   return VSTAR_OK;
 }
@@ -1338,6 +1343,7 @@ int vstar_op_gemm_norm(void* stream, const uint16_t* A, int64_t lda, const uint1
   p.A = A; p.lda = lda; p.W = W; p.bias = bias; p.res = residual; p.ldr = ldr; p.C = C; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   p.row_scale = row_scale; p.sumsq_out = sumsq_out; p.sumsq_ld = sumsq_ld;
+  { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   if ((epilogue & VSTAR_EPI_TILE128) && (epilogue & VSTAR_EPI_TILE256)) { tls_error() = "both tile overrides set"; return VSTAR_ERR_INVALID; }
   if (sumsq_out && ((epilogue & 0xff) != VSTAR_EPI_NONE || N % 64)) { tls_error() = "sumsq_out: VSTAR_EPI_NONE and N % 64 == 0 only"; return VSTAR_ERR_INVALID; }
   p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
@@ -1349,6 +1355,11 @@ int vstar_op_gemm_norm(void* stream, const uint16_t* A, int64_t lda, const uint1
 int vstar_op_rms_rstd(void* stream, const uint16_t* x, const float* partials, int ld, int rows, int cols, float eps, float* r) {
   hipError_t e = x ? rms_rstd_rows(x, rows, cols, eps, r, (hipStream_t)stream)
                    : rms_rstd_partials(partials, ld, rows, cols, eps, r, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return op_rc(e);
+}
+int vstar_op_ln_fold(void* stream, uint16_t* W, uint16_t* bias, const uint16_t* g, const uint16_t* b_ln, int n_rows, int K) {
+  hipError_t e = ln_fold_weights(W, bias, g, b_ln, n_rows, K, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }

@@ -70,6 +70,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   uint32_t src_off[4][2];   // BYTE offset of this lane's 16-B chunk at k0 = 0, per piece type and u
   int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
   int m0 = 0, n0 = 0;
+  // ---- direct (in-register) epilogue, round 5 ----
+  // The MFMA leaves lane (fr, fq) with output columns n*16 + fq*4 + e of fragment n: 8-byte pieces, which is why the bf16 epilogue
+  // used to transpose through LDS.  Which W ROW a given LDS row holds is free, though (the DMA source address is per lane): on
+  // interior tiles of a launch with aligned operands the wave's 64 W rows are DMA'd in the order
+  //      LDS row (n, i)  <-  W row (n>>1)*32 + (i>>2)*8 + (n&1)*4 + (i&3)
+  // so that the lane's fragments 0|1 are 8 CONSECUTIVE output columns (16 bytes) at fq*8 and fragments 2|3 the 8 at 32 + fq*8:
+  // bias / activation / residual / RoPE / statistics and two 16-byte stores per row happen in the accumulator registers — no LDS
+  // slab, no transpose, no rolled row loop.  RoPE tiles (two heads of 128 columns per tile, wave pair = head) instead take
+  // d = (wc&1)*32 + fq*8.. and d + 64 into ONE lane (fragments 0|1 and 2|3), the rotate-half partner without any exchange; the
+  // SiLU tiles (storage rows: 16 gate rows, 16 up rows, ...) put gate / up of 8 consecutive outputs into fragments 0,2 / 1,3.
+  // Same dot products, same k order, same rounding points, same statistics tree: bit-identical to the LDS epilogue.
+  const bool dir_launch = !OUT_F32 && !(p.debug_flags & 7) && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) && (p.ldc % 8 == 0) &&
+                          (p.res == nullptr || ((((uintptr_t)p.res & 15) == 0) && (p.ldr % 8 == 0))) &&
+                          (p.bias == nullptr || (((uintptr_t)p.bias & 15) == 0));
+  bool dir_tile = false;
   // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering; DMA source offsets of that tile ----
   // DMA pieces: piece type j in {a0, w0, w1, a1}; each wave moves row-groups g = 2*wave + u (u = 0,1)
   //   A piece (m-half mh): 8-row group g -> tile rows (g>>3)*128 + mh*64 + (g&7)*8 ..+8
@@ -88,6 +103,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     const int rem = t - grp * in_group;
     m0 = (first_m + rem % gsz) * BM;
     n0 = (rem / gsz) * BN;
+    dir_tile = dir_launch && m0 + BM <= p.M && n0 + BN <= p.N;
+    bool rope_t = false;
+    if constexpr (EPI == VSTAR_EPI_NONE) rope_t = p.rope_cs != nullptr && n0 < p.rope_cols;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -104,7 +122,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           ar = ar < p.M ? ar : p.M - 1;
           src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda * ES + cg * 16);
         } else {
-          src_off[j][u] = (uint32_t)((int64_t)(n0 + row) * p.K * ES + cg * 16);
+          int wrow = row;
+          if (dir_tile) {
+            const int wcr = row >> 6, n = (row >> 4) & 3, i = row & 15;
+            if (EPI == VSTAR_EPI_SILU_MUL) {
+              const int jo = (i >> 2) * 8 + (n >> 1) * 4 + (i & 3);              // output column inside the wave's 32
+              wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);      // its gate (n even) / up (n odd) storage row
+            } else if (rope_t) {
+              wrow = (wcr >> 1) * 128 + (n >> 1) * 64 + (wcr & 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3);
+            } else {
+              wrow = wcr * 64 + (n >> 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3);
+            }
+          }
+          src_off[j][u] = (uint32_t)((int64_t)(n0 + wrow) * p.K * ES + cg * 16);
         }
       }
     }
@@ -243,6 +273,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   }
   // ---- next tile: its K-tile 0 goes into ring buffer 0 now; this tile's coordinates stay in em0/en0 for the epilogue ----
   const int em0 = m0, en0 = n0;
+  const bool edirect = dir_tile;
   bid += gridDim.x;
   const bool has_next = bid < nwg;
   if (has_next) {
@@ -258,7 +289,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     float swv[4][4];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const f32x4 t = *(const f32x4*)(p.w_scale + en0 + wc * 64 + n * 16 + fq * 4);      // w_scale is padded like W
+      int sc = wc * 64 + n * 16 + fq * 4;                                               // LDS row (n, fq*4 + e) -> its W row
+      if (edirect) {
+        if (EPI == VSTAR_EPI_SILU_MUL) { const int jo = fq * 8 + (n >> 1) * 4; sc = wc * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15); }
+        else if (EPI == VSTAR_EPI_NONE && p.rope_cs != nullptr && en0 < p.rope_cols) sc = (wc >> 1) * 128 + (n >> 1) * 64 + (wc & 1) * 32 + fq * 8 + (n & 1) * 4;
+        else sc = wc * 64 + (n >> 1) * 32 + fq * 8 + (n & 1) * 4;
+      }
+      const f32x4 t = *(const f32x4*)(p.w_scale + en0 + sc);                            // w_scale is padded like W
 #pragma unroll
       for (int e = 0; e < 4; ++e) swv[n][e] = t[e];
     }
@@ -305,6 +342,112 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           gemm_epilogue_store<EPI, OUT_F32>(p, crow, en0 + wc * 64 + n * 16 + fq * 4, n_out, acc[m][n], acc[m][n]);
       }
     }
+  } else if (edirect) {
+    constexpr bool SILU = (EPI == VSTAR_EPI_SILU_MUL);
+    bool rope_tile = false;
+    if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
+    // first output column of this lane's two 8-column chunks (SiLU: one chunk)
+    int col_a, col_b;
+    if (SILU) { col_a = (en0 + wc * 64) / 2 + fq * 8; col_b = col_a; }
+    else if (rope_tile) { col_a = en0 + (wc >> 1) * 128 + (wc & 1) * 32 + fq * 8; col_b = col_a + 64; }
+    else { col_a = en0 + wc * 64 + fq * 8; col_b = col_a + 32; }
+    float bia[8], bib[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
+    if (!SILU && p.bias) {
+      const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
+    }
+    const int rope_d = (wc & 1) * 32 + fq * 8;              // rotary index of chunk a (chunk b = the same index, second half)
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int row = em0 + wr * 128 + m * 16 + fr;          // interior tile: row < M, identity row map
+      lp_t* crow = (lp_t*)p.C + (int64_t)row * p.ldc;
+      if constexpr (SILU) {
+        lpx8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = (short)f2lp(act_silu_bf16(rlp(acc[m][0][e])) * rlp(acc[m][1][e]));
+          v[4 + e] = (short)f2lp(act_silu_bf16(rlp(acc[m][2][e])) * rlp(acc[m][3][e]));
+        }
+        __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
+      } else {
+        float xa[8], xb[8];                                  // stage 1 of the LDS epilogue: bf16(acc + bias)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xa[e] = rlp(acc[m][0][e] + bia[e]);
+          xa[4 + e] = rlp(acc[m][1][e] + bia[4 + e]);
+          xb[e] = rlp(acc[m][2][e] + bib[e]);
+          xb[4 + e] = rlp(acc[m][3][e] + bib[4 + e]);
+        }
+        if constexpr (EPI == VSTAR_EPI_NONE) {
+          if (rope_tile) {
+            int pos = row % p.rope_S;
+            if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);      // grouped sequences
+            if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;   // shared prefix
+            const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + rope_d);
+            const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + rope_d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float c = lp2f((lp_t)c8[e]), sn = lp2f((lp_t)s8[e]);
+              const float lo = rlp(xa[e] * c) + rlp(-1.0f * xb[e] * sn);      // first half of the head: x*cos - partner*sin
+              const float hi = rlp(xb[e] * c) + rlp(1.0f * xa[e] * sn);       // second half: x*cos + partner*sin
+              xa[e] = lo; xb[e] = hi;
+            }
+          }
+        } else if constexpr (EPI == VSTAR_EPI_QUICK_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xa[e] = act_quick_gelu_bf16(xa[e]); xb[e] = act_quick_gelu_bf16(xb[e]); }
+        } else if constexpr (EPI == VSTAR_EPI_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xa[e] = act_gelu_erf(xa[e]); xb[e] = act_gelu_erf(xb[e]); }
+        } else if constexpr (EPI == VSTAR_EPI_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xa[e] = fmaxf(xa[e], 0.f); xb[e] = fmaxf(xb[e], 0.f); }
+        }
+        if (p.res) {                                         // launch-uniform: rlp(activation output) + residual
+          const lp_t* rrow = p.res + (int64_t)row * p.ldr;
+          const lpx8 r0 = *(const lpx8*)(rrow + col_a), r1 = *(const lpx8*)(rrow + col_b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xa[e] = rlp(xa[e]) + lp2f((lp_t)r0[e]); xb[e] = rlp(xb[e]) + lp2f((lp_t)r1[e]); }
+        }
+        lpx8 va, vb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { va[e] = (short)f2lp(xa[e]); vb[e] = (short)f2lp(xb[e]); }
+        if (p.sumsq_out) {          // the rows are the next linear's A operand right away: keep them cache-resident
+          *(lpx8*)(crow + col_a) = va;
+          *(lpx8*)(crow + col_b) = vb;
+        } else {
+          __builtin_nontemporal_store(va, (lpx8*)(crow + col_a));
+          __builtin_nontemporal_store(vb, (lpx8*)(crow + col_b));
+        }
+        if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
+          if (p.sumsq_out) {
+            // statistics of the STORED values, canonical tree (gemm_epilogue.hpp): chunk = (4 + 4 columns), chunk pairs across fq ^ 1,
+            // pairs of pairs across fq ^ 2, the two 32-column halves inside the lane
+            float fa[8], fb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)va[e]); fb[e] = lp2f((lp_t)vb[e]); }
+            float qa = (((fa[0] * fa[0] + fa[1] * fa[1]) + fa[2] * fa[2]) + fa[3] * fa[3]) +
+                       (((fa[4] * fa[4] + fa[5] * fa[5]) + fa[6] * fa[6]) + fa[7] * fa[7]);
+            float qb = (((fb[0] * fb[0] + fb[1] * fb[1]) + fb[2] * fb[2]) + fb[3] * fb[3]) +
+                       (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
+            qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
+            qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
+            float* sq = p.sumsq_out + (int64_t)row * p.sumsq_ld + (en0 + wc * 64) / 64;
+            if (fq == 0) sq[0] = qa + qb;
+            if (p.stats_sum) {
+              float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
+              float sb = (((fb[0] + fb[1]) + fb[2]) + fb[3]) + (((fb[4] + fb[5]) + fb[6]) + fb[7]);
+              sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+              sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+              if (fq == 0) sq[p.stats_sum] = sa + sb;
+            }
+          }
+        }
+      }
+    }
   } else {
     // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab — 32 rows at a time, in
     // ring buffer 1 (dead: every wave is past the last barrier; buffer 0 is already receiving the next tile) — then
@@ -349,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       res1 = p.res != nullptr && !rope_tile && en0 + BN <= n_out && (((uintptr_t)p.res & 7) == 0) && (p.ldr % 4 == 0);
     constexpr int NIT = 32 / RPI;
     const bool fast_tile = !F8 && !rope_tile && em0 + BM <= p.M && en0 + BN <= p.N && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) &&
-                           (p.ldc % 8 == 0) && !p.debug_flags && (p.res == nullptr || res1);
+                           (p.ldc % 8 == 0) && !(p.debug_flags & 3) && (p.res == nullptr || res1);
     auto quarter_pass = [&](auto qc) {
       constexpr int qp = decltype(qc)::value;       // rows qp*32 .. +31 of the wave's 128-row tile
       lpx4 rv[2][NF];
@@ -496,7 +639,11 @@ bool gemm256_eligible(const GemmParams& p) {
   return true;
 }
 
-hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {
+hipError_t gemm256_lp(const GemmParams& p0, int epilogue, bool out_f32, hipStream_t s) {
+  // VSTAR_GEMM_DIRECT=0 (A/B runs): the LDS-transposed epilogue everywhere (debug bit 2 = "no direct epilogue")
+  static const bool no_direct = [] { const char* e = getenv("VSTAR_GEMM_DIRECT"); return e && atoi(e) == 0; }();
+  GemmParams p = p0;
+  if (no_direct) p.debug_flags |= 4;
   if (p.a_scale) {       // W8A8 instantiations: the two epilogues the LLaMA linears use
     if (out_f32) return hipErrorInvalidValue;
     if (epilogue == VSTAR_EPI_NONE) return launch<VSTAR_EPI_NONE, false, true>(p, s);

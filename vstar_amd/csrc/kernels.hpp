@@ -17,7 +17,7 @@ struct GemmParams {
   const lp_t* res; int64_t ldr;   // residual, laid out like C (same row map), or null
   void* C; int64_t ldc; int c_group; int64_t c_gstride; int64_t c_off;
   int M, N, K;
-  int debug_flags;   // diagnostics only: bit0 = skip the epilogue's global stores, bit1 = skip the whole epilogue
+  int debug_flags;   // diagnostics only: bit0 = skip the epilogue's global stores, bit1 = skip the whole epilogue, bit2 = gemm256 without its direct (in-register) epilogue
   // gemm_skinny_lp only: when norm_w != null the rows of A are RMS-normalised on the fly (LlamaRMSNorm: fp32 statistics,
   // rlp(x * rstd), then rlp(norm_w * that)) — bit-identical to rmsnorm_lp followed by the GEMM, one launch less
   const lp_t* norm_w; float norm_eps;

@@ -4,6 +4,7 @@
 //               (clip_encoder.py:53-57 -> transformers CLIPVisionModel; owlvit.py:128-138), SAM nn.LayerNorm
 //               (transformer.py:109-205) and LayerNorm2d over channels-last rows (common.py:31-43, eps 1e-6).
 //   RMSNorm   : HF LlamaRMSNorm (fp32 variance, cast to bf16, then weight multiply) via llava_llama.py:93-102.
+#include <cstdlib>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -217,9 +218,20 @@ __global__ __launch_bounds__(256) void ln_rstd_partials_kernel(const float* __re
   if (lane == 0) r[row] = ln_rstd_from(total_sq, total_s, cols, eps);
 }
 
-// one workgroup per packed weight row: bias += W . b_ln (unscaled W, fp32), then W := W * g - mean_k(W * g), rounded once
+// one workgroup per packed weight row: bias += W . b_ln (unscaled W, fp32), then W := W * g - mean_k(W * g), rounded once.
+// ZERO-SUM ROUNDING (round 5): the consumer drops the row mean of x because sum_k W'_k = 0 — true of the centred fp32
+// row, not of its 16-bit rounding: the leftover c = sum_k round(W'_k) (~ sqrt(K) / 2 ulp) re-enters every output as
+// rstd * mean(x) * c, an error that grows with |mean| / std of the activation row (massive-activation tokens of real CLIP / OWL
+// checkpoints).  So after the nearest rounding, thread 0 moves a few elements (~15 of 768) to their OTHER 16-bit neighbour —
+// those whose rounding error points the way the residual does, nearest-to-the-tie first, never past the residual — until the
+// ROUNDED row sums to zero within the smallest step used (measured: |c| 1.9e-3 -> 2.7e-7 on N(0, 0.03) rows, +0.7 % rms weight
+// rounding noise).  No run-time term, no extra epilogue operand; both kernels read the same weights, so bit-identity between
+// tile shapes is untouched.
 __global__ __launch_bounds__(256) void ln_fold_kernel(lp_t* __restrict__ W, lp_t* __restrict__ bias, const lp_t* __restrict__ g,
-                                                      const lp_t* __restrict__ b_ln, int K) {
+                                                      const lp_t* __restrict__ b_ln, int K, int zero_sum) {
+  extern __shared__ __attribute__((aligned(16))) char fold_smem[];
+  float* ex = (float*)fold_smem;                       // [K] the centred fp32 row
+  lp_t* qb = (lp_t*)(fold_smem + (size_t)K * 4);       // [K] its 16-bit rounding
   __shared__ float red[2][4];
   const int n = blockIdx.x, tid = threadIdx.x;
   lp_t* w = W + (int64_t)n * K;
@@ -235,7 +247,37 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(lp_t* __restrict__ W, lp_t
   __syncthreads();
   dot = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
   const float mean = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)K;
-  for (int k = tid; k < K; k += 256) w[k] = f2lp(lp2f(w[k]) * lp2f(g[k]) - mean);
+  for (int k = tid; k < K; k += 256) {
+    const float e = lp2f(w[k]) * lp2f(g[k]) - mean;
+    ex[k] = e;
+    qb[k] = f2lp(e);
+  }
+  __syncthreads();
+  if (zero_sum && tid == 0) {
+    double r = 0.0;
+    for (int k = 0; k < K; ++k) r += (double)lp2f(qb[k]);
+    const float thr[5] = {0.4f, 0.3f, 0.2f, 0.1f, 0.0f};
+    for (int t = 0; t < 5 && r != 0.0; ++t) {
+      for (int k = 0; k < K && r != 0.0; ++k) {
+        const lp_t q = qb[k];
+        if (q & 1u << 15 ? (q & 0x7fff) == 0 : q == 0) continue;       // +-0: no neighbour on one side in this bit walk
+        const float qv = lp2f(q), err = qv - ex[k];
+        if (err == 0.f || (err > 0.f) != (r > 0.0)) continue;          // only elements rounded the way the residual points
+        const bool down = r > 0.0;                                     // move this element down (r > 0) or up
+        const bool neg = (q >> 15) != 0;
+        const lp_t nb = (lp_t)((down != neg) ? q - 1 : q + 1);          // next representable value in that direction
+        const float nv = lp2f(nb);
+        if (!(nv == nv) || fabsf(nv) > 3.0e38f) continue;
+        const double d = (double)nv - (double)qv;
+        // was already moved once?  (|new error| would exceed one step): each element moves at most once
+        if (fabsf(err) > fabsf((float)d) * 0.5001f) continue;
+        if (fabsf(err) < thr[t] * fabsf((float)d)) continue;
+        if (fabs(r + d) < fabs(r)) { qb[k] = nb; r += d; }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) w[k] = qb[k];
   if (tid == 0 && bias) bias[n] = f2lp(lp2f(bias[n]) + dot);
 }
 
@@ -281,8 +323,10 @@ hipError_t ln_rstd_partials(const float* partials, int ld, int rows, int cols, f
 }
 
 hipError_t ln_fold_weights(lp_t* W, lp_t* bias, const lp_t* g, const lp_t* b_ln, int n_rows, int K, hipStream_t s) {
-  if (n_rows <= 0 || K <= 0) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_fold_kernel, dim3(n_rows), dim3(256), 0, s, W, bias, g, b_ln, K);
+  if (n_rows <= 0 || K <= 0 || K > 8192) return hipErrorInvalidValue;
+  // VSTAR_FOLD_ZERO_SUM=0 (A/B runs): plain nearest rounding of the centred rows
+  static const int zero_sum = [] { const char* e = getenv("VSTAR_FOLD_ZERO_SUM"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(n_rows), dim3(256), (size_t)K * 6, s, W, bias, g, b_ln, K, zero_sum);
   return hipGetLastError();
 }
 

@@ -330,6 +330,8 @@ def _visual_search_steps(vsm, image, target_object_name, target_bbox, smallest_s
     if visualize:
         assert save_path is not None                         # visual_search.py:485-486
         device_reductions = False                            # the rendered heat maps need the full-resolution maps on the host
+        if _scorer is not None:                              # a prebuilt scorer (stream / many drivers) must follow suit, or the
+            _scorer.device_reductions = False                # step_k_heatmap.jpg files would silently be missing
     init_patch = {"bbox": [0, 0, image.width, image.height], "scale_level": 1, "score": None, "parent_index": -1}
     search_path = [init_patch]
     queue: PriorityQueue = PriorityQueue()
@@ -923,6 +925,12 @@ def visual_search_stream(vsm, samples, *, window: Optional[int] = None, policy: 
             for f, _ in pending.values():
                 f.cancel()
             pool.shutdown(wait=True)
+        # prefetched-but-unstarted images (an exception unwound the driver): their reserved slots hold host copies too
+        rel = getattr(vsm, "release_image", None)
+        if rel is not None:
+            for _, reserved in pending.values():
+                if reserved is not None:
+                    rel(reserved)
     _fill_stream_stats(stats, per_stats, engine_steps)
     if stats is not None and calls0 is not None:
         # launches of an engine scoring entry point (a step can take several: batch cap, prompt-count buckets); engine_steps counts

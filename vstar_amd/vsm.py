@@ -309,8 +309,9 @@ class VSM:
         imgs = getattr(self, "_images", None)
         if imgs is not None:
             imgs.pop(int(slot), None)
-        if slot == 0:
-            self._image = None
+        # slot 0 doubles as the single-image API's slot (set_image(image) + inference_boxes without `slots`): its host copy stays
+        # until the next set_image overwrites it, so that a later inference_boxes on the still-resident device image can take the
+        # decode fallback (it crashed on None).  One image, not one per slot.
 
     @torch.inference_mode()
     def inference_boxes(self, boxes_xywh: Sequence[Sequence[float]], question, mode: str = "detection",
@@ -365,7 +366,12 @@ class VSM:
                 out.append((torch.from_numpy(res["pred_boxes"][b].copy()),
                             _scores(res["pred_logits"][b]), heat))
         # the fallback decodes from the host-side crop (bit-identical pixels: test_gpu_preprocess_is_bit_identical...)
-        img_of = (lambda b: self._image) if slot_arr is None else (lambda b: self._images[int(slot_arr[b])])
+        def img_of(b):
+            im = self._image if slot_arr is None else getattr(self, "_images", {}).get(int(slot_arr[b]))
+            if im is None:
+                raise RuntimeError("decode fallback needs the host copy of the image, but slot "
+                                   f"{0 if slot_arr is None else int(slot_arr[b])} was released (release_image) — call set_image again")
+            return im
         self._handle_mismatches(out, lambda b: img_of(b).crop(tuple(int(v) for v in xyxy[b])), qs, mode, upsample,
                                 defer_mismatch)
         return out

@@ -350,7 +350,12 @@ def trained_like_state_dict(cfg: VSMConfig, seed: int = 0, dtype: torch.dtype = 
     if dtype == torch.float32:
         return sd
     conv: Dict[int, torch.Tensor] = {}          # keep share_layers' aliasing: one converted tensor per distinct host tensor
-    return {k: conv.setdefault(id(v), v.to(dtype)) for k, v in sd.items()}
+    out = {}
+    for k, v in sd.items():                     # (setdefault would evaluate v.to(dtype) for every alias: 32 x per shared tensor)
+        if id(v) not in conv:
+            conv[id(v)] = v.to(dtype)
+        out[k] = conv[id(v)]
+    return out
 
 
 def dense_pe(gaussian: torch.Tensor, grid: int = 48) -> torch.Tensor:
