@@ -533,7 +533,8 @@ def main():
     skipped = 2.0 * (S - 4) * cfg.llm_hidden * (cfg.llm_hidden + 3 * cfg.llm_mlp)
     # HBM-side traffic of the GEMM family per launch, from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v7.json) — not re-measured live
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_stale = None, None, None
+    from vstar_amd.provenance import kernel_source_hash
     import glob
     # newest committed PMC summary first: rNN_pmc_final.json of the latest round, then its numbered passes (round 2 read a stale
     # file here because "_final" did not match the pattern)
@@ -546,7 +547,12 @@ def main():
             continue
         try:
             pmc = json.load(open(cand))
-            gem = [k for k in pmc if "gemm" in k["kernel"]]
+            # round 5: a PMC summary is stamped with the hash of the kernel sources it was measured on; only a file of THIS build's
+            # kernels is quoted (an unstamped pre-round-5 file, or another build's, leaves `traffic` null with the reason stated)
+            if not isinstance(pmc, dict) or pmc.get("kernel_source_hash") != kernel_source_hash():
+                traffic_stale = os.path.relpath(cand, ROOT) if traffic_stale is None else traffic_stale
+                continue
+            gem = [k for k in pmc["kernels"] if "gemm" in k["kernel"]]
             traffic = round(sum(k["fetch_GB_corrected"] + k["write_GB"] for k in gem) * 1e9 / sum(k["launches"] for k in gem))
             traffic_src = os.path.relpath(cand, ROOT)
             break
@@ -555,9 +561,13 @@ def main():
     peak = 5000.0 if args.fp8 else PEAK_BF16_TFLOPS      # --fp8: 93 % of the GEMM FLOPs run on the fp8 MFMA (dense peak ~5 PF)
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved / peak, 4), "traffic": None if args.fp8 else traffic,
-                "traffic_note": f"bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE) from the committed rocprofv3 --pmc "
-                                f"passes of this command ({traffic_src}; counters cannot be read inside an un-profiled run); includes "
-                                "Infinity-Cache hits; algorithmic operand+output bytes per launch ~0.3 GB",
+                "traffic_note": (f"bytes per GEMM launch at the L2<->fabric boundary (FETCHx2+WRITE) from the committed rocprofv3 --pmc "
+                                 f"passes of this command ({traffic_src}, stamped with this build's kernel_source_hash "
+                                 f"{kernel_source_hash()}; counters cannot be read inside an un-profiled run); includes "
+                                 "Infinity-Cache hits; algorithmic operand+output bytes per launch ~0.3 GB") if traffic is not None else
+                                (f"null: no committed PMC summary carries this build's kernel_source_hash {kernel_source_hash()} "
+                                 f"(newest candidate: {traffic_stale}) — re-run tools/collect_r05.sh on the GPU box"),
+                "kernel_source_hash": kernel_source_hash(),
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),

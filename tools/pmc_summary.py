@@ -47,7 +47,11 @@ def main():
             rec.update(mfma_busy_cycles=mfma.get(k, 0), grbm_gui_active_sum_over_8_xcd=gui[k],
                        mfma_busy_frac=round(mfma.get(k, 0) / (gui[k] / 8 * 1024), 3))
         out.append(rec)
-    json.dump(out, sys.stdout, indent=1)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from vstar_amd.provenance import kernel_source_hash
+    # round 5: stamped with the hash of the kernel sources the profiled run was built from (bench.py refuses another build's file)
+    json.dump({"kernel_source_hash": kernel_source_hash(), "kernels": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

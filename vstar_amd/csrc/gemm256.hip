@@ -46,13 +46,24 @@ typedef __attribute__((address_space(3))) void* lptr_t;
     __builtin_amdgcn_sched_barrier(0);                              \
   } while (0)
 
+#ifdef GEMM_TIMELINE   // diagnostic builds only (tools/gemm_timeline.py): wall-clock stamps (100 MHz) of the tile phases
+__device__ unsigned long long g_timeline[2][2][64][8];      // [block 0 | block 100][wave 0 | wave 4][tile][point]
+#define TL_STAMP(pt)                                                                                              \
+  do {                                                                                                            \
+    if (lane == 0 && (wave & 3) == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && tl_tile < 64)                   \
+      g_timeline[blockIdx.x ? 1 : 0][wave >> 2][tl_tile][pt] = wall_clock64();                                    \
+  } while (0)
+#else
+#define TL_STAMP(pt) do { } while (0)
+#endif
+
 template <int EPI, bool OUT_F32, bool F8>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   constexpr int ES = F8 ? 1 : 2;                    // bytes per operand element; a K-tile is 128 bytes of every row either way
   constexpr int BKE = 128 / ES;                     // elements per K-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
+  int lane = tid & 63;                             // (re-read after every K loop, see there)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = wave >> 2;                     // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
 
@@ -66,7 +77,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // The first K-tile of the NEXT output tile is DMA'd (into ring buffer 0, dead by then) BEFORE the epilogue of the
   // current one, whose LDS slabs live in ring buffer 1 (where the last K-tile — K/64 is even — was just consumed): the
   // pipeline fill of a tile overlaps the output stores of its predecessor.
-  const int st_r = lane >> 3, st_c = lane & 7;
+  int st_r = lane >> 3, st_c = lane & 7;
   uint32_t src_off[4][2];   // BYTE offset of this lane's 16-B chunk at k0 = 0, per piece type and u
   int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
   int m0 = 0, n0 = 0;
@@ -81,7 +92,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // d = (wc&1)*32 + fq*8.. and d + 64 into ONE lane (fragments 0|1 and 2|3), the rotate-half partner without any exchange; the
   // SiLU tiles (storage rows: 16 gate rows, 16 up rows, ...) put gate / up of 8 consecutive outputs into fragments 0,2 / 1,3.
   // Same dot products, same k order, same rounding points, same statistics tree: bit-identical to the LDS epilogue.
-  const bool dir_launch = !OUT_F32 && !(p.debug_flags & 7) && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) && (p.ldc % 8 == 0) &&
+  // (not for the erf GELU: 128 inlined erff bodies per lane spill; its two launches per step keep the rolled LDS epilogue)
+  const bool dir_launch = !OUT_F32 && EPI != VSTAR_EPI_GELU && !(p.debug_flags & 7) && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) && (p.ldc % 8 == 0) &&
                           (p.res == nullptr || ((((uintptr_t)p.res & 15) == 0) && (p.ldr % 8 == 0))) &&
                           (p.bias == nullptr || (((uintptr_t)p.bias & 15) == 0));
   bool dir_tile = false;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   // ---- fragment read offsets (same row-major + (row>>1)&7 chunk swizzle as gemm.hip) ----
   const int wr = wave >> 2, wc = wave & 3;
-  const int fr = lane & 15, fq = lane >> 4;
+  int fr = lane & 15, fq = lane >> 4;
   const int swz = (fr >> 1) & 7;
   int a_rd[2], w_rd[2];
 #pragma unroll
@@ -163,12 +175,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 
   int bid = blockIdx.x;
   if (bid >= nwg) return;
+  // Experiment switch (VSTAR_GEMM_XCD_STAGGER=n -> debug bits 8..15): XCD x (= blockIdx % 8) starts x * n * ~0.26 us late, so that
+  // the eight XCDs — which share no L2 and therefore do not pull each other back into step — reach their store bursts at
+  // different times (all 256 CUs storing 128 KB at once is a 32-MiB burst against ~5 TB/s of write bandwidth).
+  if (const int stg = (p.debug_flags >> 8) & 0xff) {
+    for (int i = 0; i < (int)(blockIdx.x & 7) * stg; ++i) __builtin_amdgcn_s_sleep(8);
+  }
   set_tile(bid);
   issue_piece(std::integral_constant<int, 0>{}, 0);
   issue_piece(std::integral_constant<int, 1>{}, 0);
   issue_piece(std::integral_constant<int, 2>{}, 0);
   issue_piece(std::integral_constant<int, 3>{}, 0);
+  int tl_tile = 0; (void)tl_tile;
   for (;;) {
+  TL_STAMP(0);
   f32x4 acc[8][4];
 #pragma unroll
   for (int m = 0; m < 8; ++m)
@@ -186,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   BAR();
   if (group == 1) BAR();
+  TL_STAMP(1);
 
   // Two phases per K-tile (4 barrier rendezvous instead of 8; a barrier interval costs ~100 cycles of pure sync):
   //   phase A: read A[m-half 0], W[n-half 0], W[n-half 1] (16 x b128) -> quadrants (0,0),(0,1)   = 32 MFMA
@@ -258,7 +279,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     MFMA_PAIR(1, w1f, 1, w0f, 0)
 #undef MFMA_PAIR
   }
+  TL_STAMP(2);
   if (group == 0) BAR();   // every wave must execute the same number of barriers
+  TL_STAMP(3);
+  // Every per-lane constant the next tile's set-up and the epilogue use (row / column offsets, pointers) derives from the lane
+  // id.  Kept live ACROSS the K loop they cost registers the loop does not have (its 253 are accumulators + fragments + DMA
+  // offsets) and the compiler spills them: ten scratch reloads, each behind its own `s_waitcnt vmcnt(0)`, were 3 us of every
+  // tile (tools/gemm_timeline.py).  Re-reading the lane id here through an opaque instruction pair ends those live ranges at the
+  // loop: everything below is recomputed from it (a few dozen VALU instructions per tile).
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  st_r = lane >> 3; st_c = lane & 7;
+  fr = lane & 15; fq = lane >> 4;
 
   // folded RMSNorm: this lane's eight row scales, requested before the next tile's set-up so that they land behind it
   float rs_v[8];
@@ -283,6 +314,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     issue_piece(std::integral_constant<int, 2>{}, 0);
     issue_piece(std::integral_constant<int, 3>{}, 0);
   }
+  TL_STAMP(4);
 
   // ---- W8A8: dequantise the accumulators (per-row activation scale x per-output-channel weight scale, packed-row order) ----
   if constexpr (F8) {
@@ -351,20 +383,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     if (SILU) { col_a = (en0 + wc * 64) / 2 + fq * 8; col_b = col_a; }
     else if (rope_tile) { col_a = en0 + (wc >> 1) * 128 + (wc & 1) * 32 + fq * 8; col_b = col_a + 64; }
     else { col_a = en0 + wc * 64 + fq * 8; col_b = col_a + 32; }
-    float bia[8], bib[8];
+    const int row0 = em0 + wr * 128 + fr;                     // interior tile: rows row0 + 16 m < M, identity row map
+    lp_t* crow = (lp_t*)p.C + (int64_t)row0 * p.ldc;
+    if constexpr (SILU) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
-    if (!SILU && p.bias) {
-      const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
-    }
-    const int rope_d = (wc & 1) * 32 + fq * 8;              // rotary index of chunk a (chunk b = the same index, second half)
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int row = em0 + wr * 128 + m * 16 + fr;          // interior tile: row < M, identity row map
-      lp_t* crow = (lp_t*)p.C + (int64_t)row * p.ldc;
-      if constexpr (SILU) {
+      for (int m = 0; m < 8; ++m) {
         lpx8 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -372,17 +395,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
           v[4 + e] = (short)f2lp(act_silu_bf16(rlp(acc[m][2][e])) * rlp(acc[m][3][e]));
         }
         __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
-      } else {
-        float xa[8], xb[8];                                  // stage 1 of the LDS epilogue: bf16(acc + bias)
+        crow += 16 * p.ldc;
+      }
+    } else {
+      // ---- stage 1 for the WHOLE wave tile: bf16(acc + bias), packed — 64 registers; the 128 accumulators are dead after it ----
+      lpx8 pa[8], pb[8];
+      {
+        float bia[8], bib[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xa[e] = rlp(acc[m][0][e] + bia[e]);
-          xa[4 + e] = rlp(acc[m][1][e] + bia[4 + e]);
-          xb[e] = rlp(acc[m][2][e] + bib[e]);
-          xb[4 + e] = rlp(acc[m][3][e] + bib[4 + e]);
+        for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
+        if (p.bias) {
+          const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
         }
-        if constexpr (EPI == VSTAR_EPI_NONE) {
-          if (rope_tile) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pa[m][e] = (short)f2lp(acc[m][0][e] + bia[e]);
+            pa[m][4 + e] = (short)f2lp(acc[m][1][e] + bia[4 + e]);
+            pb[m][e] = (short)f2lp(acc[m][2][e] + bib[e]);
+            pb[m][4 + e] = (short)f2lp(acc[m][3][e] + bib[4 + e]);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- stage 2 on the packed values: RoPE / activation, in place ----
+      if constexpr (EPI == VSTAR_EPI_NONE) {
+        if (rope_tile) {
+          const int rope_d = (wc & 1) * 32 + fq * 8;          // rotary index of chunk a (chunk b: the same index, second half)
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const int row = row0 + m * 16;
             int pos = row % p.rope_S;
             if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);      // grouped sequences
             if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;   // shared prefix
@@ -391,51 +435,71 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
               const float c = lp2f((lp_t)c8[e]), sn = lp2f((lp_t)s8[e]);
-              const float lo = rlp(xa[e] * c) + rlp(-1.0f * xb[e] * sn);      // first half of the head: x*cos - partner*sin
-              const float hi = rlp(xb[e] * c) + rlp(1.0f * xa[e] * sn);       // second half: x*cos + partner*sin
-              xa[e] = lo; xb[e] = hi;
+              const float xa = lp2f((lp_t)pa[m][e]), xb = lp2f((lp_t)pb[m][e]);
+              pa[m][e] = (short)f2lp(rlp(xa * c) + rlp(-1.0f * xb * sn));      // first half of the head: x*cos - partner*sin
+              pb[m][e] = (short)f2lp(rlp(xb * c) + rlp(1.0f * xa * sn));       // second half: x*cos + partner*sin
             }
           }
-        } else if constexpr (EPI == VSTAR_EPI_QUICK_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { xa[e] = act_quick_gelu_bf16(xa[e]); xb[e] = act_quick_gelu_bf16(xb[e]); }
-        } else if constexpr (EPI == VSTAR_EPI_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { xa[e] = act_gelu_erf(xa[e]); xb[e] = act_gelu_erf(xb[e]); }
-        } else if constexpr (EPI == VSTAR_EPI_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { xa[e] = fmaxf(xa[e], 0.f); xb[e] = fmaxf(xb[e], 0.f); }
         }
-        if (p.res) {                                         // launch-uniform: rlp(activation output) + residual
-          const lp_t* rrow = p.res + (int64_t)row * p.ldr;
-          const lpx8 r0 = *(const lpx8*)(rrow + col_a), r1 = *(const lpx8*)(rrow + col_b);
+      } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { xa[e] = rlp(xa[e]) + lp2f((lp_t)r0[e]); xb[e] = rlp(xb[e]) + lp2f((lp_t)r1[e]); }
+        for (int m = 0; m < 8; ++m) {
+          gemm_epilogue_act8<EPI>(pa[m]);
+          gemm_epilogue_act8<EPI>(pb[m]);
         }
-        lpx8 va, vb;
+      }
+      // ---- residual: all sixteen 16-byte pieces of this lane in flight together, ONE wait.  Requested row by row where they are
+      // used they were eight memory round trips in series — 6 us of a 10-us epilogue (tools/gemm_timeline.py: o_proj + residual
+      // 10.5 us per tile, without 4.0) — and requested next to the live fp32 accumulators they spill; next to the packed values
+      // they fit (64 + 64 registers).
+      if (p.res) {
+        __builtin_amdgcn_sched_barrier(0);
+        lpx8 ra[8], rb[8];
+        const lp_t* rrow = p.res + (int64_t)row0 * p.ldr;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { va[e] = (short)f2lp(xa[e]); vb[e] = (short)f2lp(xb[e]); }
+        for (int m = 0; m < 8; ++m) {
+          ra[m] = *(const lpx8*)(rrow + col_a);
+          rb[m] = *(const lpx8*)(rrow + col_b);
+          rrow += 16 * p.ldr;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            pa[m][e] = (short)f2lp(lp2f((lp_t)pa[m][e]) + lp2f((lp_t)ra[m][e]));
+            pb[m][e] = (short)f2lp(lp2f((lp_t)pb[m][e]) + lp2f((lp_t)rb[m][e]));
+          }
+      }
+      // ---- stores (+ the statistics of the stored values), row by row ----
+      float* sq = nullptr;
+      if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
+        if (p.sumsq_out) sq = p.sumsq_out + (int64_t)row0 * p.sumsq_ld + (en0 + wc * 64) / 64;
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_barrier(0);      // pa / pb die as they are stored
         if (p.sumsq_out) {          // the rows are the next linear's A operand right away: keep them cache-resident
-          *(lpx8*)(crow + col_a) = va;
-          *(lpx8*)(crow + col_b) = vb;
+          *(lpx8*)(crow + col_a) = pa[m];
+          *(lpx8*)(crow + col_b) = pb[m];
         } else {
-          __builtin_nontemporal_store(va, (lpx8*)(crow + col_a));
-          __builtin_nontemporal_store(vb, (lpx8*)(crow + col_b));
+          __builtin_nontemporal_store(pa[m], (lpx8*)(crow + col_a));
+          __builtin_nontemporal_store(pb[m], (lpx8*)(crow + col_b));
         }
+        crow += 16 * p.ldc;
         if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
-          if (p.sumsq_out) {
-            // statistics of the STORED values, canonical tree (gemm_epilogue.hpp): chunk = (4 + 4 columns), chunk pairs across fq ^ 1,
-            // pairs of pairs across fq ^ 2, the two 32-column halves inside the lane
+          if (sq) {
+            // canonical tree (gemm_epilogue.hpp): chunk = (4 + 4 columns), chunk pairs across fq ^ 1, pairs of pairs across
+            // fq ^ 2, the two 32-column halves inside the lane
             float fa[8], fb[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)va[e]); fb[e] = lp2f((lp_t)vb[e]); }
+            for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)pa[m][e]); fb[e] = lp2f((lp_t)pb[m][e]); }
             float qa = (((fa[0] * fa[0] + fa[1] * fa[1]) + fa[2] * fa[2]) + fa[3] * fa[3]) +
                        (((fa[4] * fa[4] + fa[5] * fa[5]) + fa[6] * fa[6]) + fa[7] * fa[7]);
             float qb = (((fb[0] * fb[0] + fb[1] * fb[1]) + fb[2] * fb[2]) + fb[3] * fb[3]) +
                        (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
             qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
             qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
-            float* sq = p.sumsq_out + (int64_t)row * p.sumsq_ld + (en0 + wc * 64) / 64;
             if (fq == 0) sq[0] = qa + qb;
             if (p.stats_sum) {
               float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
@@ -444,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
               sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
               if (fq == 0) sq[p.stats_sum] = sa + sb;
             }
+            sq += 16 * p.sumsq_ld;
           }
         }
       }
@@ -604,6 +669,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     quarter_pass(std::integral_constant<int, 3>{});
   }
   }  // epilogue
+  TL_STAMP(5);
+  ++tl_tile;
   if (!has_next) break;
   }  // persistent tile loop
 }
@@ -626,6 +693,12 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+#if defined(GEMM_TIMELINE) && !defined(VSTAR_LP_F16)
+extern "C" int vstar_debug_gemm_timeline(unsigned long long* out) {     // 2 x 2 x 64 x 8 stamps
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_timeline), sizeof(g_timeline));
+}
+#endif
+
 // Shapes this kernel accepts: K/64 even and >= 2, operands addressable with 32-bit element offsets.
 bool gemm256_eligible(const GemmParams& p) {
   if (p.a_scale) {      // W8A8: K counts fp8 elements, a K-tile is 128 of them, K/128 even
@@ -644,6 +717,8 @@ hipError_t gemm256_lp(const GemmParams& p0, int epilogue, bool out_f32, hipStrea
   static const bool no_direct = [] { const char* e = getenv("VSTAR_GEMM_DIRECT"); return e && atoi(e) == 0; }();
   GemmParams p = p0;
   if (no_direct) p.debug_flags |= 4;
+  static const int stagger = [] { const char* e = getenv("VSTAR_GEMM_XCD_STAGGER"); return e ? atoi(e) & 0xff : 0; }();
+  p.debug_flags |= stagger << 8;
   if (p.a_scale) {       // W8A8 instantiations: the two epilogues the LLaMA linears use
     if (out_f32) return hipErrorInvalidValue;
     if (epilogue == VSTAR_EPI_NONE) return launch<VSTAR_EPI_NONE, false, true>(p, s);
