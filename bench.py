@@ -520,6 +520,15 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     crops_per_s = world * B * args.steps / dt
 
+    # board power and shader clock WHILE the step runs (rank 0, untimed extra steps; rocm-smi in a side thread).  Round 5 found the
+    # GEMM family pinned at the board's power cap on random operands: ~1400 W with the shader clock throttled to ~1.73 GHz of its
+    # 2.4 GHz (profiles/r05_power_probe.txt) — the context in which `roofline.frac` (against the 2.4-GHz peak) has to be read.
+    power = None
+    if rank == 0 and not args.tiny:
+        try:
+            power = _sample_power(step, seconds=2.5)
+        except Exception as exc:            # noqa: BLE001 — context only, never fatal
+            power = {"error": f"{type(exc).__name__}: {exc}"}
     # roofline of the dominant kernel family (bf16 MFMA GEMM): HIP events around every GEMM launch on the engine stream
     eng.profile(True)
     for _ in range(2):
@@ -568,6 +577,11 @@ def main():
                                 (f"null: no committed PMC summary carries this build's kernel_source_hash {kernel_source_hash()} "
                                  f"(newest candidate: {traffic_stale}) — re-run tools/collect_r05.sh on the GPU box"),
                 "kernel_source_hash": kernel_source_hash(),
+                "under_load": None if not power or "error" in power else dict(
+                    power, peak_at_sclk=round(peak * power["sclk_mhz"] / 2400.0, 1) if power.get("sclk_mhz") else None,
+                    frac_of_peak_at_sclk=round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4) if power.get("sclk_mhz") else None,
+                    note="board power / shader clock sampled with rocm-smi while the step runs; `peak` is the 2.4-GHz figure, "
+                         "peak_at_sclk scales it to the clock the power cap allows on these operands"),
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
@@ -734,6 +748,45 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         _print_last(json.dumps(line))
+
+
+def _sample_power(step, seconds: float = 2.5) -> dict:
+    """Runs `step` for ~`seconds` (untimed) while a side thread polls `rocm-smi --showpower --showclocks --json`; returns the mean
+    board power (W) and shader clock (MHz) over the samples taken under load."""
+    import re
+    import subprocess
+    import threading
+
+    def sample():
+        out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+        card = next(iter(json.loads(out).values()))
+        pw = next((float(v) for k, v in card.items() if "ower" in k and re.match(r"^[\d.]+$", str(v))), None)
+        ck = next((str(v) for k, v in card.items() if "sclk" in k.lower() and "speed" in k.lower()), "")
+        m = re.search(r"(\d+)\s*Mhz", ck, re.I)
+        return pw, float(m.group(1)) if m else None
+
+    samples, stop = [], threading.Event()
+
+    def loop():
+        while not stop.is_set():
+            try:
+                samples.append(sample())
+            except Exception:            # noqa: BLE001
+                pass
+            time.sleep(0.25)
+    th = threading.Thread(target=loop, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+    torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    pw = [s[0] for s in samples[1:] if s[0] is not None]
+    ck = [s[1] for s in samples[1:] if s[1] is not None]
+    if not pw and not ck:
+        return {"error": "rocm-smi returned no power / clock fields"}
+    return {"power_w": round(sum(pw) / len(pw), 0) if pw else None, "sclk_mhz": round(sum(ck) / len(ck), 0) if ck else None, "samples": len(samples)}
 
 
 def _self_launch(n: int) -> None:

@@ -81,6 +81,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   uint32_t src_off[4][2];   // BYTE offset of this lane's 16-B chunk at k0 = 0, per piece type and u
   int lds_off[4][2];        // wave-uniform LDS byte offset of the 1-KiB piece inside a K-tile buffer
   int m0 = 0, n0 = 0;
+  uint32_t a_base = 0, w_base = 0;     // this tile's scalar byte offsets into A and W
+  int cur_wkind = -1;                  // what src_off currently holds (see set_tile)
+  bool cur_a_general = true;
   // ---- direct (in-register) epilogue, round 5 ----
   // The MFMA leaves lane (fr, fq) with output columns n*16 + fq*4 + e of fragment n: 8-byte pieces, which is why the bf16 epilogue
   // used to transpose through LDS.  Which W ROW a given LDS row holds is free, though (the DMA source address is per lane): on
@@ -118,6 +121,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
     dir_tile = dir_launch && m0 + BM <= p.M && n0 + BN <= p.N;
     bool rope_t = false;
     if constexpr (EPI == VSTAR_EPI_NONE) rope_t = p.rope_cs != nullptr && n0 < p.rope_cols;
+    // The per-lane part of a DMA source offset does not depend on the tile: W rows are never clamped (W is padded) and an interior
+    // A tile under the identity row map is m0 * lda away from tile 0's.  So the tile enters through two SCALAR bases (a_base,
+    // w_base, added to the scalar pointer in issue_piece) and the eight per-lane offsets are recomputed only when their KIND changes
+    // (W row order: identity / direct / RoPE; A: interior vs clamped-or-mapped rows) — a few tiles per launch instead of every
+    // tile's ~250 VALU instructions on the critical path between two K loops (1.3 - 1.7 us per tile, tools/gemm_timeline.py).
+    const int wkind = !dir_tile ? 0 : ((EPI != VSTAR_EPI_SILU_MUL && rope_t) ? 2 : 1);
+    const bool a_general = (m0 + BM > p.M) || p.a_group > 0;
+    w_base = (uint32_t)((int64_t)n0 * p.K * ES);
+    a_base = a_general ? 0u : (uint32_t)((int64_t)m0 * p.lda * ES);
+    const bool redo_w = wkind != cur_wkind, redo_a = a_general || cur_a_general;
+    cur_wkind = wkind;
+    cur_a_general = a_general;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -130,23 +145,29 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
         const int cg = st_c ^ ((row >> 1) & 7);
         lds_off[j][u] = (isA ? 0 : A_BYTES) + row0 * 128;
         if (isA) {
-          int ar = m0 + row;
-          ar = ar < p.M ? ar : p.M - 1;
-          src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda * ES + cg * 16);
-        } else {
+          if (redo_a) {
+            if (a_general) {
+              int ar = m0 + row;
+              ar = ar < p.M ? ar : p.M - 1;
+              src_off[j][u] = (uint32_t)(gemm_map_row(ar, p.a_group, p.a_gstride, p.a_off) * p.lda * ES + cg * 16);
+            } else {
+              src_off[j][u] = (uint32_t)((int64_t)row * p.lda * ES + cg * 16);
+            }
+          }
+        } else if (redo_w) {
           int wrow = row;
-          if (dir_tile) {
+          if (wkind != 0) {
             const int wcr = row >> 6, n = (row >> 4) & 3, i = row & 15;
             if (EPI == VSTAR_EPI_SILU_MUL) {
               const int jo = (i >> 2) * 8 + (n >> 1) * 4 + (i & 3);              // output column inside the wave's 32
               wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);      // its gate (n even) / up (n odd) storage row
-            } else if (rope_t) {
+            } else if (wkind == 2) {
               wrow = (wcr >> 1) * 128 + (n >> 1) * 64 + (wcr & 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3);
             } else {
               wrow = wcr * 64 + (n >> 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3);
             }
           }
-          src_off[j][u] = (uint32_t)((int64_t)(n0 + wrow) * p.K * ES + cg * 16);
+          src_off[j][u] = (uint32_t)((int64_t)wrow * p.K * ES + cg * 16);
         }
       }
     }
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   auto issue_piece = [&](auto jc, int T) {
     constexpr int J = decltype(jc)::value;
     char* base = smem + (T & 1) * TILE_BYTES;
-    const char* gb = (const char*)((J == 0 || J == 3) ? p.A : p.W) + T * 128;
+    const char* gb = ((J == 0 || J == 3) ? (const char*)p.A + a_base : (const char*)p.W + w_base) + T * 128;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_global_load_lds((gptr_t)(gb + src_off[J][u]), (lptr_t)(base + lds_off[J][u]), 16, 0, 0);
