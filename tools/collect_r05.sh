@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-5 evidence: tools/collect_r05.sh [quick]  ->  gpurun_out/r05f/  (summaries only; raw rocprofv3 databases stay in /tmp)
+# Every summary is stamped with the hash of the kernel sources it was measured on (vstar_amd/provenance.py).
+R=$(pwd); OUT=$R/gpurun_out/r05f; RAW=/tmp/prof_r05f
+mkdir -p $OUT $RAW
+B="python $R/bench.py --no-cpu-baseline --no-search-leg --no-small-batch --no-config5-line --no-stream-leg"
+cd /tmp && export TMPDIR=/tmp
+# ---- bf16 headline: kernel trace + the three PMC passes (separate runs, per the guide) ----
+rocprofv3 --kernel-trace --stats -d $RAW/stats -o k -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m"; do
+  n=${c##*:}; ctr=${c%%:*}
+  rocprofv3 --pmc $ctr --kernel-trace -d $RAW/pmc_$n -o pmc -- $B --steps 1 --warmup 0 > /dev/null 2>&1 || echo "pass $n failed"
+done
+# ---- W8A8 (config 5 precision), 64-crop batches: the same four passes ----
+F="$B --fp8 --batch 64"
+rocprofv3 --kernel-trace --stats -d $RAW/stats8 -o k -- $F --steps 3 --warmup 1 > /dev/null 2>&1
+if [ "$1" != "quick" ]; then
+for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m"; do
+  n=${c##*:}; ctr=${c%%:*}
+  rocprofv3 --pmc $ctr --kernel-trace -d $RAW/pmc8_$n -o pmc -- $F --steps 1 --warmup 0 > /dev/null 2>&1 || echo "fp8 pass $n failed"
+done
+fi
+cd $R
+python tools/rocpd_summary.py $RAW/stats/k_results.db > $OUT/kernel_stats.csv
+python tools/rocpd_summary.py $RAW/stats8/k_results.db > $OUT/kernel_stats_fp8.csv
+python tools/pmc_summary.py $RAW/pmc_f/pmc_results.db $RAW/pmc_w/pmc_results.db $RAW/pmc_m/pmc_results.db > $OUT/pmc.json
+[ "$1" != "quick" ] && python tools/pmc_summary.py $RAW/pmc8_f/pmc_results.db $RAW/pmc8_w/pmc_results.db $RAW/pmc8_m/pmc_results.db > $OUT/pmc_fp8.json
+head -12 $OUT/kernel_stats_fp8.csv | cut -c1-200

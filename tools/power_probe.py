@@ -84,5 +84,7 @@ for data in ("random", "zeros"):
     def eng():
         assert lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100) == 0
 
-    arm(f"gemm256   {data}", eng)
-    arm(f"hipBLASLt {data}", lambda: F.linear(a, w))
+    tag = os.environ.get("POWER_PROBE_TAG", "")
+    arm(f"gemm256{tag:<10s}{data}", eng)
+    if not tag:
+        arm(f"hipBLASLt {data}", lambda: F.linear(a, w))
