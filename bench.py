@@ -534,6 +534,7 @@ def main():
     for _ in range(2):
         step()
     gemm_ms, gemm_n, gemm_flops = eng.profile_read()
+    f8_ms_m, f8_n_m, f8_flops_m = eng.profile_read_fp8() if args.fp8 else (0.0, 0, 0.0)
     eng.profile(False)
     achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     fl = cfg.flops_per_crop(T, full=not args.skip_owl)
@@ -582,6 +583,9 @@ def main():
                     frac_of_peak_at_sclk=round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4) if power.get("sclk_mhz") else None,
                     note="board power / shader clock sampled with rocm-smi while the step runs; `peak` is the 2.4-GHz figure, "
                          "peak_at_sclk scales it to the clock the power cap allows on these operands"),
+                "fp8_linears": None if not args.fp8 or f8_ms_m <= 0 else {
+                    "achieved": round(f8_flops_m / (f8_ms_m * 1e-3) / 1e12, 1), "peak": 5000.0,
+                    "frac": round(f8_flops_m / (f8_ms_m * 1e-3) / 1e12 / 5000.0, 4), "launches_per_step": int(f8_n_m) // 2},
                 "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
@@ -673,6 +677,7 @@ def main():
             eng8.profile(True)
             step8()
             g8_ms, g8_n, g8_flops = eng8.profile_read()
+            f8_ms, f8_n, f8_flops = eng8.profile_read_fp8()          # the launches that ran on the fp8 MFMA, apart
             eng8.profile(False)
             # decision-level agreement with the bf16 engine on the first 32 crops of this batch (the reference has no fp8 path: the
             # bf16 engine, pinned to the reference, is the yardstick)
@@ -701,7 +706,15 @@ def main():
                                     "peak": 5000.0, "unit": "TFLOP/s",
                                     "frac": round(g8_flops / (g8_ms * 1e-3) / 1e12 / 5000.0, 4) if g8_ms > 0 else None,
                                     "note": "all GEMM launches of one 64-crop step timed by HIP events (93 % of their FLOPs run on the "
-                                            "fp8 MFMA; the ViT / head GEMMs stay bf16), against the dense fp8 peak"},
+                                            "fp8 MFMA; the ViT / head GEMMs stay bf16), against the dense fp8 peak",
+                                    # round 5: the two populations apart, each against its own peak
+                                    "fp8_linears": {"launches": int(f8_n), "achieved": round(f8_flops / (f8_ms * 1e-3) / 1e12, 1) if f8_ms > 0 else None,
+                                                    "peak": 5000.0, "frac": round(f8_flops / (f8_ms * 1e-3) / 1e12 / 5000.0, 4) if f8_ms > 0 else None,
+                                                    "share_of_gemm_time": round(f8_ms / g8_ms, 3) if g8_ms > 0 else None},
+                                    "bf16_gemms": {"launches": int(g8_n - f8_n),
+                                                   "achieved": round((g8_flops - f8_flops) / ((g8_ms - f8_ms) * 1e-3) / 1e12, 1) if g8_ms > f8_ms else None,
+                                                   "peak": PEAK_BF16_TFLOPS,
+                                                   "frac": round((g8_flops - f8_flops) / ((g8_ms - f8_ms) * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if g8_ms > f8_ms else None}},
                        "argmax_box_same_as_bf16_engine": None if same_box is None else round(same_box, 4),
                        "search": {k: s8[k] for k in ("search_crops_per_s", "wall_s", "crops_scored", "tree", "stage_s")},
                        "search_bf16_engine_crops_per_s": s16["search_crops_per_s"],

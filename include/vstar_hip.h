@@ -250,6 +250,9 @@ int vstar_comm_destroy(vstar_handle* h);
  * Returns accumulated GEMM kernel milliseconds and launch count since the last reset. */
 int vstar_profile_enable(vstar_handle* h, int on);
 int vstar_profile_read(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
+/* The W8A8 subset of the same profile: the launches that ran on the fp8 MFMA (the LLaMA linears of a handle created with
+ * llm_w8a8 = 1), whose roofline is the ~5 PFLOP/s fp8 peak; vstar_profile_read's totals include them. */
+int vstar_profile_read_fp8(vstar_handle* h, double* gemm_ms, int64_t* gemm_launches, double* gemm_flops);
 
 /* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (device pointers).  These are the kernels the engine is built from,

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("VSTAR_LIB") or os.path.join(os.path.dirname(os.path.a
 EXPORTS = [
     "vstar_create", "vstar_destroy", "vstar_last_error", "vstar_load_tensor", "vstar_finalize_weights",
     "vstar_vsm_score_batch", "vstar_upsample_mask", "vstar_debug_read", "vstar_stream", "vstar_profile_enable",
-    "vstar_profile_read", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
+    "vstar_profile_read", "vstar_profile_read_fp8", "vstar_op_gemm", "vstar_op_layernorm", "vstar_op_rmsnorm", "vstar_op_attention",
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_op_ln_fold", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
     "vstar_image_set_slot", "vstar_image_set_slot_async", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
@@ -121,6 +121,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_profile_enable.restype = c_int
     lib.vstar_profile_read.argtypes = [H, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]
     lib.vstar_profile_read.restype = c_int
+    lib.vstar_profile_read_fp8.argtypes = [H, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]
+    lib.vstar_profile_read_fp8.restype = c_int
     lib.vstar_op_gemm.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                   c_int, c_int, c_int, c_int, c_int]
     lib.vstar_op_gemm.restype = c_int

@@ -71,6 +71,10 @@ struct EngineBase {
   double prof_ms = 0, prof_flops = 0;
   int64_t prof_launches = 0;
   double pending_flops = 0;
+  // the W8A8 launches (fp8 MFMA) of the same profile, kept apart: their peak is twice the bf16 one
+  double prof_ms8 = 0, prof_flops8 = 0;
+  int64_t prof_launches8 = 0;
+  std::vector<double> ev_flops;        // per recorded launch: its FLOPs, negative when it ran on the fp8 MFMA
 
   void set_error(const std::string& m) { error = m; tls_error() = m; }
 
@@ -197,8 +201,11 @@ struct EngineBase {
     if (e != hipSuccess) { set_error(std::string("gemm launch: ") + hipGetErrorString(e)); return VSTAR_ERR_HIP; }
     if (profile) {
       hipEventRecord(e1, stream);
-      pending_flops += 2.0 * p.M * (double)p.N * p.K;
+      const double fl = 2.0 * p.M * (double)p.N * p.K;
+      pending_flops += fl;
+      ev_flops.push_back(p.a_scale ? -fl : fl);
       prof_launches++;
+      if (p.a_scale) prof_launches8++;
     }
     return 0;
   }
@@ -227,10 +234,14 @@ struct EngineBase {
     if (!profile) return;
     for (size_t i = 0; i + 1 < ev_used; i += 2) {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) prof_ms += ms;
+      if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) {
+        prof_ms += ms;
+        if (i / 2 < ev_flops.size() && ev_flops[i / 2] < 0) { prof_ms8 += ms; prof_flops8 += -ev_flops[i / 2]; }
+      }
     }
     prof_flops += pending_flops;
     pending_flops = 0;
+    ev_flops.clear();
     ev_used = 0;
   }
 

@@ -341,6 +341,12 @@ class VstarEngine:
         _lib.check(self.lib.vstar_profile_read(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.handle)
         return ms.value, n.value, fl.value
 
+    def profile_read_fp8(self):
+        """(ms, launches, flops) of the W8A8 launches inside the current GEMM profile (vstar_profile_read_fp8)."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(self.lib.vstar_profile_read_fp8(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.handle)
+        return ms.value, n.value, fl.value
+
     @property
     def stream(self) -> int:
         return int(self.lib.vstar_stream(self.handle) or 0)
