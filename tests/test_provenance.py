@@ -1,0 +1,49 @@
+"""Provenance of committed evidence: summaries are stamped with a hash of the KERNEL sources, and bench.py only
+quotes a PMC figure measured on the kernels it is running.  CPU-only."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_kernel_source_hash_is_stable_and_tracks_kernel_edits(tmp_path, monkeypatch):
+    from vstar_amd import provenance
+    h = provenance.kernel_source_hash()
+    assert len(h) == 16 and int(h, 16) >= 0 and h == provenance.kernel_source_hash()
+    # a copy of csrc with one kernel byte changed hashes differently; a host-only edit elsewhere does not enter at all
+    dst = tmp_path / "csrc"
+    shutil.copytree(os.path.join(ROOT, "vstar_amd", "csrc"), dst, ignore=shutil.ignore_patterns("build"))
+    monkeypatch.setattr(provenance, "_CSRC", str(dst))
+    assert provenance.kernel_source_hash() == h
+    with open(dst / "gemm256.hip", "a") as f:
+        f.write("\n// edited\n")
+    assert provenance.kernel_source_hash() != h
+
+
+def test_pmc_summaries_of_this_round_carry_a_stamp():
+    """Every r05+ PMC summary under profiles/ is the stamped form ({"kernel_source_hash", "kernels"}); older rounds' files are plain
+    lists and are never quoted by bench.py any more."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r0[5-9]_pmc*.json")):
+        d = json.load(open(path))
+        assert isinstance(d, dict) and len(d["kernel_source_hash"]) == 16 and isinstance(d["kernels"], list), path
+
+
+def test_power_sampler_parses_rocm_smi_json(tmp_path, monkeypatch):
+    """bench.py::_sample_power with a stand-in rocm-smi on PATH: mean power / shader clock over the samples taken while `step` runs."""
+    fake = tmp_path / "rocm-smi"
+    fake.write_text("#!/bin/sh\necho '{\"card0\": {\"Current Socket Graphics Package Power (W)\": \"1398.0\", "
+                    "\"sclk clock speed:\": \"(1737Mhz)\", \"sclk clock level:\": \"1\", \"mclk clock speed:\": \"(2000Mhz)\"}}'\n")
+    fake.chmod(0o755)
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "class _T:\n    @staticmethod\n    def synchronize(): pass\n"
+            "bench.torch.cuda.synchronize = lambda: None\n"
+            "print(__import__('json').dumps(bench._sample_power(lambda: time.sleep(0.05), seconds=0.9)))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, PATH=str(tmp_path) + os.pathsep + os.environ["PATH"]))
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["power_w"] == 1398.0 and d["sclk_mhz"] == 1737.0 and d["samples"] >= 2

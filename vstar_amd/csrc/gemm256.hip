@@ -1,4 +1,4 @@
-// gemm256.hip — the large-shape bf16 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
+// gemm256.hip — the large-shape bf16 / fp16 / W8A8 MFMA GEMM for gfx950: 256x256x64 block tile, 8 waves (2 M x 4 N, 128x64 each),
 // 128 KiB LDS ring (2 K-tiles), global_load_lds DMA running 6 quarter-tiles ahead behind COUNTED vmcnt waits (the first
 // K-tile of the next output tile is already in flight during the epilogue), and two
 // wave groups staggered by one barrier so that on every SIMD one wave is in its MFMA cluster while its partner issues
@@ -16,6 +16,13 @@
 // (of either group) retired (lgkmcnt(0)) before an earlier barrier, and each wave then waits with a COUNTED vmcnt until
 // everything the next phase reads has landed (vmcnt(8) in A, vmcnt(6) in B) before the barrier that precedes that phase.
 // Group 1 (waves 4-7) runs one barrier behind group 0, so L of one group always overlaps M of the other.
+// (Six pieces is the measured optimum: four cost 14 - 24 %, eight — a ten-slot piece ring over all of LDS — 4 - 5 %; round 5,
+// tools/experiments/gemm256_ring10/.)
+//
+// Epilogue (round 5).  Interior tiles of a launch with aligned operands finish IN THE ACCUMULATOR REGISTERS: the wave's 64 W
+// rows are DMA'd in a permuted order so that a lane's four fragments are two runs of 8 consecutive output columns — see
+// `dir_launch` below.  Edge tiles, row-mapped outputs, fp32 outputs and the erf GELU keep the LDS-transposed epilogue.  No
+// per-lane value lives across the K loop (the lane id is re-read after it), so no instantiation spills.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
