@@ -411,6 +411,7 @@ def main():
     ap.add_argument("--text-tokens", type=int, default=64)
     ap.add_argument("--tiny", action="store_true", help="plumbing check with the tiny-width model (NOT a valid bench)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-sample", action="store_true", help="skip the 2.5 s of extra steps during which rocm-smi is sampled (profiling runs)")
     ap.add_argument("--skip-owl", action="store_true", help="core path only (diagnostic; NOT the headline metric)")
     ap.add_argument("--fake-engine", action="store_true", help="CPU plumbing check of the N-process path (gloo, stub step): "
                     "exercises rank/world handling, the per-step all-gather, the barrier and the max-over-ranks timing. NOT a bench")
@@ -524,7 +525,7 @@ def main():
     # GEMM family pinned at the board's power cap on random operands: ~1400 W with the shader clock throttled to ~1.73 GHz of its
     # 2.4 GHz (profiles/r05_power_probe.txt) — the context in which `roofline.frac` (against the 2.4-GHz peak) has to be read.
     power = None
-    if rank == 0 and not args.tiny:
+    if rank == 0 and not args.tiny and not args.no_power_sample:
         try:
             power = _sample_power(step, seconds=2.5)
         except Exception as exc:            # noqa: BLE001 — context only, never fatal

@@ -163,7 +163,8 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
     eng.close()
 
 
-def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda):
+@pytest.mark.parametrize("image_size", [336, 224])
+def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda, image_size):
     """Round 5: the 8-crop fixtures above cannot tell a 10 % systematic excess from sampling error — the
     per-crop errors on the OWL-ViT side are heavy-tailed and the pooled engine / reference-bf16 ratio moved between 0.72 and 1.21
     from fixture to fixture.  tests/golden/full7b_tl_336_x32.npz holds the reference's fp32 AND bf16 outputs for ALL 32 crops of the
@@ -174,11 +175,11 @@ def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda):
         sit sqrt(2) noise units apart, a systematic difference between the two bf16 evaluations would show as more;
       * mask offset (units of the noise model's sigma, tests/_parity.py): engine rms <= reference-bf16's + 0.2, no crop beyond 4;
       * the signed mask offsets average to zero within 3 standard errors (no bias of the engine against fp32)."""
-    z = np.load(os.path.join(GOLD, "full7b_tl_336_x32.npz"))
+    z = np.load(os.path.join(GOLD, f"full7b_tl_{image_size}_x32.npz"))       # 224: the geometry the reference REALLY runs (S = 320)
     B, T = int(z["batch"]), int(z["text_tokens"])
     crops = [int(c) for c in z["crops"]]
     assert len(crops) == B == 32
-    cfg = VSMConfig.seal_7b(336, max_batch=B, max_text_len=T + 1)
+    cfg = VSMConfig.seal_7b(image_size, max_batch=B, max_text_len=T + 1)
     eng = VstarEngine(cfg, 0)
     eng.load_state_dict(_state_dict(cfg, z))
     clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)

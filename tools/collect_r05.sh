@@ -3,7 +3,7 @@
 # Every summary is stamped with the hash of the kernel sources it was measured on (vstar_amd/provenance.py).
 R=$(pwd); OUT=$R/gpurun_out/r05f; RAW=/tmp/prof_r05f
 mkdir -p $OUT $RAW
-B="python $R/bench.py --no-cpu-baseline --no-search-leg --no-small-batch --no-config5-line --no-stream-leg"
+B="python $R/bench.py --no-cpu-baseline --no-search-leg --no-small-batch --no-config5-line --no-stream-leg --no-power-sample"
 cd /tmp && export TMPDIR=/tmp
 # ---- bf16 headline: kernel trace + the three PMC passes (separate runs, per the guide) ----
 rocprofv3 --kernel-trace --stats -d $RAW/stats -o k -- $B --steps 3 --warmup 1 > /dev/null 2>&1
@@ -24,5 +24,22 @@ cd $R
 python tools/rocpd_summary.py $RAW/stats/k_results.db > $OUT/kernel_stats.csv
 python tools/rocpd_summary.py $RAW/stats8/k_results.db > $OUT/kernel_stats_fp8.csv
 python tools/pmc_summary.py $RAW/pmc_f/pmc_results.db $RAW/pmc_w/pmc_results.db $RAW/pmc_m/pmc_results.db > $OUT/pmc.json
+cp $OUT/pmc.json profiles/r05_pmc_final.json      # (on the box: so that the bench line below quotes THIS build's traffic figure)
 [ "$1" != "quick" ] && python tools/pmc_summary.py $RAW/pmc8_f/pmc_results.db $RAW/pmc8_w/pmc_results.db $RAW/pmc8_m/pmc_results.db > $OUT/pmc_fp8.json
-head -12 $OUT/kernel_stats_fp8.csv | cut -c1-200
+head -6 $OUT/kernel_stats_fp8.csv | cut -c1-200
+if [ "$1" != "quick" ]; then
+  # ---- the driver's line, per-shape GEMM table, parity logs, decode benches ----
+  python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+  python tools/gemm_bench.py --iters 40 > $OUT/gemm_bench.txt 2>/dev/null
+  python -m pytest tests/test_fulldepth_gpu.py tests/test_decision_parity_gpu.py tests/test_w8a8_decisions_gpu.py -m gpu -q -s 2>&1 | grep -v "^$" > $OUT/fulldepth_parity_log.txt
+  for g in 336 224; do NOISE_STUDY_GEOMETRY=$g python tools/noise_study.py 2>/dev/null | grep NOISE_STUDY | sed "s/^NOISE_STUDY //" > $OUT/noise_study_x32_$g.json; done
+  python tools/vqa_bench.py --out $OUT/vqa_bench.json > /dev/null 2>&1 || true
+  python tools/cue_bench.py 2>/dev/null | tail -1 > $OUT/cue_bench.json || true
+  cp gpurun_out/w8a8_decisions*.json gpurun_out/decision_parity.json $OUT/ 2>/dev/null
+  python -c "
+import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']
+print('bench', d['value'], d['ms_per_step'], r['frac'], r.get('under_load'), 'traffic', r['traffic'])
+print('config5', d['config5'].get('crops_per_s'), d['config5'].get('roofline'))"
+  tail -4 $OUT/fulldepth_parity_log.txt
+fi
+ls -la $OUT

@@ -21,7 +21,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-GOLD = os.path.join(ROOT, "tests", "golden", "full7b_tl_336_x32.npz")
+GEOM = int(os.environ.get("NOISE_STUDY_GEOMETRY", "336"))          # 336 (bench geometry) or 224 (the reference's own)
+GOLD = os.path.join(ROOT, "tests", "golden", f"full7b_tl_{GEOM}_x32.npz")
 
 
 def one():
@@ -35,7 +36,7 @@ def one():
     from vstar_amd.weights import template_chain, trained_like_state_dict
     z = np.load(GOLD)
     B, T = int(z["batch"]), int(z["text_tokens"])
-    cfg = VSMConfig.seal_7b(336, max_batch=B, max_text_len=T + 1)
+    cfg = VSMConfig.seal_7b(GEOM, max_batch=B, max_text_len=T + 1)
     eng = VstarEngine(cfg, 0)
     eng.load_state_dict(trained_like_state_dict(cfg, seed=int(z["weight_seed"]), dtype=torch.bfloat16, share_layers=True,
                                                 chain=template_chain(SyntheticTokenizer(cfg.llm_vocab))))
