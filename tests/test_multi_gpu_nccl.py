@@ -78,8 +78,8 @@ def test_real_entry_point_over_nccl_equals_single_process(single, world, mode):
 @pytest.mark.parametrize("world", WORLDS)
 def test_bench_line_at_n_ranks(world):
     """bench.py --gpus N started WITHOUT a launcher (it spawns its own ranks): the line's collective spans N ranks, the value is the
-    whole-job aggregate, and cpu_baseline is present (tiny widths: a plumbing run, so the CPU port is skipped by --tiny — the
-    object's presence at full size is covered by the CPU test of the flag logic in tests/test_host.py)."""
+    whole-job aggregate (tiny widths: a plumbing run, so the CPU port — which rank 0 times at every N at full size, bench.py's
+    `cpu_baseline` block — is skipped by --tiny)."""
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--tiny",
                           "--batch", "4", "--stream-samples", "8", "--no-search-leg"], capture_output=True, text=True, timeout=1200,
                          cwd=ROOT, env=_env())
