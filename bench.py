@@ -491,10 +491,13 @@ def main():
     import ctypes
     vp = ctypes.c_void_p
 
-    def step():
+    def step_local():        # this rank's scoring pass alone (no collective): what rank 0 repeats while it samples power / clock
         _lib.check(eng.lib.vstar_vsm_score_batch(
             eng.handle, B, vp(clip.data_ptr()), vp(owl.data_ptr()), ids.ctypes.data_as(vp), L, loc.ctypes.data_as(vp),
             verify.ctypes.data_as(vp), nv, flags, vp(rec_dev.data_ptr())), eng.handle)   # synchronises the engine stream
+
+    def step():
+        step_local()
         if use_group:
             out = torch.empty((world * B, _lib.RESULT_FLOATS), dtype=torch.float32, device=dev)
             dist.all_gather_into_tensor(out, rec_dev)
@@ -527,7 +530,7 @@ def main():
     power = None
     if rank == 0 and not args.tiny and not args.no_power_sample:
         try:
-            power = _sample_power(step, seconds=2.5)
+            power = _sample_power(step_local, seconds=2.5)      # rank 0 only: must not enter a collective the other ranks skip
         except Exception as exc:            # noqa: BLE001 — context only, never fatal
             power = {"error": f"{type(exc).__name__}: {exc}"}
     # roofline of the dominant kernel family (bf16 MFMA GEMM): HIP events around every GEMM launch on the engine stream
