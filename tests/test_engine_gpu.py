@@ -314,6 +314,28 @@ def test_prefill_argmax_equals_first_decoded_token_at_real_widths(cuda):
     eng.close()
 
 
+def test_decode_tile_major_weights_are_bit_identical(cuda, monkeypatch):
+    """Round 5: the decode GEMV streams q|k|v, gate|up and down from a TILE-MAJOR copy of the weights (GemmParams::W_tiled: one
+    sequential HBM region per workgroup instead of 16 - 32 row streams).  Same requests, same LDS image, same arithmetic: the greedy
+    continuation at the real LLaMA widths (where the LDS-ring GEMV runs) equals the row-major one (VSTAR_DECODE_TILED=0) token for
+    token."""
+    cfg = VSMConfig.seal_7b(224, clip_layers=2, llm_layers=3, owl_layers=1, llm_vocab=4096, max_batch=2, max_text_len=80)
+    sd = random_state_dict(cfg, seed=13, dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(21)
+    clip = torch.randn(1, 3, 224, 224, generator=g).bfloat16()
+    ids = torch.randint(3, cfg.llm_vocab - 3, (1, 40), generator=g)
+    ids[0, 0] = 1
+    ids[0, 12] = -200
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("VSTAR_DECODE_TILED", flag)          # read when the decode runner is built (first generate call)
+        eng = VstarEngine(cfg, 0)
+        eng.load_state_dict(sd)
+        outs.append(eng.generate(clip, [int(t) for t in ids[0]], 16, -1))
+        eng.close()
+    assert len(outs[0]) == 16 and outs[0] == outs[1], outs
+
+
 def test_fused_rope_epilogue_is_bit_identical_to_separate_pass(cuda, monkeypatch):
     """The q|k RoPE fused into the 256^2 GEMM epilogue (M >= 1024 rows) == GEMM followed by rope_kernel, bit for bit."""
     cfg = VSMConfig.tiny()

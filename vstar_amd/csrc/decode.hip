@@ -215,14 +215,20 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void gemm_skinny_ring_kernel(cons
 
   const int nd = p.K >> 6;
   const int n = (nd - wave + SK_WAVES - 1) / SK_WAVES;          // this wave's double steps: ds = wave + 8 i
+  // tile-major weights (GemmParams::W_tiled): this workgroup's pieces lie back to back, [k-step][t][h] x 1 KiB, already in request order
+  const bool tiled = p.W_tiled != nullptr;
+  const lp_t* wt = tiled ? p.W_tiled + ((int64_t)blockIdx.x * nd * (2 * NT)) * 512 + lane * 8 : nullptr;
   auto issue = [&](int slot, int i) {
-    const int k = (wave + i * SK_WAVES) * 64;
+    const int ks = wave + i * SK_WAVES;
+    const int k = ks * 64;
     char* st = ring + slot * STAGE;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[t][h] + k), (lptr_t)(st + t * 2048 + h * 1024), 16, 0, 0);
+      for (int h = 0; h < 2; ++h) {
+        const lp_t* src = tiled ? wt + ((int64_t)ks * (2 * NT) + t * 2 + h) * 512 : wsrc[t][h] + k;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(st + t * 2048 + h * 1024), 16, 0, 0);
+      }
     __builtin_amdgcn_global_load_lds((gptr_t)(asrc + k), (lptr_t)(st + NT * 2048), 16, 0, 0);
   };
   // the first RD stages go out before anything else: neither the weights nor the raw activation rows depend on the statistics
@@ -325,10 +331,30 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void gemm_skinny_ring_kernel(cons
   else gemm_epilogue_store<EPI, OUT_F32>(p, fr, n0 + g * 4, n_out, s[0], s[0]);
 }
 
+// one thread per 16-byte chunk of the tile-major image (see GemmParams::W_tiled)
+__global__ void skinny_tile_pack_kernel(const lp_t* __restrict__ W, lp_t* __restrict__ Wt, int K, int nt, int64_t n_chunks) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_chunks) return;
+  const int lane = (int)(idx & 63);
+  const int64_t piece = idx >> 6;
+  const int per_step = 2 * nt, nd = K >> 6;
+  const int req = (int)(piece % per_step);
+  const int64_t r2 = piece / per_step;
+  const int ks = (int)(r2 % nd);
+  const int64_t wg = r2 / nd;
+  const int t = req >> 1, h = req & 1;
+  const int row16 = h * 8 + (lane >> 3);
+  const int64_t row = wg * 16 * nt + t * 16 + row16;
+  const int chunk = (lane & 7) ^ ((row16 >> 1) & 7);          // the source-side swizzle of gemm_skinny_ring_kernel's requests
+  *(lpx8*)(Wt + idx * 8) = *(const lpx8*)(W + row * K + ks * 64 + chunk * 8);
+}
+
 template <int EPI, bool OUT_F32>
-hipError_t launch_skinny_ring(const GemmParams& p, hipStream_t s) {
+hipError_t launch_skinny_ring(const GemmParams& p0, hipStream_t s) {
   constexpr int NT = (EPI == VSTAR_EPI_SILU_MUL) ? 2 : 1;
   constexpr int lds = SK_WAVES * SKR_WAVE_BYTES;
+  GemmParams p = p0;
+  if (p.N % (16 * NT)) p.W_tiled = nullptr;                     // whole 16 NT-row tiles only
   const int blocks = (p.N + 16 * NT - 1) / (16 * NT);
   static bool attr_done[2] = {false, false};
   const int nm = p.norm_w ? 1 : 0;
@@ -872,6 +898,13 @@ __global__ void argmax_rows_lp_kernel(const lp_t* __restrict__ x, int cols, int6
 
 bool gemm_skinny_eligible(const GemmParams& p) {
   return p.M > 0 && p.M <= 64 && p.a_group <= 0 && p.c_group <= 0 && p.K % 64 == 0 && (p.lda % 8) == 0;
+}
+
+hipError_t skinny_pack_tiles(const lp_t* W, lp_t* Wt, int n_rows, int K, int nt, hipStream_t s) {
+  if (n_rows <= 0 || K <= 0 || K % 64 || (nt != 1 && nt != 2) || n_rows % (16 * nt)) return hipErrorInvalidValue;
+  const int64_t n_chunks = (int64_t)n_rows * K / 8;
+  hipLaunchKernelGGL(skinny_tile_pack_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, s, W, Wt, K, nt, n_chunks);
+  return hipGetLastError();
 }
 
 hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s) {

@@ -50,6 +50,10 @@ struct GemmParams {
   // kernel choice: 0 = the dispatcher decides, 128 / 256 = force that tile (256 fails with hipErrorInvalidValue when the shape
   // is not gemm256_eligible).  Process-wide default for 0 calls: environment VSTAR_GEMM_TILE (A/B runs).
   int tile_force;
+  // gemm_skinny_ring_kernel only (round 5): a TILE-MAJOR copy of W for the decode GEMV, or null — [N / (16 NT)][K / 64][2 NT] pieces of
+  // 1 KiB, each in the lane order of the LDS-DMA request that fetches it (skinny_pack_tiles): a workgroup then streams ONE sequential
+  // region of HBM instead of 16 / 32 row streams 2 K bytes apart (tools/probes/stream_layout_probe.hip: gate|up 5.4 -> 7.0 TB/s)
+  const lp_t* W_tiled;
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 // which kernel the last gemm_lp call of THIS thread launched: 128, 256, or 0 when nothing was launched (observability for the
@@ -70,6 +74,9 @@ bool gemm256_eligible(const GemmParams& p);   // true: gemm_lp runs the 256^2 ke
 // decode-sized GEMM (decode.hip): M <= 64, identity row maps; same operands/epilogues as gemm_lp
 bool gemm_skinny_eligible(const GemmParams& p);
 hipError_t gemm_skinny_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+// Wt <- tile-major image of the packed row-major W [n_rows][K] for gemm_skinny_ring_kernel (nt = 2 for SiLU(gate)*up weights whose
+// rows interleave gate / up in blocks of 16, else 1); n_rows % (16 nt) == 0, K % 64 == 0; Wt holds n_rows * K elements
+hipError_t skinny_pack_tiles(const lp_t* W, lp_t* Wt, int n_rows, int K, int nt, hipStream_t s);
 
 // ---- KV-cached language model + Perceiver resampler (decode.hip) ----
 // x[r,:] = src[r] >= 0 ? table[src[r]] : (src[r] == INT32_MIN ? 0 : feats[-(src[r]+1)])

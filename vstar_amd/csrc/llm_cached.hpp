@@ -52,6 +52,12 @@ struct LlmCached {
   int dec_keys_bound = 0;                        // context bound the captured attention launch was sized for
   int32_t* d_dec = nullptr;                      // coherent HOST memory: [0] = tokens emitted so far, [1..] = the tokens
   int dec_cap = 0;
+  // ---- tile-major copies of the big decode weights (round 5; GemmParams::W_tiled) ----
+  // The weight-streaming GEMV gives a workgroup 16 (gate|up: 32) ROWS of the row-major matrix, i.e. 16 - 32 sequential streams 2 K
+  // bytes apart and 4096 - 22016 of them over the chip; laid out tile-major the same bytes stream at 6.5 - 7.0 TB/s instead of
+  // 5.4 - 6.5 (profiles/r05_stream_layout_probe.txt).  HBM has the room for a second copy (q|k|v, gate|up, down: 11.8 GB at 7B);
+  // built when the runner is initialised, VSTAR_DECODE_TILED=0 keeps the row-major streams (A/B, tests: bit-identical).
+  std::vector<lp_t*> wt_qkv, wt_gate_up, wt_down;
 
   void set_error(const std::string& m) { e->set_error(m); }
   int init(EngineBase* owner, const LlmCachedCfg& c, const lp_t* embed_, const std::vector<LlmBlock>* blocks_,
@@ -68,8 +74,9 @@ struct LlmCached {
   int decode_step_body(int keys_bound);
   int decode_greedy_graph(int32_t first_token, int past, int slot, int max_new, int eos_id, int32_t* out_ids, int* n_out, bool* used);
   int lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi = VSTAR_EPI_NONE,
-               const lp_t* res = nullptr, int64_t ldr = 0);
-  int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi);
+               const lp_t* res = nullptr, int64_t ldr = 0, const lp_t* Wt = nullptr);
+  int lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M, int epi,
+               const lp_t* Wt = nullptr);
   int llm_layers_prefill(int nseq, int S);
   int llm_layers_cached(int R, int nseq, int max_keys, bool single_rows);
   int forward(int nseq, const int32_t* row_off, const int32_t* src, const int32_t* kv_slot, const int32_t* prefix_slot,
@@ -120,6 +127,28 @@ inline int LlmCached::init(EngineBase* owner, const LlmCachedCfg& c, const lp_t*
     if (hipMemset(split_ws, 0, wb) != hipSuccess) { set_error("split-KV workspace memset failed"); return VSTAR_ERR_HIP; }
   }
   if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { set_error("hipEventCreate failed"); return VSTAR_ERR_HIP; }
+  {  // tile-major copies of q|k|v, gate|up and down for the decode GEMV (o_proj's 33 MB live in the Infinity Cache either way)
+    const char* env = getenv("VSTAR_DECODE_TILED");
+    const bool on = !(env && atoi(env) == 0);
+    auto tile = [&](const Lin& L, int nt, std::vector<lp_t*>& out) -> int {
+      const int rows = (L.N + 16 * nt - 1) / (16 * nt) * (16 * nt);     // (the packed W is padded to 256 rows)
+      lp_t* t = nullptr;
+      if (L.N % (16 * nt) || L.K % 64) { out.push_back(nullptr); return 0; }
+      RC(e->dalloc(&t, (size_t)rows * L.K));
+      if (skinny_pack_tiles(L.W, t, rows, L.K, nt, e->stream) != hipSuccess) { set_error("skinny_pack_tiles failed"); return VSTAR_ERR_HIP; }
+      out.push_back(t);
+      return 0;
+    };
+    if (on && c.hidden >= 512) {
+      for (int i = 0; i < c.layers; ++i) {
+        const LlmBlock& b = (*blocks)[i];
+        RC(tile(b.qkv, 1, wt_qkv));
+        RC(tile(b.gate_up, 2, wt_gate_up));
+        RC(tile(b.down, 1, wt_down));
+      }
+      if (hipStreamSynchronize(e->stream) != hipSuccess) { set_error("tile packing failed"); return VSTAR_ERR_HIP; }
+    }
+  }
   ready = true;
   return 0;
 }
@@ -135,9 +164,10 @@ inline int LlmCached::init(EngineBase* owner, const LlmCachedCfg& c, const lp_t*
 
 // GEMM dispatch for the language model: weight-streaming kernel for decode-sized M, MFMA tile kernels otherwise
 inline int LlmCached::lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C, int64_t ldc, int M, int epi, const lp_t* res,
-                               int64_t ldr) {
+                               int64_t ldr, const lp_t* Wt) {
   GemmParams p{};
   p.A = A; p.lda = lda; p.W = L.W; p.bias = L.b; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
+  p.W_tiled = Wt;
   if (gemm_skinny_eligible(p)) {
     const hipError_t he = gemm_skinny_lp(p, epi, false, e->stream);
     if (he != hipSuccess) { set_error(std::string("skinny gemm launch: ") + hipGetErrorString(he)); return VSTAR_ERR_HIP; }
@@ -149,10 +179,11 @@ inline int LlmCached::lin_auto(const lp_t* A, int64_t lda, const Lin& L, void* C
 // RMSNorm + Linear: for decode-sized M the norm is fused into the weight-streaming GEMM's operand load (bit-identical to
 // the two-kernel form), otherwise norm kernel into `scratch`, then the GEMM
 inline int LlmCached::lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch, const Lin& L, void* C, int64_t ldc, int M,
-                               int epi) {
+                               int epi, const lp_t* Wt) {
   const int H = cfg.hidden;
   GemmParams p{};
   p.A = x; p.lda = H; p.W = L.W; p.bias = L.b; p.C = C; p.ldc = ldc; p.M = M; p.N = L.N; p.K = L.K;
+  p.W_tiled = Wt;
   if (M <= 16 && L.K == H && gemm_skinny_eligible(p)) {
     p.norm_w = norm_w; p.norm_eps = cfg.rms_eps;
     const hipError_t he = gemm_skinny_lp(p, epi, false, e->stream);
@@ -160,7 +191,7 @@ inline int LlmCached::lin_norm(const lp_t* x, const lp_t* norm_w, lp_t* scratch,
     return 0;
   }
   LCHK(rmsnorm_lp(x, norm_w, scratch, M, H, cfg.rms_eps, nullptr, e->stream));
-  return lin_auto(scratch, H, L, C, ldc, M, epi);
+  return lin_auto(scratch, H, L, C, ldc, M, epi, nullptr, 0, Wt);
 }
 
 inline int LlmCached::llm_layers_prefill(int nseq, int S) {
@@ -191,14 +222,14 @@ inline int LlmCached::llm_layers_cached(int R, int nseq, int max_keys, bool sing
     const LlmBlock& b = (*blocks)[i];
     lp_t* kc = kcache + (int64_t)i * layer_stride;
     lp_t* vc = vcache + (int64_t)i * layer_stride;
-    RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE));
+    RC(lin_norm(lx, b.in_norm, lh, b.qkv, lqkv, 3 * H, R, VSTAR_EPI_NONE, wt_qkv.empty() ? nullptr : wt_qkv[i]));
     // decode steps (one new row per sequence): RoPE + cache append happen inside the attention kernel
     if (!single_rows) LCHK(rope_kv_append(lqkv, rope, d_row_pos, d_row_slot, kc, vc, slot_stride, c.max_ctx, R, c.heads, e->stream));
     LCHK(cached_attention(lqkv, kc, vc, d_row_seq, d_row_pos, d_kv, d_prefix, d_past, single_rows ? rope : nullptr, latt, R,
                           c.heads, c.max_ctx, slot_stride, max_keys, e->stream, split_ws, SPLIT_ROWS));
     RC(lin_auto(latt, H, b.o, lx, H, R, VSTAR_EPI_NONE, lx, H));
-    RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.mlp, R, VSTAR_EPI_SILU_MUL));
-    RC(lin_auto(lact, c.mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H));
+    RC(lin_norm(lx, b.post_norm, lh, b.gate_up, lact, c.mlp, R, VSTAR_EPI_SILU_MUL, wt_gate_up.empty() ? nullptr : wt_gate_up[i]));
+    RC(lin_auto(lact, c.mlp, b.down, lx, H, R, VSTAR_EPI_NONE, lx, H, wt_down.empty() ? nullptr : wt_down[i]));
   }
   return 0;
 }

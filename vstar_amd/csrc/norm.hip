@@ -227,27 +227,28 @@ __global__ __launch_bounds__(256) void ln_rstd_partials_kernel(const float* __re
 // ROUNDED row sums to zero within the smallest step used (measured: |c| 1.9e-3 -> 2.7e-7 on N(0, 0.03) rows, +0.7 % rms weight
 // rounding noise).  No run-time term, no extra epilogue operand; both kernels read the same weights, so bit-identity between
 // tile shapes is untouched.
-__global__ __launch_bounds__(256) void ln_fold_kernel(lp_t* __restrict__ W, lp_t* __restrict__ bias, const lp_t* __restrict__ g,
+// (one WAVE per row: the zero-sum pass is serial in one lane, so small workgroups keep more rows in flight per CU — load-time only)
+__global__ __launch_bounds__(64) void ln_fold_kernel(lp_t* __restrict__ W, lp_t* __restrict__ bias, const lp_t* __restrict__ g,
                                                       const lp_t* __restrict__ b_ln, int K, int zero_sum) {
   extern __shared__ __attribute__((aligned(16))) char fold_smem[];
   float* ex = (float*)fold_smem;                       // [K] the centred fp32 row
   lp_t* qb = (lp_t*)(fold_smem + (size_t)K * 4);       // [K] its 16-bit rounding
-  __shared__ float red[2][4];
   const int n = blockIdx.x, tid = threadIdx.x;
   lp_t* w = W + (int64_t)n * K;
   float dot = 0.f, sum = 0.f;
-  for (int k = tid; k < K; k += 256) {
+  // (four interleaved partial sums per lane, combined pairwise, then across the wave: the summation order of the 256-thread form)
+  float dp[4] = {0.f, 0.f, 0.f, 0.f}, sp[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = tid, q = 0; k < K; k += 64, q = (q + 1) & 3) {
     const float wv = lp2f(w[k]);
-    dot += wv * lp2f(b_ln[k]);
-    sum += wv * lp2f(g[k]);
+    dp[q] += wv * lp2f(b_ln[k]);
+    sp[q] += wv * lp2f(g[k]);
   }
-  dot = wave_sum(dot);
-  sum = wave_sum(sum);
-  if ((tid & 63) == 0) { red[0][tid >> 6] = dot; red[1][tid >> 6] = sum; }
-  __syncthreads();
-  dot = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-  const float mean = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)K;
-  for (int k = tid; k < K; k += 256) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { dp[q] = wave_sum(dp[q]); sp[q] = wave_sum(sp[q]); }
+  dot = (dp[0] + dp[1]) + (dp[2] + dp[3]);
+  sum = (sp[0] + sp[1]) + (sp[2] + sp[3]);
+  const float mean = sum / (float)K;
+  for (int k = tid; k < K; k += 64) {
     const float e = lp2f(w[k]) * lp2f(g[k]) - mean;
     ex[k] = e;
     qb[k] = f2lp(e);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void ln_fold_kernel(lp_t* __restrict__ W, lp_t
     }
   }
   __syncthreads();
-  for (int k = tid; k < K; k += 256) w[k] = qb[k];
+  for (int k = tid; k < K; k += 64) w[k] = qb[k];
   if (tid == 0 && bias) bias[n] = f2lp(lp2f(bias[n]) + dot);
 }
 
@@ -326,7 +327,7 @@ hipError_t ln_fold_weights(lp_t* W, lp_t* bias, const lp_t* g, const lp_t* b_ln,
   if (n_rows <= 0 || K <= 0 || K > 8192) return hipErrorInvalidValue;
   // VSTAR_FOLD_ZERO_SUM=0 (A/B runs): plain nearest rounding of the centred rows
   static const int zero_sum = [] { const char* e = getenv("VSTAR_FOLD_ZERO_SUM"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  hipLaunchKernelGGL(ln_fold_kernel, dim3(n_rows), dim3(256), (size_t)K * 6, s, W, bias, g, b_ln, K, zero_sum);
+  hipLaunchKernelGGL(ln_fold_kernel, dim3(n_rows), dim3(64), (size_t)K * 6, s, W, bias, g, b_ln, K, zero_sum);
   return hipGetLastError();
 }
 
