@@ -13,8 +13,8 @@ for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
 done
 # ---- W8A8 (config 5 precision), 64-crop batches: the same four passes ----
 F="$B --fp8 --batch 64"
-rocprofv3 --kernel-trace --stats -d $RAW/stats8 -o k -- $F --steps 3 --warmup 1 > /dev/null 2>&1
-if [ "$1" != "quick" ]; then
+[ "$1" != "bf16" ] && rocprofv3 --kernel-trace --stats -d $RAW/stats8 -o k -- $F --steps 3 --warmup 1 > /dev/null 2>&1
+if [ "$1" != "quick" ] && [ "$1" != "bf16" ]; then
 for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m"; do
   n=${c##*:}; ctr=${c%%:*}
   rocprofv3 --pmc $ctr --kernel-trace -d $RAW/pmc8_$n -o pmc -- $F --steps 1 --warmup 0 > /dev/null 2>&1 || echo "fp8 pass $n failed"
@@ -22,12 +22,21 @@ done
 fi
 cd $R
 python tools/rocpd_summary.py $RAW/stats/k_results.db > $OUT/kernel_stats.csv
-python tools/rocpd_summary.py $RAW/stats8/k_results.db > $OUT/kernel_stats_fp8.csv
+[ "$1" != "bf16" ] && python tools/rocpd_summary.py $RAW/stats8/k_results.db > $OUT/kernel_stats_fp8.csv
 python tools/pmc_summary.py $RAW/pmc_f/pmc_results.db $RAW/pmc_w/pmc_results.db $RAW/pmc_m/pmc_results.db > $OUT/pmc.json
 cp $OUT/pmc.json profiles/r05_pmc_final.json      # (on the box: so that the bench line below quotes THIS build's traffic figure)
-[ "$1" != "quick" ] && python tools/pmc_summary.py $RAW/pmc8_f/pmc_results.db $RAW/pmc8_w/pmc_results.db $RAW/pmc8_m/pmc_results.db > $OUT/pmc_fp8.json
-head -6 $OUT/kernel_stats_fp8.csv | cut -c1-200
-if [ "$1" != "quick" ]; then
+[ "$1" != "quick" ] && [ "$1" != "bf16" ] && python tools/pmc_summary.py $RAW/pmc8_f/pmc_results.db $RAW/pmc8_w/pmc_results.db $RAW/pmc8_m/pmc_results.db > $OUT/pmc_fp8.json
+[ "$1" != "bf16" ] && head -6 $OUT/kernel_stats_fp8.csv | cut -c1-200
+if [ "$1" = "bf16" ]; then      # (round 5, last kernel edit touched decode.hip only: re-stamp the bf16 evidence, bench line, decode benches)
+  python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+  python tools/vqa_bench.py --out $OUT/vqa_bench.json > /dev/null 2>&1 || true
+  python tools/cue_bench.py 2>/dev/null | tail -1 > $OUT/cue_bench.json || true
+  python -c "
+import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']
+print('bench', d['value'], d['ms_per_step'], r['frac'], r['under_load'], 'traffic', r['traffic'], r['kernel_source_hash'])
+print('config5', d['config5'].get('crops_per_s'), d['config5']['roofline']['fp8_linears'])"
+fi
+if [ "$1" != "quick" ] && [ "$1" != "bf16" ]; then
   # ---- the driver's line, per-shape GEMM table, parity logs, decode benches ----
   python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench.json
   python tools/gemm_bench.py --iters 40 > $OUT/gemm_bench.txt 2>/dev/null

@@ -242,15 +242,30 @@ __global__ __launch_bounds__(SK_WAVES * 64, 2) void gemm_skinny_ring_kernel(cons
   float rstd = 1.f;
   if (NORM) {
     float* rs_sh = (float*)(smem + (SK_WAVES - 1) * SKR_WAVE_BYTES + (RD - 1) * STAGE);
+    // Round 5: the row's loads go out EIGHT AT A TIME and are consumed behind one wait.  With the ring's DMA requests already in
+    // flight the compiler guards every ordinary load with `s_waitcnt vmcnt(0)`, so the one-load-per-iteration form paid a memory
+    // round trip per 512 elements — eight in series for K = 4096, ~5 us of the ~10 us by which the two norm-fused GEMVs of a layer
+    // exceeded their streaming time (profiles/r05_vqa_kernel_stats_*.csv).  Same loads, same summation order (vi ascending, then e):
+    // out-of-range slots read a clamped address and contribute +0.
+    const int nvec = p.K >> 3;
     for (int row = wave; row < p.M; row += SK_WAVES) {
       const lp_t* xr = p.A + (int64_t)row * p.lda;
       float sum = 0.f;
-      for (int vi = lane; vi * 8 < p.K; vi += 64) {
-        const lpx8 t = *(const lpx8*)(xr + vi * 8);
+      for (int v0 = lane; v0 < nvec; v0 += 64 * 8) {
+        lpx8 t[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = lp2f((lp_t)t[e]);
-          sum += v * v;
+        for (int j = 0; j < 8; ++j) {
+          const int vi = v0 + 64 * j;
+          t[j] = *(const lpx8*)(xr + (vi < nvec ? vi : nvec - 1) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const bool in = v0 + 64 * j < nvec;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = in ? lp2f((lp_t)t[j][e]) : 0.f;
+            sum += v * v;
+          }
         }
       }
       sum = wave_sum(sum);
