@@ -548,7 +548,9 @@ def main():
     # HBM-side traffic of the GEMM family per launch, from the committed rocprofv3 PMC passes of this same command
     # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; profiles/r01_pmc_v7.json) — not re-measured live
     traffic, traffic_src, traffic_stale = None, None, None
-    from vstar_amd.provenance import kernel_source_hash
+    # round 6: the stamp is the hash COMPILED INTO the loaded libvstar_hip.so (build.sh -> vstar_build_source_hash), not
+    # a hash of whatever sources lie in the tree when this line runs; a tree that differs from the binary is reported, not hidden
+    from vstar_amd.provenance import kernel_source_hash as _tree_hash, library_source_hash as kernel_source_hash
     import glob
     # newest committed PMC summary first: rNN_pmc_final.json of the latest round, then its numbered passes (round 2 read a stale
     # file here because "_final" did not match the pattern)
@@ -582,6 +584,7 @@ def main():
                                 (f"null: no committed PMC summary carries this build's kernel_source_hash {kernel_source_hash()} "
                                  f"(newest candidate: {traffic_stale}) — re-run tools/collect_r05.sh on the GPU box"),
                 "kernel_source_hash": kernel_source_hash(),
+                "kernel_source_hash_matches_tree": kernel_source_hash() == _tree_hash(),
                 "under_load": None if not power or "error" in power else dict(
                     power, peak_at_sclk=round(peak * power["sclk_mhz"] / 2400.0, 1) if power.get("sclk_mhz") else None,
                     frac_of_peak_at_sclk=round(achieved / (peak * power["sclk_mhz"] / 2400.0), 4) if power.get("sclk_mhz") else None,

@@ -100,6 +100,9 @@ typedef struct vstar_result {
 int vstar_create(const vstar_config* cfg, int device, vstar_handle** out);
 void vstar_destroy(vstar_handle* h);
 const char* vstar_last_error(const vstar_handle* h);
+/* 16 hex digits: hash of the kernel sources (vstar_amd/csrc/*.hip, *.hpp, build.sh) this library was BUILT from.  No reference
+ * counterpart; evidence files under profiles/ are stamped with it (vstar_amd/provenance.py). */
+const char* vstar_build_source_hash(void);
 
 /* Weight hand-over, one checkpoint tensor at a time, keyed by its HF state-dict name
  * (VSM keys as listed in SURVEY.md §5; the CLIP tower's keys carry the prefix "clip.").

@@ -4,7 +4,6 @@ bf16 on torch-CPU; the engine must land within `factor` x the bf16 evaluation's 
 import numpy as np
 
 
-MASK_SIGMA_CAL = 1.2      # measured rms of the reference-bf16's own mask offsets in units of the model's sigma (see below)
 
 
 def rel_l2(got, ref):
@@ -38,7 +37,7 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
     # tails) — a change of rounding points (the folded ViT LayerNorms) moved one tiny-model mask from 2.9 to 3.08 sigma.  The bound is
     # therefore 4 sigma per mask (6e-5 each) AND the rms over the call's n masks within 1 + 3 / sqrt(2 n) of its expectation 1
     # (three standard deviations of the rms of n unit Gaussians: 3.1 for one mask, 2.06 for four, 1.375 for thirty-two).
-    zs = []
+    zs, zs16 = [], []
     for b in range(got.shape[0]):
         eps = np.hypot(rel_l2(h16[b], h32[b]), rel_l2(m16[b], m32[b]))
         sigma = eps * np.linalg.norm(h32[b]) * np.linalg.norm(m32[b]) / np.sqrt(h32.shape[-1])
@@ -47,16 +46,21 @@ def assert_mask_within_bf16_noise(got, ref32, ref16, hyper32, hyper16, upmean32,
         if report is not None:
             report[f"mask_offset_sigma[{b}]"] = (off / sigma, off16 / sigma)
         zs.append(off / sigma)
+        zs16.append(off16 / sigma)
         assert off <= 4.0 * sigma, f"mask {b}: offset {off:.4f} outside 4 sigma = {4 * sigma:.4f} of the bf16 noise model"
-    # Round 5: the UNIT is calibrated.  The noise model's sigma is a first-order estimate; measured against it, the reference's OWN
-    # bf16 run has offset rms 1.12 over the 32 crops of tests/golden/full7b_tl_336_x32.npz (1.29 / 1.32 / 1.28 over the 8-crop
-    # fixtures) where a perfectly scaled sigma would give 1.00 — the model under-estimates the spread by ~1.2 x for ANY bf16
-    # evaluation of this head (the engine: 1.23 over the same 32 crops, tests/test_fulldepth_gpu.py).  The bound is three standard
-    # deviations of the rms of n Gaussians of THAT scale; the per-mask 4-sigma cap above is unchanged.
+    # The UNIT is calibrated PER FIXTURE (round 6; the round-5 global constant 1.2 loosened every caller's gate).  The noise model's
+    # sigma is a first-order estimate: measured against it, the reference's OWN bf16 run on the same masks has offset rms `rms16`
+    # (1.12 over the 32 crops of full7b_tl_336_x32.npz, 1.28 - 1.32 over the 8-crop fixtures) where a perfectly scaled sigma would
+    # give 1.00.  The engine is therefore bounded by THAT run: rms <= max(1, rms16) * (1 + 3 / sqrt(2 n)) — three standard deviations
+    # of the rms of n Gaussians of the scale the reference's bf16 evaluation shows on these very masks, never tighter than the ideal
+    # model; the per-mask 4-sigma cap above is unchanged.
     n = len(zs)
     rms = float(np.sqrt(np.mean(np.square(zs))))
-    bound = MASK_SIGMA_CAL * (1.0 + 3.0 / np.sqrt(2.0 * n))
-    assert rms <= bound, f"mask offsets: rms {rms:.2f} sigma over {n} masks (bound {bound:.2f})"
+    rms16 = float(np.sqrt(np.mean(np.square(zs16))))
+    if report is not None:
+        report["mask_offset_rms"] = (rms, rms16)
+    bound = max(1.0, rms16) * (1.0 + 3.0 / np.sqrt(2.0 * n))
+    assert rms <= bound, f"mask offsets: rms {rms:.2f} sigma over {n} masks (bound {bound:.2f}; reference bf16 {rms16:.2f})"
 
 
 def fmt(report):

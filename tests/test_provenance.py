@@ -47,3 +47,10 @@ def test_power_sampler_parses_rocm_smi_json(tmp_path, monkeypatch):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(out.stdout.strip().splitlines()[-1])
     assert d["power_w"] == 1398.0 and d["sclk_mhz"] == 1737.0 and d["samples"] >= 2
+
+
+def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib):
+    """the stamp identifies the BINARY — build.sh compiles kernel_source_hash() into the library; a tree whose kernel
+    sources differ from the loaded library's is refused by checked_hash()."""
+    from vstar_amd import provenance
+    assert provenance.library_source_hash() == provenance.kernel_source_hash() == provenance.checked_hash()

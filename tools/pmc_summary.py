@@ -49,9 +49,10 @@ def main():
         out.append(rec)
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from vstar_amd.provenance import kernel_source_hash
-    # round 5: stamped with the hash of the kernel sources the profiled run was built from (bench.py refuses another build's file)
-    json.dump({"kernel_source_hash": kernel_source_hash(), "kernels": out}, sys.stdout, indent=1)
+    from vstar_amd.provenance import checked_hash
+    # stamped with the hash compiled into the library the profiled command LOADED (round 6; checked_hash() refuses to stamp when the
+    # tree's sources are not the ones that library was built from); bench.py quotes only a file carrying its own library's hash
+    json.dump({"kernel_source_hash": checked_hash(), "kernels": out}, sys.stdout, indent=1)
 
 
 if __name__ == "__main__":

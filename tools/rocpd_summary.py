@@ -10,8 +10,8 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from vstar_amd.provenance import kernel_source_hash  # noqa: E402
-print(f"# kernel_source_hash {kernel_source_hash()}")      # round 5: which kernel sources this profile belongs to
+from vstar_amd.provenance import checked_hash  # noqa: E402
+print(f"# kernel_source_hash {checked_hash()}")      # round 5: which kernel sources this profile belongs to
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
 for name, calls, tot, avg, pct in rows:

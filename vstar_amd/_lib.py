@@ -21,7 +21,7 @@ EXPORTS = [
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_op_ln_fold", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
     "vstar_image_set_slot", "vstar_image_set_slot_async", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
-    "vstar_comm_destroy",
+    "vstar_comm_destroy", "vstar_build_source_hash",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -75,6 +75,8 @@ def load() -> ctypes.CDLL:
     lib.vstar_destroy.restype = None
     lib.vstar_last_error.argtypes = [H]
     lib.vstar_last_error.restype = c_char_p
+    lib.vstar_build_source_hash.argtypes = []
+    lib.vstar_build_source_hash.restype = c_char_p
     lib.vstar_load_tensor.argtypes = [H, c_char_p, c_void_p, c_int, c_int, POINTER(c_int64)]
     lib.vstar_load_tensor.restype = c_int
     lib.vstar_finalize_weights.argtypes = [H]

@@ -24,6 +24,23 @@ for f in gemm gemm256 norm attention elementwise decode vqa_engine; do
   [ -f $f.hip ] || continue
   if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
 done
+# the hash of the kernel sources THIS binary is built from (vstar_amd/provenance.py::kernel_source_hash, same algorithm), compiled
+# into the library and exported as vstar_build_source_hash(): evidence files are stamped with the LOADED library's value, so a
+# .hip edited between building and profiling / summarising shows up as a mismatch instead of a matching stamp.
+SRC_HASH=$(python3 - <<'PY'
+import glob, hashlib, os
+h = hashlib.sha256()
+for path in sorted(glob.glob("*.hip") + glob.glob("*.hpp") + ["build.sh"]):
+    h.update(os.path.basename(path).encode())
+    h.update(open(path, "rb").read())
+print(h.hexdigest()[:16])
+PY
+)
+cat > build/src_hash.cpp.new <<EOF2
+extern "C" const char* vstar_build_source_hash(void) { return "$SRC_HASH"; }
+EOF2
+if ! cmp -s build/src_hash.cpp.new build/src_hash.cpp; then mv build/src_hash.cpp.new build/src_hash.cpp; else rm build/src_hash.cpp.new; fi
+if [ ! -f build/src_hash.o ] || [ build/src_hash.cpp -nt build/src_hash.o ]; then g++ -O2 -fPIC -c build/src_hash.cpp -o build/src_hash.o; fi
 fail=0
 for p in "${pids[@]}"; do wait $p || fail=1; done
 [ $fail -eq 0 ] || { echo "build failed"; exit 1; }

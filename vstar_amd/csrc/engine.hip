@@ -857,9 +857,12 @@ int vstar_engine::score(int B, const lp_t* clip_pix, const lp_t* owl_pix, const 
   last_B = B; last_S = S;
   const bool graphs_on = score_graph_on;
   const bool dev_pix = (flags & (VSTAR_F_INTERNAL_PIXELS | VSTAR_F_DEVICE_INPUTS)) != 0;
-  if (graphs_on && dev_pix && B <= score_graph_max_B && !profile && h_ids_pin && h_rowidx_pin) {
-    // per-call data through the pinned staging buffers (the previous call has synchronised, or its copies have long been consumed:
-    // a VSTAR_F_NO_SYNC caller must not reuse the engine before its own synchronisation — same contract as for `ids` itself)
+  grp_R0 = grp_Lc = 0;      // host-side state of the pass: reset HERE, not in score_body — a replayed graph never runs that code
+  // Not for VSTAR_F_NO_SYNC callers: the graph's H2D nodes read the single pinned staging buffers asynchronously, so a second
+  // un-synchronised call would overwrite them before the first graph's copy has run (the eager path stages pageable `ids` at call
+  // time and has no such window).
+  if (graphs_on && dev_pix && B <= score_graph_max_B && !profile && h_ids_pin && h_rowidx_pin && !(flags & VSTAR_F_NO_SYNC)) {
+    // per-call data through the pinned staging buffers (this call synchronises before it returns, see the condition above)
     memcpy(h_ids_pin, ids, (size_t)B * L * 4);
     memcpy(h_rowidx_pin, rowidx.data(), rowidx.size() * 4);
     const ScoreSig sig{B, L, n_verify, img_col, psh, flags & ~(unsigned)VSTAR_F_NO_SYNC, cpix, opix};

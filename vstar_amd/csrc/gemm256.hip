@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
   // Same dot products, same k order, same rounding points, same statistics tree: bit-identical to the LDS epilogue.
   // (not for the erf GELU: 128 inlined erff bodies per lane spill; its two launches per step keep the rolled LDS epilogue)
   const bool dir_launch = !OUT_F32 && EPI != VSTAR_EPI_GELU && !(p.debug_flags & 7) && p.c_group <= 0 && (((uintptr_t)p.C & 15) == 0) && (p.ldc % 8 == 0) &&
-                          (p.res == nullptr || ((((uintptr_t)p.res & 15) == 0) && (p.ldr % 8 == 0))) &&
+                          (p.res == nullptr || (EPI != VSTAR_EPI_SILU_MUL && (((uintptr_t)p.res & 15) == 0) && (p.ldr % 8 == 0))) &&
                           (p.bias == nullptr || (((uintptr_t)p.bias & 15) == 0));
   bool dir_tile = false;
   // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering; DMA source offsets of that tile ----

@@ -58,6 +58,7 @@ struct LlmCached {
   // 5.4 - 6.5 (profiles/r05_stream_layout_probe.txt).  HBM has the room for a second copy (q|k|v, gate|up, down: 11.8 GB at 7B);
   // built when the runner is initialised, VSTAR_DECODE_TILED=0 keeps the row-major streams (A/B, tests: bit-identical).
   std::vector<lp_t*> wt_qkv, wt_gate_up, wt_down;
+  bool tiled_fallback = false;      // the tile-major copies were wanted but did not fit / pack: decode runs on the row-major weights
 
   void set_error(const std::string& m) { e->set_error(m); }
   int init(EngineBase* owner, const LlmCachedCfg& c, const lp_t* embed_, const std::vector<LlmBlock>* blocks_,
@@ -127,26 +128,45 @@ inline int LlmCached::init(EngineBase* owner, const LlmCachedCfg& c, const lp_t*
     if (hipMemset(split_ws, 0, wb) != hipSuccess) { set_error("split-KV workspace memset failed"); return VSTAR_ERR_HIP; }
   }
   if (hipEventCreate(&ev0) != hipSuccess || hipEventCreate(&ev1) != hipSuccess) { set_error("hipEventCreate failed"); return VSTAR_ERR_HIP; }
-  {  // tile-major copies of q|k|v, gate|up and down for the decode GEMV (o_proj's 33 MB live in the Infinity Cache either way)
+  {  // tile-major copies of q|k|v, gate|up and down for the decode GEMV (o_proj's 33 MB live in the Infinity Cache either way).
+     // OPTIONAL: the row-major weights serve the same GEMV (W_tiled == nullptr), so a failed allocation or pack — ~11.8 GB more at
+     // 7B — drops the copies, clears the error and continues row-major instead of failing generate().
     const char* env = getenv("VSTAR_DECODE_TILED");
     const bool on = !(env && atoi(env) == 0);
-    auto tile = [&](const Lin& L, int nt, std::vector<lp_t*>& out) -> int {
+    wt_qkv.clear(); wt_gate_up.clear(); wt_down.clear();      // a retried init starts from empty lists: wt_*[i] is layer i or nothing
+    std::vector<void*> mine;                                  // this block's allocations, freed together if any step fails
+    bool ok = true;
+    auto tile = [&](const Lin& L, int nt, std::vector<lp_t*>& out) {
       const int rows = (L.N + 16 * nt - 1) / (16 * nt) * (16 * nt);     // (the packed W is padded to 256 rows)
-      lp_t* t = nullptr;
-      if (L.N % (16 * nt) || L.K % 64) { out.push_back(nullptr); return 0; }
-      RC(e->dalloc(&t, (size_t)rows * L.K));
-      if (skinny_pack_tiles(L.W, t, rows, L.K, nt, e->stream) != hipSuccess) { set_error("skinny_pack_tiles failed"); return VSTAR_ERR_HIP; }
-      out.push_back(t);
-      return 0;
+      if (L.N % (16 * nt) || L.K % 64) { out.push_back(nullptr); return; }
+      void* t = nullptr;
+      if (hipMalloc(&t, (size_t)rows * L.K * sizeof(lp_t)) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+      mine.push_back(t);
+      if (skinny_pack_tiles(L.W, (lp_t*)t, rows, L.K, nt, e->stream) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+      out.push_back((lp_t*)t);
     };
     if (on && c.hidden >= 512) {
+      size_t need = 0, free_b = 0, total_b = 0;
       for (int i = 0; i < c.layers; ++i) {
         const LlmBlock& b = (*blocks)[i];
-        RC(tile(b.qkv, 1, wt_qkv));
-        RC(tile(b.gate_up, 2, wt_gate_up));
-        RC(tile(b.down, 1, wt_down));
+        need += ((size_t)b.qkv.N * b.qkv.K + (size_t)b.gate_up.N * b.gate_up.K + (size_t)b.down.N * b.down.K) * sizeof(lp_t);
       }
-      if (hipStreamSynchronize(e->stream) != hipSuccess) { set_error("tile packing failed"); return VSTAR_ERR_HIP; }
+      // keep 1 GiB of headroom for the caller's later allocations (KV growth happens above; this is the last big block of init)
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < need + ((size_t)1 << 30)) { (void)hipGetLastError(); ok = false; }
+      for (int i = 0; ok && i < c.layers; ++i) {
+        const LlmBlock& b = (*blocks)[i];
+        tile(b.qkv, 1, wt_qkv);
+        if (ok) tile(b.gate_up, 2, wt_gate_up);
+        if (ok) tile(b.down, 1, wt_down);
+      }
+      if (hipStreamSynchronize(e->stream) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+      if (ok) {
+        for (void* q : mine) e->allocs.push_back(q);            // owned by the engine from here on
+      } else {
+        for (void* q : mine) hipFree(q);
+        wt_qkv.clear(); wt_gate_up.clear(); wt_down.clear();    // row-major decode (callers test .empty())
+        tiled_fallback = true;
+      }
     }
   }
   ready = true;

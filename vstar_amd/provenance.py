@@ -18,3 +18,20 @@ def kernel_source_hash() -> str:
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def library_source_hash() -> str:
+    """The hash compiled into the LOADED libvstar_hip.so (build.sh -> vstar_build_source_hash): which sources the binary that is
+    actually running was built from.  Evidence is stamped with THIS value; `kernel_source_hash()` of the tree must equal it or the
+    build is stale (a source hash taken at summary time does not identify the profiled binary)."""
+    from . import _lib
+    return _lib.load().vstar_build_source_hash().decode()
+
+
+def checked_hash() -> str:
+    """library_source_hash(), after checking that the tree's kernel sources are the ones the loaded library was built from."""
+    lib_h, src_h = library_source_hash(), kernel_source_hash()
+    if lib_h != src_h:
+        raise RuntimeError(f"libvstar_hip.so was built from kernel sources {lib_h}, the tree holds {src_h}: rebuild "
+                           "(__graft_entry__.build()) before producing or quoting evidence")
+    return lib_h
