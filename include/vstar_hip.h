@@ -100,7 +100,7 @@ typedef struct vstar_result {
 int vstar_create(const vstar_config* cfg, int device, vstar_handle** out);
 void vstar_destroy(vstar_handle* h);
 const char* vstar_last_error(const vstar_handle* h);
-/* 16 hex digits: hash of the kernel sources (vstar_amd/csrc/*.hip, *.hpp, build.sh) this library was BUILT from.  No reference
+/* 16 hex digits: hash of the kernel sources (the .hip / .hpp files of vstar_amd/csrc and build.sh) this library was BUILT from.  No reference
  * counterpart; evidence files under profiles/ are stamped with it (vstar_amd/provenance.py). */
 const char* vstar_build_source_hash(void);
 
@@ -265,8 +265,10 @@ int vstar_profile_read_fp8(vstar_handle* h, double* gemm_ms, int64_t* gemm_launc
 enum { VSTAR_EPI_NONE = 0, VSTAR_EPI_QUICK_GELU = 1, VSTAR_EPI_GELU = 2, VSTAR_EPI_RELU = 3, VSTAR_EPI_SILU_MUL = 4,
        VSTAR_EPI_NOSYNC = 0x100, /* OR-ed into `epilogue`: launch only, do not synchronise (micro-benchmarks) */
        VSTAR_EPI_TILE128 = 0x200, /* OR-ed into `epilogue`: force the 128x128 kernel for this call */
-       VSTAR_EPI_TILE256 = 0x400  /* OR-ed into `epilogue`: force the 256x256 kernel; VSTAR_ERR_INVALID when the shape is outside
-                                     its domain (M >= 1024, N >= 256, K % 128 == 0) — never silently re-routed */ };
+       VSTAR_EPI_TILE256 = 0x400, /* OR-ed into `epilogue`: force the 8-wave 256x256 kernel; VSTAR_ERR_INVALID when the shape is outside
+                                     its domain (M >= 1024, N >= 256, K % 128 == 0) — never silently re-routed */
+       VSTAR_EPI_TILE4W = 0x800   /* OR-ed into `epilogue`: force the 4-wave / AGPR 256x256 kernel (gemm4w.hip); error outside its
+                                     domain (M % 256 == 0, N % 256 == 0, K % 128 == 0, 16-byte aligned operands, bf16/fp16 output) */ };
 
 /* C[M,N] = epi(A[M,K] @ W[N,K]^T + bias) (+ residual).  bf16 in, fp32 accumulate (MFMA), bf16 or fp32 out.
  * Replaces every nn.Linear / conv-as-GEMM on the path (SURVEY.md §8d GEMM shape list).

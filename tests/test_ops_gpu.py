@@ -3,6 +3,7 @@ on the SAME bf16 inputs.  Tolerances: fp32-out GEMM <= 1e-3 relative (fp32 accum
 rounding step (2^-8 relative) of the fp32 result plus a small absolute term."""
 import ctypes
 import math
+import os
 
 import pytest
 import torch
@@ -29,12 +30,12 @@ def _gemm(lib, a, w, bias=None, res=None, epi=0, f32=False, n=None, tile=0):
     n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
     c = torch.full((M, n_out), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16, device=a.device)
     wp = _pad_w(w)
-    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256}[tile]
+    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256, _lib.TILE_4W: _lib.EPI_TILE4W}[tile]
     rc = lib.vstar_op_gemm(None, P(a), K, P(wp), P(bias), P(res), n_out if res is not None else 0, P(c), n_out,
                            1 if f32 else 0, M, N, K, epi | flag)
     assert rc == 0, lib.vstar_last_error(None)
     ran = lib.vstar_op_gemm_last_tile()
-    assert ran in (128, 256, 384)
+    assert ran in (128, 256, 384, _lib.TILE_4W)
     if tile:
         assert ran == tile, f"asked for the {tile}^2 kernel, the {ran}^2 kernel ran"
     torch.cuda.synchronize()
@@ -302,10 +303,13 @@ def test_gemm_tile_override_contract(lib, cuda):
     rc = lib.vstar_op_gemm(None, P(a), 128, P(w), None, None, 0, P(c), 256, 0, 300, 256, 128, _lib.EPI_TILE256 | _lib.EPI_TILE128)
     assert rc != 0
     _gemm(lib, a, w, tile=128)
-    # dispatcher defaults: a full grid of 256^2 tiles stays on the 256^2 kernel, an under-filled one moves to 128^2
+    # dispatcher defaults: a full grid of interior 256^2 tiles goes to the 4-wave kernel (round 6), one with an M tail stays on the
+    # 8-wave 256^2 kernel, an under-filled one moves to 128^2
     big_a = torch.randn(20480, 256).bfloat16().to(cuda)
     big_w = torch.randn(4096, 256).bfloat16().to(cuda)
     _gemm(lib, big_a, big_w)
+    assert lib.vstar_op_gemm_last_tile() == (_lib.TILE_4W if os.environ.get("VSTAR_GEMM4W", "1") != "0" else 256)
+    _gemm(lib, big_a[:20400], big_w)
     assert lib.vstar_op_gemm_last_tile() == 256
     _gemm(lib, big_a[:1200], big_w[:384])
     assert lib.vstar_op_gemm_last_tile() == 128
@@ -361,6 +365,61 @@ def test_gemm128_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res, f32)
     c128 = _gemm(lib, a, w, bias, res, epi=epi, f32=f32, tile=128)
     assert not torch.isnan(c256.float()).any()
     assert torch.equal(c256, c128)
+
+
+@pytest.mark.parametrize("M,N,K,epi,use_bias,use_res", [
+    (1024, 256, 128, 0, False, False),          # the smallest shape of the domain: two K-tiles, no loop iteration
+    (1024, 512, 256, 3, True, True),            # RELU + bias + residual, one loop iteration
+    (1536, 768, 384, 1, True, False),           # QUICK_GELU + bias, K/64 = 6
+    (1280, 4096, 4096, 0, False, True),         # o_proj form: residual
+    (2048, 512, 11008, 0, False, True),         # long K (down_proj)
+    (1024, 8192, 2048, 4, False, False),        # SiLU(gate)*up
+    (20480, 4096, 4096, 0, True, True),         # the bench batch's o_proj rows: 1280 tiles, five per workgroup (persistent loop)
+])
+def test_gemm4w_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res):
+    """The 4-wave / AGPR 256^2 kernel (gemm4w.hip, hand-scheduled K loop) against the 8-wave gemm256 on the same operands: same k
+    order, same epilogue arithmetic -> BIT-identical.  Five repetitions each: the loop's LDS hand-offs are ordered by counted
+    vmcnt + barriers only, a misplaced wait shows up as a rare wrong tile."""
+    g = torch.Generator(device=cuda).manual_seed(M * 3 + N + K + epi)
+    a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    if epi == _lib.EPI_SILU_MUL:
+        w = _pack_gate_up(w[: N // 2].cpu(), w[N // 2:].cpu()).to(cuda)
+    n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
+    bias = torch.randn(N, generator=g, device=cuda).bfloat16() if use_bias else None
+    res = torch.randn(M, n_out, generator=g, device=cuda).bfloat16() if use_res else None
+    c256 = _gemm(lib, a, w, bias, res, epi=epi, tile=256)
+    assert not torch.isnan(c256.float()).any()
+    for rep in range(5):
+        c4w = _gemm(lib, a, w, bias, res, epi=epi, tile=_lib.TILE_4W)
+        bad = (c4w.view(torch.int16) != c256.view(torch.int16)).sum().item()
+        assert bad == 0, (rep, bad)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 256), (2048, 512, 1024)])
+def test_gemm4w_row_scale_and_statistics(lib, cuda, M, N, K):
+    """Folded-norm row scale in, sum-of-squares partials out (the LLaMA o_proj / down / q|k|v forms): bit-identical to gemm256."""
+    g = torch.Generator(device=cuda).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    res = (3 * torch.randn(M, N, generator=g, device=cuda)).bfloat16()
+    rs = (0.5 + torch.rand(M, generator=g, device=cuda)).float()
+    c256, s256 = _gemm_norm(lib, a, w, res, tile=256, row_scale=rs, want_sumsq=True)
+    c4w, s4w = _gemm_norm(lib, a, w, res, tile=_lib.TILE_4W, row_scale=rs, want_sumsq=True)
+    torch.cuda.synchronize()
+    assert torch.equal(c256, c4w) and torch.equal(s256, s4w)
+    c256, _ = _gemm_norm(lib, a, w, None, epi=_lib.EPI_NONE, tile=256, row_scale=rs)
+    c4w, _ = _gemm_norm(lib, a, w, None, epi=_lib.EPI_NONE, tile=_lib.TILE_4W, row_scale=rs)
+    torch.cuda.synchronize()
+    assert torch.equal(c256, c4w)
+
+
+def test_gemm4w_refuses_shapes_outside_its_domain(lib, cuda):
+    a = torch.randn(1100, 256, device=cuda).bfloat16()           # M % 256 != 0
+    w = torch.randn(256, 256, device=cuda).bfloat16()
+    c = torch.empty(1100, 256, device=cuda, dtype=torch.bfloat16)
+    rc = lib.vstar_op_gemm(None, P(a), 256, P(_pad_w(w)), None, None, 0, P(c), 256, 0, 1100, 256, 256, _lib.EPI_TILE4W)
+    assert rc != 0
 
 
 @pytest.mark.parametrize("name,M,N,K,epi,use_bias,use_res", [
@@ -460,7 +519,7 @@ def _gemm_norm(lib, a, w, res=None, epi=0, tile=0, row_scale=None, want_sumsq=Fa
     n_out = N // 2 if epi == _lib.EPI_SILU_MUL else N
     c = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=a.device)
     ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=a.device) if want_sumsq else None
-    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256}[tile]
+    flag = {0: 0, 128: _lib.EPI_TILE128, 256: _lib.EPI_TILE256, _lib.TILE_4W: _lib.EPI_TILE4W}[tile]
     rc = lib.vstar_op_gemm_norm(None, P(a), K, P(_pad_w(w)), None, P(res), n_out if res is not None else 0, P(c), n_out, M, N, K,
                                 epi | flag, P(row_scale), P(ss), N // 64)
     assert rc == 0, lib.vstar_last_error(None)

@@ -61,7 +61,7 @@ for name in ("hipblaslt", "rocblas"):
 print(f"# torch {torch.__version__}, device {torch.cuda.get_device_name(0)}, operands {'zeros' if args.zeros else 'N(0,1) / N(0,1/K)'}, "
       f"{args.iters} launches x {args.rounds} interleaved rounds, best round per column; TFLOP/s = 2MNK / time")
 print(f"{'shape':<14s} {'M':>7s} {'N':>6s} {'K':>6s} | " + " ".join(f"{b + ' ms':>13s} {'TF/s':>7s}" for b in backends) +
-      f" | {'gemm256 ms':>11s} {'TF/s':>7s} | engine / best library")
+      f" | {'gemm256 ms':>11s} {'TF/s':>7s} | {'gemm4w ms':>10s} {'TF/s':>7s} | gemm256 / lib   gemm4w / lib")
 for name, M, N, K in shapes:
     if args.zeros:
         a = torch.zeros(M, K, device=dev, dtype=torch.bfloat16)
@@ -77,13 +77,21 @@ for name, M, N, K in shapes:
         rc = lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100)
         assert rc == 0
 
+    def eng4():
+        rc = lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100 | _lib.EPI_TILE4W)
+        assert rc == 0
+
+    has4 = M % 256 == 0 and N % 256 == 0 and K % 128 == 0        # gemm4w's domain (round 6)
     best = {b: 1e9 for b in backends}
-    best_e = 1e9
+    best_e = best_4 = 1e9
     for _ in range(args.rounds):
         for b in backends:
             torch.backends.cuda.preferred_blas_library(b)
             best[b] = min(best[b], timed(lambda: F.linear(a, wl), args.iters))
-        best_e = min(best_e, timed(eng, args.iters))
+        best_e = min(best_e, timed(lambda: (lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100 | _lib.EPI_TILE256)
+                                            if M >= 1024 and K % 128 == 0 else eng()), args.iters))
+        if has4:
+            best_4 = min(best_4, timed(eng4, args.iters))
     # same numbers: the library's output is the check of the engine's (bf16 rounding of an fp32 accumulation either way)
     torch.backends.cuda.preferred_blas_library(backends[0])
     ref = F.linear(a, wl).float()
@@ -91,5 +99,10 @@ for name, M, N, K in shapes:
     err = float((c.float() - ref).norm() / ref.norm().clamp_min(1e-30))
     tf = lambda ms: 2.0 * M * N * K / ms / 1e9  # noqa: E731
     lib_best = min(best.values())
+    if has4:
+        c4 = torch.empty_like(c)
+        rc = lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c4), N, 0, M, N, K, _lib.EPI_TILE4W)
+        assert rc == 0 and torch.equal(c4, c), "gemm4w differs from gemm256"
     print(f"{name:<14s} {M:7d} {N:6d} {K:6d} | " + " ".join(f"{best[b]:13.3f} {tf(best[b]):7.0f}" for b in backends) +
-          f" | {best_e:11.3f} {tf(best_e):7.0f} | x{lib_best / best_e:.3f}   (rel diff of outputs {err:.1e})")
+          f" | {best_e:11.3f} {tf(best_e):7.0f} | " + (f"{best_4:10.3f} {tf(best_4):7.0f}" if has4 else f"{'-':>10s} {'-':>7s}") +
+          f" | x{lib_best / best_e:.3f}   " + (f"x{lib_best / best_4:.3f}" if has4 else "-") + f"   (rel diff of outputs {err:.1e})")

@@ -82,9 +82,13 @@ for data in ("random", "zeros"):
     c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 
     def eng():
-        assert lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100) == 0
+        assert lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100 | _lib.EPI_TILE256) == 0
+
+    def eng4():      # round 6: the 4-wave / AGPR kernel (gemm4w.hip)
+        assert lib.vstar_op_gemm(None, P(a), K, P(w), None, None, N, P(c), N, 0, M, N, K, 0 | 0x100 | _lib.EPI_TILE4W) == 0
 
     tag = os.environ.get("POWER_PROBE_TAG", "")
     arm(f"gemm256{tag:<10s}{data}", eng)
+    arm(f"gemm4w {tag:<10s}{data}", eng4)
     if not tag:
         arm(f"hipBLASLt {data}", lambda: F.linear(a, w))

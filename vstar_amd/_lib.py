@@ -33,7 +33,8 @@ EXPORTS_VQA = [
 F32, F16, BF16 = 0, 1, 2
 MAX_IMAGE_SLOTS = 64
 EPI_NONE, EPI_QUICK_GELU, EPI_GELU, EPI_RELU, EPI_SILU_MUL = range(5)
-EPI_NOSYNC, EPI_TILE128, EPI_TILE256 = 0x100, 0x200, 0x400
+EPI_NOSYNC, EPI_TILE128, EPI_TILE256, EPI_TILE4W = 0x100, 0x200, 0x400, 0x800
+TILE_4W = 2564          # vstar_op_gemm_last_tile() value of the 4-wave / AGPR 256 x 256 kernel
 F_SKIP_OWL, F_DEVICE_INPUTS, F_DEVICE_OUTPUT, F_NO_SYNC, F_INTERNAL_PIXELS, F_SHARE_PREFIX = 1, 2, 4, 8, 16, 32
 
 

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused
 mkdir -p build
 rm -f build/gemm256a.o build/f16_gemm256a.o     # (round-3 experiment, moved to tools/experiments/gemm256a)
 pids=()
-HDRS="common.hpp kernels.hpp gemm_epilogue.hpp engine_base.hpp llm_cached.hpp ../../include/vstar_hip.h ../../include/vstar_vqa.h"
+HDRS="common.hpp kernels.hpp gemm_epilogue.hpp gemm4w_loop.inc engine_base.hpp llm_cached.hpp ../../include/vstar_hip.h ../../include/vstar_vqa.h"
 stale() {  # stale <object> <source>
   [ ! -f "$1" ] && return 0
   [ "$2" -nt "$1" ] && return 0
@@ -16,11 +16,11 @@ stale() {  # stale <object> <source>
   return 1
 }
 # bf16 instantiation: every kernel file + the VSM engine
-for f in gemm gemm256 norm attention elementwise decode quant heads preprocess engine comm; do
+for f in gemm gemm256 gemm4w norm attention elementwise decode quant heads preprocess engine comm; do
   if stale build/$f.o $f.hip; then $HIPCC $FLAGS -c $f.hip -o build/$f.o & pids+=($!); fi
 done
 # fp16 instantiation (-DVSTAR_LP_F16): the dtype-generic kernel files + the VQA-LLM engine
-for f in gemm gemm256 norm attention elementwise decode vqa_engine; do
+for f in gemm gemm256 gemm4w norm attention elementwise decode vqa_engine; do
   [ -f $f.hip ] || continue
   if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
 done

@@ -1441,7 +1441,7 @@ int vstar_op_gemm(void* stream, const uint16_t* A, int64_t lda, const uint16_t* 
   { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   const bool nosync = (epilogue & VSTAR_EPI_NOSYNC) != 0;
   if ((epilogue & VSTAR_EPI_TILE128) && (epilogue & VSTAR_EPI_TILE256)) { tls_error() = "both tile overrides set"; return VSTAR_ERR_INVALID; }
-  p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
+  p.tile_force = (epilogue & VSTAR_EPI_TILE4W) ? GEMM_TILE_4W : (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
   if (p.tile_force == 256 && !gemm256_eligible(p)) {
     tls_error() = "VSTAR_EPI_TILE256: shape outside the 256x256 kernel's domain (M >= 1024, N >= 256, K % 128 == 0)";
     return VSTAR_ERR_INVALID;
@@ -1460,7 +1460,7 @@ int vstar_op_gemm_norm(void* stream, const uint16_t* A, int64_t lda, const uint1
   { const char* e = getenv("VSTAR_GEMM_DEBUG"); p.debug_flags = e ? atoi(e) : 0; }
   if ((epilogue & VSTAR_EPI_TILE128) && (epilogue & VSTAR_EPI_TILE256)) { tls_error() = "both tile overrides set"; return VSTAR_ERR_INVALID; }
   if (sumsq_out && ((epilogue & 0xff) != VSTAR_EPI_NONE || N % 64)) { tls_error() = "sumsq_out: VSTAR_EPI_NONE and N % 64 == 0 only"; return VSTAR_ERR_INVALID; }
-  p.tile_force = (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
+  p.tile_force = (epilogue & VSTAR_EPI_TILE4W) ? GEMM_TILE_4W : (epilogue & VSTAR_EPI_TILE256) ? 256 : (epilogue & VSTAR_EPI_TILE128) ? 128 : 0;
   if (p.tile_force == 256 && !gemm256_eligible(p)) { tls_error() = "VSTAR_EPI_TILE256: shape outside the 256x256 kernel's domain"; return VSTAR_ERR_INVALID; }
   hipError_t e = gemm_lp(p, epilogue & 0xff, false, (hipStream_t)stream);
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);

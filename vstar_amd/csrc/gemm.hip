@@ -344,6 +344,8 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 
 bool gemm256_eligible(const GemmParams& p);
 hipError_t gemm256_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32);      // gemm4w.hip: the 4-wave / AGPR 256^2 kernel
+hipError_t gemm4w_lp(const GemmParams& p, int epilogue, hipStream_t s);
 
 static thread_local int t_last_tile = 0;
 int gemm_last_tile() { return t_last_tile; }
@@ -369,9 +371,22 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15) || (p.lda % 8)) return hipErrorInvalidValue;
   static const int env_force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const int force = p.tile_force ? p.tile_force : env_force;
-  if (force != 0 && force != 128 && force != 256) return hipErrorInvalidValue;
+  if (force != 0 && force != 128 && force != 256 && force != GEMM_TILE_4W) return hipErrorInvalidValue;
   const bool elig = gemm256_eligible(p);
   if (p.tile_force == 256 && !elig) return hipErrorInvalidValue;   // an explicit per-call request must not be silently re-routed
+  // The 4-wave / AGPR kernel (gemm4w.hip): launches made of interior 256^2 tiles with the in-register epilogue.  Same k order and
+  // epilogue arithmetic as gemm256: bit-identical (tests/test_ops_gpu.py::test_gemm4w_equals_gemm256).  tile_force = 256 keeps the
+  // 8-wave kernel (A/B, tests), GEMM_TILE_4W demands this one; VSTAR_GEMM4W=0/1 sets the default for unforced calls.
+  {
+    static const int env4w = [] { const char* e = getenv("VSTAR_GEMM4W"); return e ? atoi(e) : GEMM4W_DEFAULT; }();
+    const bool elig4 = elig && gemm4w_eligible(p, epilogue, out_f32);
+    if (p.tile_force == GEMM_TILE_4W && !elig4) return hipErrorInvalidValue;
+    if (elig4 && (force == GEMM_TILE_4W || (force == 0 && env4w != 0))) {
+      t_last_tile = GEMM_TILE_4W;
+      return gemm4w_lp(p, epilogue, s);
+    }
+    if (force == GEMM_TILE_4W) return hipErrorInvalidValue;      // (environment-forced onto a shape outside the domain)
+  }
   if (force != 128 && elig) {   // W is padded to 256 rows
     // Under-filled grids (small batches: e.g. o_proj at 1280 rows = 80 tiles of 256^2 on 256 CUs): the 128^2 kernel has four
     // times the tiles; one of its tiles takes ~0.36 of a 256^2 tile (1/4 of the work at ~0.7 of the efficiency), so compare

@@ -1,0 +1,406 @@
+// gemm4w.hip — the 256 x 256 x 64 GEMM tile with FOUR waves (one per SIMD), each owning a 128 x 128 output in 256 AGPR
+// accumulators, and a hand-scheduled K loop (tools/gen_gemm4w_asm.py -> gemm4w_loop.inc).  Round 6.
+//
+// Why a second 256^2 kernel.  On real operands the GEMM family runs ON the board's 1400 W cap: throughput is set by
+// energy per FLOP.  The 8-wave gemm256 reads 0.375 fragment ds_read_b128 per MFMA (128 x 64 per wave) and pays four barrier
+// rendezvous per K-tile between two wave groups; this kernel reads 0.25 (128 x 128 per wave), keeps all 512 registers of a SIMD
+// for ONE wave (256 accumulators in AGPRs + two fragment sets), and hides every LDS read, DMA issue and barrier between the
+// MFMAs of that wave.  The structure — 4 waves, AGPR accumulators, LDS-DMA for both operands, the two halves of an LDS buffer
+// released separately so that the DMA of K-tile T+2 starts in the first half of K-tile T — is what the vendor's own
+// 256x256x64 kernel does (facts read from its code object: DESIGN.md §5.1); the code is ours: same LDS image, same DMA
+// addressing, same permuted-W in-register epilogue and same k order as gemm256.hip, hence bit-identical results.
+//
+// Domain (everything else stays on gemm256.hip): bf16 / fp16 operands and output, M % 256 == 0, N % 256 == 0, K % 128 == 0,
+// identity row maps, 16-byte aligned C / residual / bias — i.e. launches made of interior tiles with the direct epilogue;
+// epilogues NONE (+bias, +residual, fused RoPE, folded-norm row scale, sum-of-squares / sum statistics), QUICK_GELU, RELU, SILU_MUL.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "gemm_epilogue.hpp"
+#include <type_traits>
+#include <utility>
+
+#ifdef VSTAR_LP_F16
+#define G4W_DT "f16"
+#else
+#define G4W_DT "bf16"
+#endif
+#ifndef G4W_LOOP_INC        // variant builds (tools/build_variant.sh): another generated schedule
+#define G4W_LOOP_INC "gemm4w_loop.inc"
+#endif
+#include G4W_LOOP_INC
+
+namespace VS_NS {
+
+namespace {
+
+constexpr int BM = 256, BN = 256;
+constexpr int LDS_TOTAL = 2 * 65536;
+
+template <int IDX>
+__device__ __forceinline__ float agpr_read() {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(IDX));
+  return x;
+}
+// fragment (m, n') of the wave's 8 x 8: a[(m * 8 + n') * 4 ..+3] (tools/gen_gemm4w_asm.py::mfma)
+template <int M, int NP>
+__device__ __forceinline__ f32x4 acc_frag() {
+  constexpr int B = (M * 8 + NP) * 4;
+  return (f32x4){agpr_read<B>(), agpr_read<B + 1>(), agpr_read<B + 2>(), agpr_read<B + 3>()};
+}
+// row m of the 128 x 64 half H of the wave's tile, as one row of gemm256's acc[8][4]
+template <int H, int M>
+__device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
+  a[0] = acc_frag<M, H * 4 + 0>();
+  a[1] = acc_frag<M, H * 4 + 1>();
+  a[2] = acc_frag<M, H * 4 + 2>();
+  a[3] = acc_frag<M, H * 4 + 3>();
+}
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
+// The in-register epilogue of ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid: 128 rows x 64 W rows, accumulators in
+// gemm256's layout.  Same arithmetic, rounding points, statistics tree and store pattern as gemm256.hip's direct epilogue (see the
+// comments there: W rows are DMA'd in a permuted order so that a lane's fragments are runs of 8 consecutive output columns).
+// The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes them (16 registers at a time instead of the half's 128).
+template <int EPI, int H>
+__device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
+  float rs_v[8];            // RMSNorm / LayerNorm folded into this linear: rstd[row] * (x . (W * norm_w)^T)
+  if (p.row_scale) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) rs_v[m] = p.row_scale[em0 + wr * 128 + m * 16 + fr];
+  }
+  auto acc_row = [&](auto mc, f32x4 (&a)[4]) {
+    constexpr int m = decltype(mc)::value;
+    load_acc_row<H, m>(a);
+    if (p.row_scale) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[n][e] *= rs_v[m];
+    }
+  };
+  constexpr bool SILU = (EPI == VSTAR_EPI_SILU_MUL);
+  bool rope_tile = false;
+  if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
+  int col_a, col_b;
+  if (SILU) { col_a = (en0 + wc * 64) / 2 + fq * 8; col_b = col_a; }
+  else if (rope_tile) { col_a = en0 + (wc >> 1) * 128 + (wc & 1) * 32 + fq * 8; col_b = col_a + 64; }
+  else { col_a = en0 + wc * 64 + fq * 8; col_b = col_a + 32; }
+  const int row0 = em0 + wr * 128 + fr;
+  lp_t* crow = (lp_t*)p.C + (int64_t)row0 * p.ldc;
+  if constexpr (SILU) {
+    static_for<8>([&](auto mc) {
+      f32x4 a[4];
+      acc_row(mc, a);
+      lpx8 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (short)f2lp(act_silu_bf16(rlp(a[0][e])) * rlp(a[1][e]));
+        v[4 + e] = (short)f2lp(act_silu_bf16(rlp(a[2][e])) * rlp(a[3][e]));
+      }
+      __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
+      crow += 16 * p.ldc;
+    });
+  } else {
+    lpx8 pa[8], pb[8];
+    {
+      float bia[8], bib[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
+      if (p.bias) {
+        const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
+      }
+      static_for<8>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        f32x4 a[4];
+        acc_row(mc, a);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          pa[m][e] = (short)f2lp(a[0][e] + bia[e]);
+          pa[m][4 + e] = (short)f2lp(a[1][e] + bia[4 + e]);
+          pb[m][e] = (short)f2lp(a[2][e] + bib[e]);
+          pb[m][4 + e] = (short)f2lp(a[3][e] + bib[4 + e]);
+        }
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (EPI == VSTAR_EPI_NONE) {
+      if (rope_tile) {
+        const int rope_d = (wc & 1) * 32 + fq * 8;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int row = row0 + m * 16;
+          int pos = row % p.rope_S;
+          if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);
+          if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;
+          const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + rope_d);
+          const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + rope_d);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float c = lp2f((lp_t)c8[e]), sn = lp2f((lp_t)s8[e]);
+            const float xa = lp2f((lp_t)pa[m][e]), xb = lp2f((lp_t)pb[m][e]);
+            pa[m][e] = (short)f2lp(rlp(xa * c) + rlp(-1.0f * xb * sn));
+            pb[m][e] = (short)f2lp(rlp(xb * c) + rlp(1.0f * xa * sn));
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        gemm_epilogue_act8<EPI>(pa[m]);
+        gemm_epilogue_act8<EPI>(pb[m]);
+      }
+    }
+    if (p.res) {
+      __builtin_amdgcn_sched_barrier(0);
+      lpx8 ra[8], rb[8];
+      const lp_t* rrow = p.res + (int64_t)row0 * p.ldr;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        ra[m] = *(const lpx8*)(rrow + col_a);
+        rb[m] = *(const lpx8*)(rrow + col_b);
+        rrow += 16 * p.ldr;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pa[m][e] = (short)f2lp(lp2f((lp_t)pa[m][e]) + lp2f((lp_t)ra[m][e]));
+          pb[m][e] = (short)f2lp(lp2f((lp_t)pb[m][e]) + lp2f((lp_t)rb[m][e]));
+        }
+    }
+    float* sq = nullptr;
+    if constexpr (EPI == VSTAR_EPI_NONE) {
+      if (p.sumsq_out) sq = p.sumsq_out + (int64_t)row0 * p.sumsq_ld + (en0 + wc * 64) / 64;
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (p.sumsq_out) {
+        *(lpx8*)(crow + col_a) = pa[m];
+        *(lpx8*)(crow + col_b) = pb[m];
+      } else {
+        __builtin_nontemporal_store(pa[m], (lpx8*)(crow + col_a));
+        __builtin_nontemporal_store(pb[m], (lpx8*)(crow + col_b));
+      }
+      crow += 16 * p.ldc;
+      if constexpr (EPI == VSTAR_EPI_NONE) {
+        if (sq) {
+          float fa[8], fb[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)pa[m][e]); fb[e] = lp2f((lp_t)pb[m][e]); }
+          float qa = (((fa[0] * fa[0] + fa[1] * fa[1]) + fa[2] * fa[2]) + fa[3] * fa[3]) +
+                     (((fa[4] * fa[4] + fa[5] * fa[5]) + fa[6] * fa[6]) + fa[7] * fa[7]);
+          float qb = (((fb[0] * fb[0] + fb[1] * fb[1]) + fb[2] * fb[2]) + fb[3] * fb[3]) +
+                     (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
+          qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
+          qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
+          if (fq == 0) sq[0] = qa + qb;
+          if (p.stats_sum) {
+            float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
+            float sb = (((fb[0] + fb[1]) + fb[2]) + fb[3]) + (((fb[4] + fb[5]) + fb[6]) + fb[7]);
+            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
+            sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+            if (fq == 0) sq[p.stats_sum] = sa + sb;
+          }
+          sq += 16 * p.sumsq_ld;
+        }
+      }
+    }
+  }
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifndef G4W_PF_LEAD
+#define G4W_PF_LEAD 4      // the L2 prefetch of a K-tile runs this many K-tiles ahead of the tile being computed (its DMA: two ahead)
+#endif
+
+// PF: the loop text with the L2 prefetch duty (long K: the launcher decides)
+template <int EPI, bool PF>
+__global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc2 = wave & 1;
+  const int tiles_m = p.M / BM, tiles_n = p.N / BN;
+  const int nwg = tiles_m * tiles_n;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+  int cur_wkind = -1;
+  uint32_t va[8], vw[8];
+  int m0 = 0, n0 = 0, pi = 0;
+  const lp_t *abase = nullptr, *wbase = nullptr;
+  // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering (gemm256.hip); DMA source offsets of that tile ----
+  auto set_tile = [&](int bid) {
+    int t;
+    {
+      const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 4;
+    const int in_group = GROUP_M * tiles_n;
+    const int grp = t / in_group;
+    const int first_m = grp * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int rem = t - grp * in_group;
+    pi = rem % gsz;
+    m0 = (first_m + pi) * BM;
+    n0 = (rem / gsz) * BN;
+    bool rope_t = false;
+    if constexpr (EPI == VSTAR_EPI_NONE) rope_t = p.rope_cs != nullptr && n0 < p.rope_cols;
+    const int wkind = (EPI != VSTAR_EPI_SILU_MUL && rope_t) ? 2 : 1;
+    // wave w moves the 8-row pieces g = 8 w + i of the A tile and of the W tile; the per-lane part of a source offset does not
+    // depend on the tile (the scalar bases carry it), only on the W row order of the tile's kind
+    if (wkind != cur_wkind) {
+      cur_wkind = wkind;
+      const int st_r = lane >> 3, st_c = lane & 7;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (wave * 8 + i) * 8 + st_r;
+        const int cg = st_c ^ ((row >> 1) & 7);
+        va[i] = (uint32_t)((int64_t)row * p.lda * 2 + cg * 16);
+        const int wcr = row >> 6, n = (row >> 4) & 3, ii = row & 15;
+        int wrow;
+        if (EPI == VSTAR_EPI_SILU_MUL) {
+          const int jo = (ii >> 2) * 8 + (n >> 1) * 4 + (ii & 3);
+          wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);
+        } else if (wkind == 2) {
+          wrow = (wcr >> 1) * 128 + (n >> 1) * 64 + (wcr & 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
+        } else {
+          wrow = wcr * 64 + (n >> 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
+        }
+        vw[i] = (uint32_t)((int64_t)wrow * p.K * 2 + cg * 16);
+      }
+    }
+    abase = p.A + (int64_t)m0 * p.lda;
+    wbase = p.W + (int64_t)n0 * p.K;
+  };
+  // K-tiles 0 and 1 of the current tile -> LDS buffers 0 and 1 (32 DMA pieces per wave); the loop text starts behind a vmcnt(0)
+  auto issue_head = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)abase + va[i] + t * 128), (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)wbase + vw[i] + t * 128), (lptr_t)(smem + t * 65536 + 32768 + wave * 8192 + i * 1024), 16, 0, 0);
+    }
+  };
+  int bid = blockIdx.x;
+  if (bid >= nwg) return;
+  set_tile(bid);
+  issue_head();
+  for (;;) {
+    // ---- fragment read addresses (buffer 0): row-major 128-B rows, chunk ^ ((row >> 1) & 7) ----
+    uint32_t rd[4];
+    {
+      const int fr = lane & 15, fq = lane >> 4;
+      const int swz = (fr >> 1) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ch = ((kk * 4 + fq) ^ swz) * 16;
+        rd[kk] = lds0 + (wr * 128 + fr) * 128 + ch;
+        rd[2 + kk] = lds0 + 32768 + (wc2 * 128 + fr) * 128 + ch;
+      }
+    }
+    // ---- L2 prefetch duty of this CU (tools/gen_gemm4w_asm.py::prefetch_ops): the 32 CUs of an XCD work on a patch of GROUP_M x 8
+    // tiles; of the A row-tile's 256 lines per K-tile this CU touches the 32 of its patch column, of the W column-tile's 256 lines
+    // the 64 of its patch row.  A wrong guess of the patch position (ragged groups, drifted workgroups) costs speed, never results.
+    const int pj = ((bid >> 3) >> 2) & 7;
+    const uint32_t kb_last = (uint32_t)(p.K - 64) * 2;
+    const uint32_t pf_lead = (uint32_t)G4W_PF_LEAD * 128 < kb_last ? (uint32_t)G4W_PF_LEAD * 128 : kb_last;
+    const uint32_t pfa0 = (uint32_t)((int64_t)(pj * 32 + wave * 8 + (lane & 7)) * p.lda * 2);
+    const uint32_t pfw0 = (uint32_t)((int64_t)((pi & 3) * 64 + wave * 16 + (lane & 15)) * p.K * 2);
+    const uint32_t pfa = pfa0 + pf_lead, pfw = pfw0 + pf_lead, pfamax = pfa0 + kb_last, pfwmax = pfw0 + kb_last;
+    uint32_t cnt = (uint32_t)(p.K / 128 - 1);          // two K-tiles per loop iteration, the last pair is peeled
+#define G4W_OPERANDS                                                                                                                 \
+    : [cnt] "+s"(cnt)                                                                                                                \
+    : [abase] "s"(abase), [wbase] "s"(wbase), [ldsw] "s"(ldsw), [rd0] "v"(rd[0]), [rd1] "v"(rd[1]), [rd2] "v"(rd[2]),                \
+      [rd3] "v"(rd[3]), [va0] "v"(va[0] + 256), [va1] "v"(va[1] + 256), [va2] "v"(va[2] + 256), [va3] "v"(va[3] + 256),            \
+      [va4] "v"(va[4] + 256), [va5] "v"(va[5] + 256), [va6] "v"(va[6] + 256), [va7] "v"(va[7] + 256), [vw0] "v"(vw[0] + 256),      \
+      [vw1] "v"(vw[1] + 256), [vw2] "v"(vw[2] + 256), [vw3] "v"(vw[3] + 256), [vw4] "v"(vw[4] + 256), [vw5] "v"(vw[5] + 256),      \
+      [vw6] "v"(vw[6] + 256), [vw7] "v"(vw[7] + 256), [pfa] "v"(pfa), [pfw] "v"(pfw), [pfamax] "v"(pfamax), [pfwmax] "v"(pfwmax)   \
+    : GEMM4W_CLOBBERS
+    if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_PF G4W_OPERANDS);
+    else asm volatile(GEMM4W_LOOP_ASM G4W_OPERANDS);
+#undef G4W_OPERANDS
+    // ---- next tile: its K-tiles 0 and 1 go into the (dead: the loop text ends behind a barrier) LDS buffers NOW, so that the
+    // pipeline fill overlaps this tile's epilogue; this tile's coordinates stay in em0 / en0 ----
+    const int em0 = m0, en0 = n0;
+    bid += gridDim.x;
+    const bool has_next = bid < nwg;
+    if (has_next) {
+      set_tile(bid);
+      issue_head();
+    }
+    // ---- epilogue: the wave's 128 x 128 as the two virtual waves (wr, 2 wc2) and (wr, 2 wc2 + 1) of gemm256's grid ----
+    if (!(p.debug_flags & 2)) {
+      const int fr = lane & 15, fq = lane >> 4;
+      direct_epilogue_half<EPI, 0>(p, em0, en0, wr, wc2 * 2, fr, fq);
+      direct_epilogue_half<EPI, 1>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
+    }
+    if (!has_next) break;
+  }
+}
+
+template <int EPI, bool PF>
+hipError_t launch(const GemmParams& p, hipStream_t s) {
+  if (gemm_plan_only()) return hipSuccess;
+  static bool attr_done = false;
+  auto kern = gemm4w_kernel<EPI, PF>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int n_cu = gemm_device_cus();
+  const int tiles = (p.M / BM) * (p.N / BN);
+  hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(256), LDS_TOTAL, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// Launches made of interior tiles that take gemm256's direct epilogue (see the header comment for the domain).
+bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
+  if (out_f32 || p.a_scale || p.norm_w) return false;
+  if (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_QUICK_GELU && epilogue != VSTAR_EPI_RELU && epilogue != VSTAR_EPI_SILU_MUL) return false;
+  if (p.M < 1024 || p.M % BM || p.N % BN || p.K % 128 || p.K < 128) return false;
+  if (p.a_group > 0 || p.c_group > 0 || (p.debug_flags & 5)) return false;
+  if (((uintptr_t)p.C & 15) || (p.ldc % 8)) return false;
+  if (p.res && (epilogue == VSTAR_EPI_SILU_MUL || ((uintptr_t)p.res & 15) || (p.ldr % 8))) return false;
+  if (p.bias && ((uintptr_t)p.bias & 15)) return false;
+  if (p.sumsq_out && epilogue != VSTAR_EPI_NONE) return false;
+  if ((int64_t)255 * p.lda * 2 + (int64_t)p.K * 2 >= (1ll << 31) || (int64_t)256 * p.K * 2 >= (1ll << 31)) return false;
+  return true;
+}
+
+hipError_t gemm4w_lp(const GemmParams& p, int epilogue, hipStream_t s) {
+  // L2 prefetch duty: measured on the MI355X (profiles/r06_gemm4w_ab.txt) it gains 4 - 15 % with the clock unconstrained (zero
+  // operands) but, on real operands under the 1400 W cap, only where the stalls it removes are long — K = 11008 (down_proj: an A
+  // operand of 451 MB, past the Infinity Cache) +2 - 5 %, K = 4096 -1 - 2 % (its extra requests cost more energy than the shorter
+  // stalls return).  VSTAR_GEMM4W_PF = 0 / 1 forces it off / on (A/B runs).
+  static const int env_pf = [] { const char* e = getenv("VSTAR_GEMM4W_PF"); return e ? atoi(e) : -1; }();
+  const bool pf = env_pf >= 0 ? env_pf != 0 : p.K >= 8192;
+#define G4W_CASE(E) case E: return pf ? launch<E, true>(p, s) : launch<E, false>(p, s);
+  switch (epilogue) {
+    G4W_CASE(VSTAR_EPI_NONE)
+    G4W_CASE(VSTAR_EPI_QUICK_GELU)
+    G4W_CASE(VSTAR_EPI_RELU)
+    G4W_CASE(VSTAR_EPI_SILU_MUL)
+  }
+#undef G4W_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace VS_NS

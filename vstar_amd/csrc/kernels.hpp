@@ -56,6 +56,12 @@ struct GemmParams {
   const lp_t* W_tiled;
 };
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
+// GemmParams::tile_force / gemm_last_tile() value of the 4-wave / AGPR 256 x 256 kernel (gemm4w.hip; "256, 4 waves")
+constexpr int GEMM_TILE_4W = 2564;
+// whether unforced calls inside gemm4w's domain take it (VSTAR_GEMM4W overrides)
+#ifndef GEMM4W_DEFAULT
+#define GEMM4W_DEFAULT 1
+#endif
 // which kernel the last gemm_lp call of THIS thread launched: 128, 256, or 0 when nothing was launched (observability for the
 // op-level tests: a dispatcher change must not silently move a test onto the other kernel)
 int gemm_last_tile();
