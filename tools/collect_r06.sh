@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round-6 evidence: tools/collect_r06.sh [stats|full]  ->  gpurun_out/r06f/  (summaries only; raw rocprofv3 databases stay in /tmp)
+# Every summary is stamped with the hash compiled into the library the profiled command loaded (vstar_amd/provenance.py::checked_hash).
+R=$(pwd); OUT=$R/gpurun_out/r06f; RAW=/tmp/prof_r06f
+mkdir -p $OUT $RAW
+B="python $R/bench.py --no-cpu-baseline --no-search-leg --no-small-batch --no-config5-line --no-stream-leg --no-power-sample"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $RAW/stats -o k -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+if [ "$1" != "stats" ]; then
+for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m"; do
+  n=${c##*:}; ctr=${c%%:*}
+  rocprofv3 --pmc $ctr --kernel-trace -d $RAW/pmc_$n -o pmc -- $B --steps 1 --warmup 0 > /dev/null 2>&1 || echo "pass $n failed"
+done
+fi
+cd $R
+python tools/rocpd_summary.py $(ls $RAW/stats/*/k_results.db $RAW/stats/k_results.db 2>/dev/null | head -1) > $OUT/kernel_stats.csv
+if [ "$1" != "stats" ]; then
+  f() { ls $RAW/pmc_$1/*/pmc_results.db $RAW/pmc_$1/pmc_results.db 2>/dev/null | head -1; }
+  python tools/pmc_summary.py $(f f) $(f w) $(f m) > $OUT/pmc.json
+  cp $OUT/pmc.json profiles/r06_pmc_final.json      # (on the box: so that the bench line below quotes THIS build's traffic figure)
+  python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+  python -c "
+import json; d=json.load(open('$OUT/bench.json')); r=d['roofline']
+print('bench', d['value'], d['ms_per_step'], r['frac'], r.get('under_load'), 'traffic', r['traffic'], r['kernel_source_hash'])"
+fi
+head -30 $OUT/kernel_stats.csv | cut -c1-180

@@ -23,6 +23,8 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--epilogues", action="store_true")
 ap.add_argument("--zeros", action="store_true")
+ap.add_argument("--vit", action="store_true", help="the ViT shapes of the bench batch with M rounded down to whole 256-row tiles (gemm4w domain)")
+ap.add_argument("--lda-pad", type=int, default=0, help="A rows padded by this many elements (row stride not a power of two)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 base = _lib.load()
@@ -37,6 +39,11 @@ P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: 
 M = args.batch * 640
 shapes = [("qkv", M, 12288, 4096, 0, 0), ("o", M, 4096, 4096, 0, 0), ("gate|up", M, 22016, 4096, 0, 0), ("down", M, 4096, 11008, 0, 0),
           ("square8k", 8192, 8192, 8192, 0, 0)]
+if args.vit:
+    Mc, Mo = 18464 // 256 * 256, 73760 // 256 * 256
+    shapes = [("clip qkv", Mc, 3072, 1024, 0, 0), ("clip out+res", Mc, 1024, 1024, 0, 1), ("clip fc1 qgelu", Mc, 4096, 1024, 1, 0),
+              ("clip fc2+res", Mc, 1024, 4096, 0, 1), ("owl qkv", Mo, 2304, 768, 0, 0), ("owl out+res", Mo, 768, 768, 0, 1),
+              ("owl fc1 qgelu", Mo, 3072, 768, 1, 0), ("owl fc2+res", Mo, 768, 3072, 0, 1)]
 if args.epilogues:
     shapes += [("o+res", M, 4096, 4096, 0, 1), ("gate|up silu", M, 22016, 4096, 4, 0), ("down+res", M, 4096, 11008, 0, 1)]
 
@@ -61,11 +68,12 @@ torch.backends.cuda.preferred_blas_library("hipblaslt")
 for name, Mm, N, K, epi, has_res in shapes:
     n_out = N // 2 if epi == 4 else N
     if args.zeros:
-        a = torch.zeros(Mm, K, device=dev, dtype=torch.bfloat16)
+        a = torch.zeros(Mm, K + args.lda_pad, device=dev, dtype=torch.bfloat16)[:, :K]
         w = torch.zeros(N, K, device=dev, dtype=torch.bfloat16)
     else:
-        a = torch.randn(Mm, K, device=dev).bfloat16()
+        a = torch.randn(Mm, K + args.lda_pad, device=dev).bfloat16()[:, :K]
         w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    lda = K + args.lda_pad
     res = torch.randn(Mm, n_out, device=dev).bfloat16() if has_res else None
     c = torch.empty(Mm, n_out, device=dev, dtype=torch.bfloat16)
     fns = {}
@@ -74,7 +82,7 @@ for name, Mm, N, K, epi, has_res in shapes:
     for ln, L in libs:
         for k, flag in (("256", _lib.EPI_TILE256), ("4w", _lib.EPI_TILE4W)):
             def f(L=L, flag=flag):
-                rc = L.vstar_op_gemm(None, P(a), K, P(w), None, P(res), n_out, P(c), n_out, 0, Mm, N, K, epi | 0x100 | flag)
+                rc = L.vstar_op_gemm(None, P(a), lda, P(w), None, P(res), n_out, P(c), n_out, 0, Mm, N, K, epi | 0x100 | flag)
                 assert rc == 0, rc
             fns[f"{ln}:{k}"] = f
     best = {k: 1e9 for k in fns}

@@ -26,10 +26,10 @@ object — structure studied, no code taken):
 Accumulation order per output element: k ascending, 32 per MFMA — the order of every other GEMM kernel of the library, hence
 bit-identical results (tests/test_ops_gpu.py::test_gemm4w_equals_gemm256).
 
-Operands of the asm statement (gemm4w.hip): %[abase] / %[wbase] uniform 64-bit base pointers (SGPR pairs) of this tile's A rows /
-W rows at k = 0, %[ldsw] LDS byte address of this wave's first A piece in buffer 0, %[cnt] = nkt / 2 - 1 loop iterations (nkt
+Operands of the asm statement (gemm4w.hip): %[srda] / %[srdw] buffer resource descriptors (4 SGPRs each) over this tile's A rows /
+W rows at k = 0, %[koff] the byte offset of the K-tile whose DMA is issued next (starts at 256: K-tile 2), %[ldsw] LDS byte address of this wave's first A piece in buffer 0, %[cnt] = nkt / 2 - 1 loop iterations (nkt
 even, >= 2), %[rd0..3] LDS read addresses (A k-half 0 / 1, W k-half 0 / 1) in buffer 0, %[va0..7] / %[vw0..7] per-lane global
-byte offsets of the wave's 8 A / 8 W pieces AT K-TILE 2: K-tiles 0 and 1 are DMA'd by the caller (gemm4w.hip issues them before the
+byte offsets of the wave's 8 A / 8 W pieces at k = 0 (constant): K-tiles 0 and 1 are DMA'd by the caller (gemm4w.hip issues them before the
 previous output tile's epilogue, so the pipeline fill overlaps its stores), %[pfa] / %[pfw] / %[pfamax] / %[pfwmax] the L2
 prefetch offsets and their clamps.
 """
@@ -61,15 +61,20 @@ def rd_w(buf, kk, s):
     return [f"ds_read_b128 v[{SET[s] + 32 + n * 4}:{SET[s] + 32 + n * 4 + 3}], v{RD + buf * 4 + 2 + kk} offset:{n * 2048}" for n in range(8)]
 
 
+CPOL = os.environ.get("G4W_CPOL", "")          # cache-policy bits of the DMA loads (experiments: "nt", "sc1", "sc0 sc1")
+
+
 def dma_a(buf):
-    """8 x [m0 write, load, K advance of the piece's offset]"""
-    return [[f"s_add_u32 m0, %[ldsw], {buf * BUF + i * 1024}", f"global_load_lds_dwordx4 v{VOFF_A + i}, %[abase]",
-             f"v_add_u32 v{VOFF_A + i}, 128, v{VOFF_A + i}"] for i in range(8)]
+    """8 x [m0 write, load, (nothing)].  Buffer loads through a resource descriptor: the piece's per-lane offset VGPR is CONSTANT, the K
+    advance is ONE scalar (%[koff], += 128 once per K-tile, see tile()) shared by all sixteen pieces — no VALU write to a register
+    a load in flight still reads, sixteen instructions less per K-tile (the vendor's form)."""
+    return [[f"s_add_u32 m0, %[ldsw], {buf * BUF + i * 1024}", f"buffer_load_dwordx4 v{VOFF_A + i}, %[srda], %[koff] offen lds {CPOL}".rstrip(),
+             None] for i in range(8)]
 
 
 def dma_w(buf):
-    return [[f"s_add_u32 m0, %[ldsw], {buf * BUF + W_REGION + i * 1024}", f"global_load_lds_dwordx4 v{VOFF_W + i}, %[wbase]",
-             f"v_add_u32 v{VOFF_W + i}, 128, v{VOFF_W + i}"] for i in range(8)]
+    return [[f"s_add_u32 m0, %[ldsw], {buf * BUF + W_REGION + i * 1024}", f"buffer_load_dwordx4 v{VOFF_W + i}, %[srdw], %[koff] offen lds {CPOL}".rstrip(),
+             None] for i in range(8)]
 
 
 def place_dma(slots, groups, positions):
@@ -77,7 +82,8 @@ def place_dma(slots, groups, positions):
     for g, pos in zip(groups, positions):
         slots[pos - 1].append(g[0])
         slots[pos].append(g[1])
-        slots[pos + 1].append(g[2])
+        if g[2]:
+            slots[pos + 1].append(g[2])
 
 
 PF_DST, PF_OFF, PF_MAX = 152, 154, 156      # v152/v153 dead destinations, v154/v155 offsets, v156/v157 their clamps (last K-tile)
@@ -88,7 +94,7 @@ def prefetch_ops():
     (4) ask for the same lines at the same moment, so ALL of them wait for the one fill from the fabric.  Each sharer touches its
     share of the lines of K-tile T + lead early — one plain dword load per wave and operand into a dead register — and the DMAs
     find them in L2.  Offsets advance one K-tile per tile, clamped to the last K-tile."""
-    return [f"global_load_dword v{PF_DST}, v{PF_OFF}, %[abase]", f"global_load_dword v{PF_DST + 1}, v{PF_OFF + 1}, %[wbase]",
+    return [f"buffer_load_dword v{PF_DST}, v{PF_OFF}, %[srda], 0 offen", f"buffer_load_dword v{PF_DST + 1}, v{PF_OFF + 1}, %[srdw], 0 offen",
             f"v_add_u32 v{PF_OFF}, 128, v{PF_OFF}", f"v_add_u32 v{PF_OFF + 1}, 128, v{PF_OFF + 1}",
             f"v_min_u32 v{PF_OFF}, v{PF_OFF}, v{PF_MAX}", f"v_min_u32 v{PF_OFF + 1}, v{PF_OFF + 1}, v{PF_MAX + 1}"]
 
@@ -109,6 +115,7 @@ def tile(buf, next_tile, next2, shape, last=False):
         slots[shape["b2"] - 1].append("s_waitcnt lgkmcnt(0)")
         slots[shape["b2"]].append("s_barrier")
         place_dma(slots, dma_w(buf), shape["dw"])
+        slots[max(shape["dw"]) + 2 if max(shape["dw"]) + 2 < 128 else 127].append("s_add_u32 %[koff], %[koff], 128")      # >= 5 wait states before the next piece reads it
     # set 1 must be complete before MFMA 64 (with next2 the B2 wait already covers it; keep the wait for the tail tiles)
     slots[63].append("s_waitcnt lgkmcnt(0)")
     if last:
@@ -192,17 +199,29 @@ def loop_text(shape, use_pf):
     L += rd_a(0, 0, 0) + rd_w(0, 0, 0)
     L += ["s_waitcnt lgkmcnt(0)"]
     # ---- main loop: two K-tiles per iteration; %[cnt] = nkt / 2 - 1 (may be 0) ----
-    L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%=", ".Lg4w_loop_%=:"]
+    L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%="]
+    stagger = int(os.environ.get("G4W_STAGGER", "0"))
+    if stagger:
+        # SIMD-pair stagger (the vendor kernel does the same): waves on SIMD 1 / 3 run a loop body whose DMA pieces
+        # sit `stagger` MFMAs later, so the two halves of the CU do not hand their requests to the texture path in the same cycle
+        sb = dict(shape, da=[x + stagger for x in shape["da"]], dw=[x + stagger for x in shape["dw"]])
+        L += ["s_getreg_b32 m0, hwreg(HW_REG_HW_ID, 4, 1)", "s_cmp_eq_u32 m0, 0", "s_cbranch_scc0 .Lg4w_loopb_%="]
+    L += [".Lg4w_loop_%=:"]
     L += tile(0, True, True, shape) + tile(1, True, True, shape)
-    L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%=", ".Lg4w_tail_%=:"]
+    L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%="]
+    if stagger:
+        L += ["s_branch .Lg4w_tail_%=", ".Lg4w_loopb_%=:"]
+        L += tile(0, True, True, sb) + tile(1, True, True, sb)
+        L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loopb_%="]
+    L += [".Lg4w_tail_%=:"]
     L += tile(0, True, False, shape) + tile(1, False, False, shape, last=True)
     L += ["s_nop 15", "s_nop 15"]              # the last MFMA results settle before the epilogue's v_accvgpr_read
     no_bar, no_kadv = os.environ.get("G4W_NO_BAR") == "1", os.environ.get("G4W_NO_KADV") == "1"
     if no_dma or no_reads or no_bar or no_kadv:  # ablation builds: timing / power only, results are garbage
-        i0 = L.index(".Lg4w_loop_%=:")
-        L = L[:i0] + [x for x in L[i0:] if not (no_dma and ("global_load_lds" in x or "s_add_u32 m0" in x or "v_add_u32 v1" in x)) and
+        i0 = L.index(".Lg4w_tail_%=:") if False else min(i for i, x in enumerate(L) if x.startswith(".Lg4w_loop"))
+        L = L[:i0] + [x for x in L[i0:] if not (no_dma and ("buffer_load_dwordx4" in x or "s_add_u32 m0" in x)) and
                       not (no_reads and x.startswith("ds_read")) and not (no_bar and x == "s_barrier") and
-                      not (no_kadv and x.startswith("v_add_u32 v1") and ", 128," in x)]
+                      not (no_kadv and x.startswith("s_add_u32 %[koff]"))]
     return L
 
 

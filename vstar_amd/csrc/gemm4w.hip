@@ -101,7 +101,11 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
         v[e] = (short)f2lp(act_silu_bf16(rlp(a[0][e])) * rlp(a[1][e]));
         v[4 + e] = (short)f2lp(act_silu_bf16(rlp(a[2][e])) * rlp(a[3][e]));
       }
+#ifdef G4W_ABL_NOSTORE
+      asm volatile("" :: "v"(v));
+#else
       __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
+#endif
       crow += 16 * p.ldc;
     });
   } else {
@@ -182,13 +186,21 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       __builtin_amdgcn_sched_barrier(0);
+#ifdef G4W_ABL_NOSTORE
+      asm volatile("" :: "v"(pa[m]), "v"(pb[m]));
+#else
+#ifdef G4W_PLAIN_STORES
+      if (true) {
+#else
       if (p.sumsq_out) {
+#endif
         *(lpx8*)(crow + col_a) = pa[m];
         *(lpx8*)(crow + col_b) = pb[m];
       } else {
         __builtin_nontemporal_store(pa[m], (lpx8*)(crow + col_a));
         __builtin_nontemporal_store(pb[m], (lpx8*)(crow + col_b));
       }
+#endif
       crow += 16 * p.ldc;
       if constexpr (EPI == VSTAR_EPI_NONE) {
         if (sq) {
@@ -323,13 +335,18 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     const uint32_t pfw0 = (uint32_t)((int64_t)((pi & 3) * 64 + wave * 16 + (lane & 15)) * p.K * 2);
     const uint32_t pfa = pfa0 + pf_lead, pfw = pfw0 + pf_lead, pfamax = pfa0 + kb_last, pfwmax = pfw0 + kb_last;
     uint32_t cnt = (uint32_t)(p.K / 128 - 1);          // two K-tiles per loop iteration, the last pair is peeled
+    // buffer resource descriptors over the tile's rows (raw buffer: stride 0, no bound in practice, dword 3 = the gfx9 raw-buffer word)
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    const i32x4 srda = {(int)(uint32_t)(uintptr_t)abase, (int)(((uintptr_t)abase >> 32) & 0xffff), -1, 0x00020000};
+    const i32x4 srdw = {(int)(uint32_t)(uintptr_t)wbase, (int)(((uintptr_t)wbase >> 32) & 0xffff), -1, 0x00020000};
+    uint32_t koff = 256;                               // K-tiles 0 and 1 are in flight (issue_head): the loop's first pieces are K-tile 2
 #define G4W_OPERANDS                                                                                                                 \
-    : [cnt] "+s"(cnt)                                                                                                                \
-    : [abase] "s"(abase), [wbase] "s"(wbase), [ldsw] "s"(ldsw), [rd0] "v"(rd[0]), [rd1] "v"(rd[1]), [rd2] "v"(rd[2]),                \
-      [rd3] "v"(rd[3]), [va0] "v"(va[0] + 256), [va1] "v"(va[1] + 256), [va2] "v"(va[2] + 256), [va3] "v"(va[3] + 256),            \
-      [va4] "v"(va[4] + 256), [va5] "v"(va[5] + 256), [va6] "v"(va[6] + 256), [va7] "v"(va[7] + 256), [vw0] "v"(vw[0] + 256),      \
-      [vw1] "v"(vw[1] + 256), [vw2] "v"(vw[2] + 256), [vw3] "v"(vw[3] + 256), [vw4] "v"(vw[4] + 256), [vw5] "v"(vw[5] + 256),      \
-      [vw6] "v"(vw[6] + 256), [vw7] "v"(vw[7] + 256), [pfa] "v"(pfa), [pfw] "v"(pfw), [pfamax] "v"(pfamax), [pfwmax] "v"(pfwmax)   \
+    : [cnt] "+s"(cnt), [koff] "+s"(koff)                                                                                             \
+    : [srda] "s"(srda), [srdw] "s"(srdw), [ldsw] "s"(ldsw), [rd0] "v"(rd[0]), [rd1] "v"(rd[1]), [rd2] "v"(rd[2]),                    \
+      [rd3] "v"(rd[3]), [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]),                                    \
+      [va4] "v"(va[4]), [va5] "v"(va[5]), [va6] "v"(va[6]), [va7] "v"(va[7]), [vw0] "v"(vw[0]),                                    \
+      [vw1] "v"(vw[1]), [vw2] "v"(vw[2]), [vw3] "v"(vw[3]), [vw4] "v"(vw[4]), [vw5] "v"(vw[5]),                                    \
+      [vw6] "v"(vw[6]), [vw7] "v"(vw[7]), [pfa] "v"(pfa), [pfw] "v"(pfw), [pfamax] "v"(pfamax), [pfwmax] "v"(pfwmax)               \
     : GEMM4W_CLOBBERS
     if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_PF G4W_OPERANDS);
     else asm volatile(GEMM4W_LOOP_ASM G4W_OPERANDS);
@@ -344,7 +361,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       issue_head();
     }
     // ---- epilogue: the wave's 128 x 128 as the two virtual waves (wr, 2 wc2) and (wr, 2 wc2 + 1) of gemm256's grid ----
+#ifdef G4W_ABL_NOEPI      // ablation build (timing only): what the whole epilogue costs
+    if (false) {
+#else
     if (!(p.debug_flags & 2)) {
+#endif
       const int fr = lane & 15, fq = lane >> 4;
       direct_epilogue_half<EPI, 0>(p, em0, en0, wr, wc2 * 2, fr, fq);
       direct_epilogue_half<EPI, 1>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
