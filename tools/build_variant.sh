@@ -11,6 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused
 mkdir -p build/ab/$NAME
 OBJS=$(ls build/*.o)
 for f in $FILES; do
+  [ "$f" = gemm4w ] && EXTRA="$EXTRA -mllvm -amdgpu-spill-vgpr-to-agpr=0"      # see build.sh
   $HIPCC $FLAGS $EXTRA -c $f.hip -o build/ab/$NAME/$f.o &
   if [ -f build/f16_$f.o ]; then $HIPCC $FLAGS $EXTRA -DVSTAR_LP_F16 -c $f.hip -o build/ab/$NAME/f16_$f.o & fi
   OBJS=$(echo "$OBJS" | grep -v "build/$f.o" | grep -v "build/f16_$f.o")

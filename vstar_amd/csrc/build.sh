@@ -16,13 +16,16 @@ stale() {  # stale <object> <source>
   return 1
 }
 # bf16 instantiation: every kernel file + the VSM engine
+# gemm4w keeps its 256 accumulators in AGPRs BEHIND the compiler's back (they are clobbers of the K-loop asm statement, read back by
+# v_accvgpr_read statements in the epilogue): the compiler must never use AGPRs as VGPR spill space there — it did (a2..a9, round 6)
+extra() { [ "$1" = gemm4w ] && echo "-mllvm -amdgpu-spill-vgpr-to-agpr=0"; }
 for f in gemm gemm256 gemm4w norm attention elementwise decode quant heads preprocess engine comm; do
-  if stale build/$f.o $f.hip; then $HIPCC $FLAGS -c $f.hip -o build/$f.o & pids+=($!); fi
+  if stale build/$f.o $f.hip; then $HIPCC $FLAGS $(extra $f) -c $f.hip -o build/$f.o & pids+=($!); fi
 done
 # fp16 instantiation (-DVSTAR_LP_F16): the dtype-generic kernel files + the VQA-LLM engine
 for f in gemm gemm256 gemm4w norm attention elementwise decode vqa_engine; do
   [ -f $f.hip ] || continue
-  if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
+  if stale build/f16_$f.o $f.hip; then $HIPCC $FLAGS $(extra $f) -DVSTAR_LP_F16 -c $f.hip -o build/f16_$f.o & pids+=($!); fi
 done
 # the hash of the kernel sources THIS binary is built from (vstar_amd/provenance.py::kernel_source_hash, same algorithm), compiled
 # into the library and exported as vstar_build_source_hash(): evidence files are stamped with the LOADED library's value, so a
