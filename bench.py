@@ -198,7 +198,7 @@ def stream_leg(eng, cfg, args, world: int, rank: int, shard: str = "crops", grou
         warnings.simplefilter("ignore")
         vsm = VSM(None, engine=eng, tokenizer=SyntheticTokenizer(cfg.llm_vocab), strict_template=_strict(args))
         vsm.shard_crops = (shard == "crops") and (world > 1 or bool(getattr(args, "rccl_selfcheck", False)))
-        if vsm.shard_crops and world > 1 and getattr(args, "engine_comm", False) and on_gpu:
+        if vsm.shard_crops and world > 1 and getattr(args, "engine_comm", "auto") != "off" and on_gpu:
             from vstar_amd.dist import maybe_engine_comm
             maybe_engine_comm(vsm)
         vsm.group_prompts = group_prompts             # False = plain batches: records bit-identical to the per-sample loop
@@ -434,8 +434,10 @@ def main():
                          "massive-activation BOS, spread norm gains, peaked attention, and a greedy decode that emits the answer template, "
                          "so the search legs run the default strict_template=True path; same step time as random weights, measured) or "
                          "the i.i.d. random set of rounds 1-3")
-    ap.add_argument("--engine-comm", action="store_true", help="N > 1: the crop-sharded stream leg gathers its records with the C-ABI's own "
-                    "RCCL communicator (vstar_allgather_results on the engine stream) instead of torch.distributed (EXPERIMENTAL)")
+    ap.add_argument("--engine-comm", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: the crop-sharded stream leg gathers its records with the C-ABI's own RCCL communicator "
+                    "(vstar_allgather_results on the engine stream); auto (default, round 6) = when its self-check against "
+                    "torch.distributed passes on every rank, else torch.distributed; off = torch.distributed")
     ap.add_argument("--fp8", action="store_true", help="BASELINE config 5 precision: LLaMA linears W8A8 on the fp8 MFMA "
                     "(separate line; the headline metric is the default bf16 run)")
     args = ap.parse_args()

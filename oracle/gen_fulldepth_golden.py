@@ -109,6 +109,8 @@ def main():
                          "answer template for SyntheticTokenizer prompts; written to full7b_tl_{336,224}.npz")
     ap.add_argument("--out", type=str, default=None, help="output file name under tests/golden/ (round 5: the 32-crop noise study "
                     "full7b_tl_336_x32.npz = every crop of the bench batch, recorded with --crops all --mask-f16)")
+    ap.add_argument("--input-rank", type=int, default=0, help="round 6: bench_inputs(rank=...) = the seed of the synthetic crop batch; rank 1 is the "
+                    "second 32-crop fixture full7b_tl_336_x32_r1.npz (VERDICT r5 item 9: settle the sign of the mask-offset mean over 64 crops)")
     ap.add_argument("--mask-f16", action="store_true", help="store the 192 x 192 masks as float16 (5e-4 relative, two orders below "
                     "the bf16 noise they are compared with): halves the file")
     a = ap.parse_args()
@@ -121,7 +123,7 @@ def main():
     torch.set_num_threads(a.threads)
     cfg = VSMConfig.seal_7b(a.image_size, max_batch=B, max_text_len=T + 1)
     loc_id = cfg.llm_vocab - 1
-    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
+    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T, rank=a.input_rank)
     t0 = time.time()
     if tl:
         from vstar_amd.preprocess import SyntheticTokenizer
@@ -142,7 +144,7 @@ def main():
     if a.mask_f16:
         f32["low_res_masks"] = f32["low_res_masks"].astype(np.float16)
         b16["low_res_masks"] = b16["low_res_masks"].astype(np.float16)
-    np.savez_compressed(out_path, crops=np.asarray(crops), batch=B, text_tokens=T, weight_seed=0, image_size=a.image_size,
+    np.savez_compressed(out_path, crops=np.asarray(crops), batch=B, text_tokens=T, weight_seed=0, image_size=a.image_size, input_rank=a.input_rank,
                         weights=a.weights,
                         **{k: v for k, v in f32.items()}, **{"bf16_" + k: v for k, v in b16.items()})
     print("->", out_path, os.path.getsize(out_path) // 1024, "KiB")

@@ -572,3 +572,30 @@ def test_calibrate_step_ms_feeds_the_speculation_policy():
     assert vsm.step_ms_table is table
     pol = SpeculationPolicy(vsm.step_ms_table, cap=8)
     assert pol.step_ms(1) == table[1] and pol.step_ms(3) == pytest.approx((table[2] + table[4]) / 2)
+
+
+def test_choose_shard_policy():
+    """`--shard auto` (vstar_amd.dist.choose_shard): priced with the measured step-time table — whole searches per rank when every rank
+    can be kept busy, crops of a step when there are fewer searches than ranks (a single search cannot use a second GPU otherwise)."""
+    from vstar_amd.dist import choose_shard, step_ms
+    assert step_ms(1) == 18.6 and step_ms(32) == 232.0 and 25.1 < step_ms(3) < 39.0 and step_ms(64) == 464.0
+    assert choose_shard(1, 8, 1) == "crops"            # one search, eight GPUs: only crop sharding spreads its speculative crops
+    assert choose_shard(4, 8, 1) == "crops"            # fewer searches than ranks
+    assert choose_shard(1, 8, 1, crops_per_search_step=1) == "samples"      # the reference's schedule has one crop per step: nothing to deal
+    assert choose_shard(191, 8, 4) == "samples"        # the V*Bench split: plenty of searches, no collective on the data path
+    assert choose_shard(64, 8, 8) == "samples"
+    assert choose_shard(10, 1, 4) == "samples"         # one rank: nothing to deal
+    # a table in which small batches are as efficient as large ones removes crop sharding's only cost advantage
+    flat = {1: 7.0, 32: 224.0}
+    assert choose_shard(191, 8, 4, flat) == "samples"
+
+
+def test_entry_points_default_to_the_engine_collective_with_fallback():
+    """Round 6: --engine-comm defaults to `auto` on both entry points (and bench.py); the bare flag still parses as `on`."""
+    import visual_search
+    import vstar_bench_eval
+    a = visual_search.parse_args(["--benchmark-folder", "x"])
+    assert a.engine_comm == "auto" and a.shard == "crops"
+    assert visual_search.parse_args(["--benchmark-folder", "x", "--engine-comm"]).engine_comm == "on"
+    assert visual_search.parse_args(["--benchmark-folder", "x", "--engine-comm", "off", "--shard", "auto"]).shard == "auto"
+    assert vstar_bench_eval.parse_args([]).engine_comm == "auto"

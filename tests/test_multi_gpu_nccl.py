@@ -54,13 +54,13 @@ def single(tmp_path_factory):
 
 @needs_two
 @pytest.mark.parametrize("world", WORLDS)
-@pytest.mark.parametrize("mode", ["crops-torch", "crops-engine-comm", "samples"])
+@pytest.mark.parametrize("mode", ["crops-torch", "crops-engine-comm", "crops-default", "samples"])
 def test_real_entry_point_over_nccl_equals_single_process(single, world, mode):
     out_json = str(single["dir"] / f"w{world}_{mode}.json")
     shard = "samples" if mode == "samples" else "crops"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "visual_search.py"), "--benchmark-folder", single["folder"], *COMMON,
-           "--shard", shard, "--output_path", out_json] + (["--engine-comm"] if mode == "crops-engine-comm" else [])
+           "--shard", shard, "--output_path", out_json] + {"crops-engine-comm": ["--engine-comm", "on"], "crops-torch": ["--engine-comm", "off"]}.get(mode, [])
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=_env())
     assert run.returncode == 0, run.stderr[-4000:]
     assert len(_metric_lines(run.stdout)) == 2 and _metric_lines(run.stdout) == _metric_lines(single["stdout"])
@@ -68,8 +68,10 @@ def test_real_entry_point_over_nccl_equals_single_process(single, world, mode):
     assert b["world_size"] == world and b["shard"] == shard
     assert b.get("backend", "nccl") == "nccl"
     assert a["hits"] == b["hits"] and a["path_lengths"] == b["path_lengths"]
-    if mode == "crops-engine-comm":
-        assert b.get("engine_comm") is True, "the C-ABI collective was requested but the run fell back to torch.distributed"
+    if mode in ("crops-engine-comm", "crops-default"):      # round 6: the C-ABI collective is the default (auto = after its self-check)
+        assert b.get("engine_comm") is True, "the C-ABI collective was due but the run fell back to torch.distributed"
+    if mode == "crops-torch":
+        assert b.get("engine_comm") is False
     if shard == "crops":
         assert b["rank0_search_stats"]["useful_crops"] == a["rank0_search_stats"]["useful_crops"]
 

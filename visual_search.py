@@ -58,12 +58,16 @@ def parse_args(argv):
     p.add_argument("--device", default=0, type=int)
     p.add_argument("--batch", default=32, type=int, help="crops per engine pass")
     p.add_argument("--synthetic-seed", default=None, type=int)
-    p.add_argument("--shard", default="crops", choices=["crops", "samples"], help="what is dealt over the ranks under torchrun")
+    p.add_argument("--shard", default="crops", choices=["crops", "samples", "auto"], help="what is dealt over the ranks under torchrun; "
+                   "auto = vstar_amd.dist.choose_shard (measured step-time table: samples when every rank can be kept busy with whole "
+                   "searches, crops when there are fewer searches than ranks x window)")
     p.add_argument("--window", default=0, type=int, help="concurrent (image, target) searches per process; 0 = one engine batch "
                    "(x world size when crops are sharded); 1 = the reference's one-sample-at-a-time schedule")
-    p.add_argument("--engine-comm", action="store_true", help="world > 1 on GPUs: gather the per-step records with the C-ABI's own "
-                   "RCCL communicator on the engine stream (vstar_allgather_results) instead of torch.distributed (EXPERIMENTAL: "
-                   "exercised on one rank only; falls back to torch.distributed if the communicator cannot be set up)")
+    p.add_argument("--engine-comm", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                   help="world > 1 on GPUs, crop sharding: gather the per-step records with the C-ABI's own RCCL collective "
+                   "(vstar_allgather_results) instead of torch.distributed.  auto (default, round 6) = use it when the communicator comes "
+                   "up and its self-check against torch.distributed passes on every rank, else fall back; on = the same, and the JSON "
+                   "summary records the outcome; off = torch.distributed")
     p.add_argument("--vsm-factory", default=None, help="module:factory(args, device) returning an object with the VSM interface "
                    "(tests substitute a CPU stand-in for the engine)")
     return p.parse_args(argv)
@@ -97,11 +101,17 @@ def main(argv):
     finished = False
     try:
         vsm = make_vsm(args, local_rank if world > 1 else args.device)
+        if args.shard == "auto":                         # the same decision on every rank: it depends on the sample list, world and window only
+            from vstar_amd.dist import choose_shard
+            n_all = sum(1 for _ in iter_samples(args.benchmark_folder))
+            args.shard = choose_shard(n_all, world, args.window or args.batch)
+            if rank == 0:
+                print(f"--shard auto: {n_all} searches on {world} rank(s), window {args.window or args.batch} -> {args.shard}")
         if args.shard == "samples":
             vsm.shard_crops = False                      # each search stays on its own GPU
-        elif args.engine_comm:
+        elif args.shard == "crops" and args.engine_comm != "off" and world > 1:
             from vstar_amd.dist import maybe_engine_comm
-            maybe_engine_comm(vsm)
+            maybe_engine_comm(vsm)                       # (no-op on gloo / CPU; falls back to torch.distributed on any failure)
         class _Loader:                                   # lazy image load when the sample enters the window; one slot per file
             def __init__(self, path):
                 self.key = path

@@ -27,9 +27,11 @@ def parse_args(argv):
     p.add_argument("--device", default=0, type=int)
     p.add_argument("--search-window", dest="search_window", default=0, type=int, help="concurrent visual searches per engine batch "
                    "(cross-image lock step); 0 = one engine batch, 1 = one image at a time like the reference")
-    p.add_argument("--engine-comm", action="store_true", help="world > 1 on GPUs: gather the per-step records with the C-ABI's own RCCL "
-                   "communicator on the engine stream (vstar_allgather_results) instead of torch.distributed — EXPERIMENTAL, falls "
-                   "back to torch.distributed on every rank together if the communicator cannot be set up")
+    p.add_argument("--engine-comm", nargs="?", const="on", default="auto", choices=["auto", "on", "off"],
+                   help="world > 1 on GPUs: gather the per-step records with the C-ABI's own RCCL communicator on the engine stream "
+                   "(vstar_allgather_results) instead of torch.distributed.  auto (default, round 6): used when the communicator comes up "
+                   "and its self-check against torch.distributed passes on every rank, otherwise every rank falls back together; off = "
+                   "torch.distributed")
     return p.parse_args(argv)
 
 
@@ -57,7 +59,7 @@ def main(argv):
             vsm = getattr(importlib.import_module(mod), fn)(args, local_rank)
         elif world > 1:
             vsm = make_vsm(args, local_rank)
-        if args.engine_comm and vsm is not None and world > 1:
+        if args.engine_comm != "off" and vsm is not None and world > 1:
             from vstar_amd.dist import maybe_engine_comm
             maybe_engine_comm(vsm)
         eval_model(args, vqa_llm, vsm, world=world, rank=rank)
