@@ -163,8 +163,8 @@ def test_bench_batch_matches_full_depth_reference(cuda, image_size, weights, fol
     eng.close()
 
 
-@pytest.mark.parametrize("image_size", [336, 224])
-def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda, image_size):
+@pytest.mark.parametrize("image_size,tag", [(336, "x32"), (224, "x32"), (336, "x32_r1")])
+def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda, image_size, tag):
     """Round 5: the 8-crop fixtures above cannot tell a 10 % systematic excess from sampling error — the
     per-crop errors on the OWL-ViT side are heavy-tailed and the pooled engine / reference-bf16 ratio moved between 0.72 and 1.21
     from fixture to fixture.  tests/golden/full7b_tl_336_x32.npz holds the reference's fp32 AND bf16 outputs for ALL 32 crops of the
@@ -175,14 +175,17 @@ def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda, image_size)
         sit sqrt(2) noise units apart, a systematic difference between the two bf16 evaluations would show as more;
       * mask offset (units of the noise model's sigma, tests/_parity.py): engine rms <= reference-bf16's + 0.2, no crop beyond 4;
       * the signed mask offsets average to zero within 3 standard errors (no bias of the engine against fp32)."""
-    z = np.load(os.path.join(GOLD, f"full7b_tl_{image_size}_x32.npz"))       # 224: the geometry the reference REALLY runs (S = 320)
+    path = os.path.join(GOLD, f"full7b_tl_{image_size}_{tag}.npz")           # 224: the geometry the reference REALLY runs (S = 320)
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated")
+    z = np.load(path)                                                          # x32_r1 (round 6): a second crop batch, bench_inputs(rank=1)
     B, T = int(z["batch"]), int(z["text_tokens"])
     crops = [int(c) for c in z["crops"]]
     assert len(crops) == B == 32
     cfg = VSMConfig.seal_7b(image_size, max_batch=B, max_text_len=T + 1)
     eng = VstarEngine(cfg, 0)
     eng.load_state_dict(_state_dict(cfg, z))
-    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T)
+    clip, owl, ids, loc, verify = bench_inputs(cfg, B, T, rank=int(z["input_rank"]) if "input_rank" in z.files else 0)
     out = eng.score_batch(clip.to(cuda), owl.to(cuda), ids, loc, verify_pos=verify)
     H = cfg.llm_hidden
     taps = {"llm_hidden_loc": eng.debug_read("llm_hidden_loc", B * H).reshape(B, H),
@@ -232,4 +235,22 @@ def test_all_32_crops_engine_noise_equals_reference_bf16_noise(cuda, image_size)
     if not abs(np.mean(signed)) <= 3.0 * np.std(signed) / np.sqrt(B):
         fails.append(f"mask offsets are biased: mean {np.mean(signed):+.4f}")
     eng.close()
+    _SIGNED_OFFSETS[(image_size, tag)] = signed
     assert not fails, "\n".join(fails)
+
+
+_SIGNED_OFFSETS = {}
+
+
+def test_mask_offset_is_unbiased_over_both_32_crop_batches(cuda):
+    """Round 6: over the 32 crops of the first 336 fixture the engine's signed mask offset against the reference's
+    fp32 masks was -0.0088 +- 0.0044 (two standard errors).  A second 32-crop batch on another input seed
+    (tests/golden/full7b_tl_336_x32_r1.npz) settles it: pooled over the 64 crops |mean| <= 2 standard errors.  Uses the offsets
+    the parametrised test above recorded in this session (same engine runs)."""
+    a, b = _SIGNED_OFFSETS.get((336, "x32")), _SIGNED_OFFSETS.get((336, "x32_r1"))
+    if a is None or b is None:
+        pytest.skip("needs both 336 fixtures to have run in this session")
+    s = np.asarray(a + b, np.float64)
+    se = s.std() / np.sqrt(len(s))
+    print(f"signed mask offsets over {len(s)} crops: mean {s.mean():+.4f} +- {se:.4f}  (batch 0: {np.mean(a):+.4f}, batch 1: {np.mean(b):+.4f})")
+    assert abs(s.mean()) <= 2.0 * se, f"mask offsets are biased over 64 crops: mean {s.mean():+.4f}, standard error {se:.4f}"
