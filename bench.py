@@ -584,7 +584,7 @@ def main():
                                  f"{kernel_source_hash()}; counters cannot be read inside an un-profiled run); includes "
                                  "Infinity-Cache hits; algorithmic operand+output bytes per launch ~0.3 GB") if traffic is not None else
                                 (f"null: no committed PMC summary carries this build's kernel_source_hash {kernel_source_hash()} "
-                                 f"(newest candidate: {traffic_stale}) — re-run tools/collect_r05.sh on the GPU box"),
+                                 f"(newest candidate: {traffic_stale}) — re-run tools/collect_r06.sh on the GPU box"),
                 "kernel_source_hash": kernel_source_hash(),
                 "kernel_source_hash_matches_tree": kernel_source_hash() == _tree_hash(),
                 "under_load": None if not power or "error" in power else dict(
@@ -595,7 +595,7 @@ def main():
                 "fp8_linears": None if not args.fp8 or f8_ms_m <= 0 else {
                     "achieved": round(f8_flops_m / (f8_ms_m * 1e-3) / 1e12, 1), "peak": 5000.0,
                     "frac": round(f8_flops_m / (f8_ms_m * 1e-3) / 1e12 / 5000.0, 4), "launches_per_step": int(f8_n_m) // 2},
-                "kernel": "gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM, all epilogues)", "launches_per_step": gemm_n // 2,
+                "kernel": "gemm4w_kernel + gemm256_kernel + gemm128_kernel (bf16 MFMA GEMM family, all epilogues; gemm4w = the LLaMA linears, 76 % of the step)", "launches_per_step": gemm_n // 2,
                 "avg_launch_ms": round(gemm_ms / max(gemm_n, 1), 4),
                 "gemm_share_of_step": round(gemm_ms / 2 / ms_per_step, 3),
                 # whole step / peak.  ALGORITHMIC FLOPs count the last LLaMA block on every row like the reference computes it;

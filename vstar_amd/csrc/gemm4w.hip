@@ -47,6 +47,17 @@ constexpr int LDS_TOTAL = 2 * 65536;
   G4W_A16(7), G4W_A16(8), G4W_A16(9), G4W_A16(10), G4W_A16(11), G4W_A16(12), G4W_A16(13), G4W_A16(14), G4W_A16(15), G4W_A16(16),     \
   G4W_A16(17), G4W_A16(18), G4W_A16(19), G4W_A16(20), G4W_A16(21), G4W_A16(22), G4W_A16(23), G4W_A16(24), "a250", "a251", "a252",   \
   "a253", "a254", "a255"
+#ifdef G4W_TIMELINE   // diagnostic builds only (tools/gemm4w_timeline.py): wall-clock stamps (100 MHz) of the tile phases, wave 0 of WG 0 / 100
+__device__ unsigned long long g4w_timeline[2][64][8];
+#define G4W_STAMP(pt)                                                                                         \
+  do {                                                                                                        \
+    if ((threadIdx.x & 63) == 0 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100) && tl_tile < 64)        \
+      g4w_timeline[blockIdx.x ? 1 : 0][tl_tile][pt] = wall_clock64();                                         \
+  } while (0)
+#else
+#define G4W_STAMP(pt) do { } while (0)
+#endif
+
 template <int IDX>
 __device__ __forceinline__ float agpr_read() {
   float x;
@@ -130,18 +141,36 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
       }
-      static_for<8>([&](auto mc) {
-        constexpr int m = decltype(mc)::value;
-        f32x4 a[4];
-        acc_row(mc, a);
+      if (p.bias) {
+        static_for<8>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          f32x4 a[4];
+          acc_row(mc, a);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          pa[m][e] = (short)f2lp(a[0][e] + bia[e]);
-          pa[m][4 + e] = (short)f2lp(a[1][e] + bia[4 + e]);
-          pb[m][e] = (short)f2lp(a[2][e] + bib[e]);
-          pb[m][4 + e] = (short)f2lp(a[3][e] + bib[4 + e]);
-        }
-      });
+          for (int e = 0; e < 4; ++e) {
+            pa[m][e] = (short)f2lp(a[0][e] + bia[e]);
+            pa[m][4 + e] = (short)f2lp(a[1][e] + bia[4 + e]);
+            pb[m][e] = (short)f2lp(a[2][e] + bib[e]);
+            pb[m][4 + e] = (short)f2lp(a[3][e] + bib[4 + e]);
+          }
+        });
+      } else {
+        // no bias (every LLaMA linear): 256 adds of +0.0f less per lane on a path that is VALU-bound with one wave per SIMD
+        // (tools/gemm4w_timeline.py: 3.9 us of epilogue arithmetic per tile).  Same bits: an MFMA chain that starts from +0 never
+        // yields -0, the only value x + 0.0f would change.
+        static_for<8>([&](auto mc) {
+          constexpr int m = decltype(mc)::value;
+          f32x4 a[4];
+          acc_row(mc, a);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pa[m][e] = (short)f2lp(a[0][e]);
+            pa[m][4 + e] = (short)f2lp(a[1][e]);
+            pb[m][e] = (short)f2lp(a[2][e]);
+            pb[m][4 + e] = (short)f2lp(a[3][e]);
+          }
+        });
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (EPI == VSTAR_EPI_NONE) {
@@ -323,7 +352,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   if (bid >= nwg) return;
   set_tile(bid);
   issue_head();
+  int tl_tile = 0; (void)tl_tile;
   for (;;) {
+    G4W_STAMP(0);
     // ---- fragment read addresses (buffer 0): row-major 128-B rows, chunk ^ ((row >> 1) & 7) ----
     uint32_t rd[4];
     {
@@ -362,6 +393,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_PF G4W_OPERANDS);
     else asm volatile(GEMM4W_LOOP_ASM G4W_OPERANDS);
 #undef G4W_OPERANDS
+    G4W_STAMP(1);
     // ---- next tile: its K-tiles 0 and 1 go into the (dead: the loop text ends behind a barrier) LDS buffers NOW, so that the
     // pipeline fill overlaps this tile's epilogue; this tile's coordinates stay in em0 / en0 ----
     const int em0 = m0, en0 = n0;
@@ -371,6 +403,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       set_tile(bid);
       issue_head();
     }
+    G4W_STAMP(2);
     // ---- epilogue: the wave's 128 x 128 as the two virtual waves (wr, 2 wc2) and (wr, 2 wc2 + 1) of gemm256's grid ----
 #ifdef G4W_ABL_NOEPI      // ablation build (timing only): what the whole epilogue costs
     if (false) {
@@ -381,6 +414,12 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       direct_epilogue_half<EPI, 0>(p, em0, en0, wr, wc2 * 2, fr, fq);
       direct_epilogue_half<EPI, 1>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
     }
+    G4W_STAMP(3);
+#ifdef G4W_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the loop text starts with the same wait: here it gets its own stamp)
+    G4W_STAMP(4);
+    ++tl_tile;
+#endif
     if (!has_next) break;
   }
 }
@@ -402,6 +441,12 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#if defined(G4W_TIMELINE) && !defined(VSTAR_LP_F16)
+extern "C" int vstar_debug_gemm4w_timeline(unsigned long long* out) {     // 2 x 64 x 8 stamps
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g4w_timeline), sizeof(g4w_timeline));
+}
+#endif
 
 // Launches made of interior tiles that take gemm256's direct epilogue (see the header comment for the domain).
 bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
