@@ -23,6 +23,7 @@ ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--epilogues", action="store_true")
 ap.add_argument("--zeros", action="store_true")
+ap.add_argument("--out-pad", type=int, default=0, help="output rows padded by this many elements (row pitch of C)")
 ap.add_argument("--vit", action="store_true", help="the ViT shapes of the bench batch with M rounded down to whole 256-row tiles (gemm4w domain)")
 ap.add_argument("--lda-pad", type=int, default=0, help="A rows padded by this many elements (row stride not a power of two)")
 args = ap.parse_args()
@@ -75,14 +76,15 @@ for name, Mm, N, K, epi, has_res in shapes:
         w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
     lda = K + args.lda_pad
     res = torch.randn(Mm, n_out, device=dev).bfloat16() if has_res else None
-    c = torch.empty(Mm, n_out, device=dev, dtype=torch.bfloat16)
+    ldc = n_out + args.out_pad
+    c = torch.empty(Mm, ldc, device=dev, dtype=torch.bfloat16)
     fns = {}
     if not epi and not has_res:
         fns["hipblaslt"] = lambda: F.linear(a, w)
     for ln, L in libs:
         for k, flag in (("256", _lib.EPI_TILE256), ("4w", _lib.EPI_TILE4W)):
             def f(L=L, flag=flag):
-                rc = L.vstar_op_gemm(None, P(a), lda, P(w), None, P(res), n_out, P(c), n_out, 0, Mm, N, K, epi | 0x100 | flag)
+                rc = L.vstar_op_gemm(None, P(a), lda, P(w), None, P(res), n_out, P(c), ldc, 0, Mm, N, K, epi | 0x100 | flag)
                 assert rc == 0, rc
             fns[f"{ln}:{k}"] = f
     best = {k: 1e9 for k in fns}
