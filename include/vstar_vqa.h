@@ -96,7 +96,8 @@ int vstar_vqa_forward(vstar_vqa_handle* h, int nseq, const int32_t* row_off, con
  * + bias) (+ residual), epilogue codes and operand rules as vstar_op_gemm (W rows padded to a multiple of 256, K % 64 == 0).
  * kernel: 0 = the engine's dispatch (weight-streaming kernel for M <= 64, MFMA tile kernels otherwise), 1 = force the
  * weight-streaming kernel (M <= 64; for M <= 8 that is its LDS-ring variant), 2 = force the tile kernels, 3 = the weight-streaming
- * kernel with the weights through registers even where the LDS-ring variant would run (bit-identity tests).  dev_norm_w (nullable, weight-streaming kernel only):
+ * kernel with the weights through registers even where the LDS-ring variant would run (bit-identity tests), 4 = the 4-wave / AGPR
+ * 256x256 tile kernel (gemm4w, round 6; error outside its domain), 5 = the 8-wave 256x256 kernel.  dev_norm_w (nullable, weight-streaming kernel only):
  * LlamaRMSNorm gains [K]; the rows of A are RMS-normalised (eps = norm_eps) while they are loaded, as the decode path
  * does for input_layernorm -> q/k/v and post_attention_layernorm -> gate/up.  Runs on the null stream and synchronises. */
 int vstar_vqa_op_gemm(const void* dev_A, const void* dev_W, const void* dev_bias, const void* dev_residual, void* dev_C,

@@ -20,13 +20,13 @@ SHAPES = {"qkv": (S, 12288, 4096, 0, 0, 1), "o": (S, 4096, 4096, 0, 1, 0), "gate
 EXPECTED = {   # crops per step -> shape -> code, on the 256 CUs of an MI355X
     1: {'qkv': 1287, 'o': 1285, 'gate_up': 1287, 'down': 1285, 'clip_qkv': 1286, 'clip_out': 1286, 'clip_fc1': 1285, 'clip_fc2': 1286,
         'owl_qkv': 1282, 'owl_out': 1286, 'owl_fc1': 1282, 'owl_fc2': 1286},
-    2: {'qkv': 2560, 'o': 1287, 'gate_up': 2560, 'down': 1287, 'clip_qkv': 1285, 'clip_out': 1286, 'clip_fc1': 1282, 'clip_fc2': 1286,
+    2: {'qkv': 25640, 'o': 1287, 'gate_up': 25640, 'down': 1287, 'clip_qkv': 1285, 'clip_out': 1286, 'clip_fc1': 1282, 'clip_fc2': 1286,
         'owl_qkv': 2560, 'owl_out': 1285, 'owl_fc1': 2560, 'owl_fc2': 1285},
-    4: {'qkv': 2560, 'o': 2560, 'gate_up': 2560, 'down': 2560, 'clip_qkv': 1282, 'clip_out': 1285, 'clip_fc1': 2560, 'clip_fc2': 1285,
+    4: {'qkv': 25640, 'o': 25640, 'gate_up': 25640, 'down': 25640, 'clip_qkv': 1282, 'clip_out': 1285, 'clip_fc1': 2560, 'clip_fc2': 1285,
         'owl_qkv': 2560, 'owl_out': 1282, 'owl_fc1': 2560, 'owl_fc2': 1287},
-    8: {'qkv': 2560, 'o': 3845, 'gate_up': 2560, 'down': 3845, 'clip_qkv': 2560, 'clip_out': 1282, 'clip_fc1': 3845, 'clip_fc2': 1287,
+    8: {'qkv': 25640, 'o': 3845, 'gate_up': 25640, 'down': 3845, 'clip_qkv': 2560, 'clip_out': 1282, 'clip_fc1': 3845, 'clip_fc2': 1287,
         'owl_qkv': 2560, 'owl_out': 2560, 'owl_fc1': 2560, 'owl_fc2': 2560},
-    32: {'qkv': 2560, 'o': 2560, 'gate_up': 2560, 'down': 2560, 'clip_qkv': 2560, 'clip_out': 3845, 'clip_fc1': 2560, 'clip_fc2': 3845,
+    32: {'qkv': 25640, 'o': 25640, 'gate_up': 25640, 'down': 25640, 'clip_qkv': 2560, 'clip_out': 3845, 'clip_fc1': 2560, 'clip_fc2': 3845,
          'owl_qkv': 3845, 'owl_out': 2560, 'owl_fc1': 2560, 'owl_fc2': 2560},
 }
 
@@ -46,8 +46,8 @@ def test_dispatch_table_of_the_path(B):
 
 def test_dispatch_rules():
     lib = _lib.load()
-    # the headline batch: every LLaMA linear on the 256^2 kernel (the only one with the fused RoPE / the W8A8 path)
-    assert all(plan(lib, 32, n) == 2560 for n in ("qkv", "o", "gate_up", "down"))
+    # the headline batch: every LLaMA linear on the 4-wave / AGPR 256^2 kernel (round 6; code 2564 = "256, 4 waves"), M % 256 == 0
+    assert all(plan(lib, 32, n) == 25640 for n in ("qkv", "o", "gate_up", "down"))
     # the 128 x 256 loader-wave tile: long K and more 128^2 tiles than CUs only — never for the short-K ViT towers at one crop
     assert plan(lib, 1, "qkv") == plan(lib, 1, "gate_up") == 1287
     assert all(plan(lib, 1, n) % 10 != 7 for n in SHAPES if SHAPES[n][2] < 2048)

@@ -6,6 +6,8 @@ import shutil
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -56,15 +58,15 @@ def test_library_carries_the_hash_of_the_sources_it_was_built_from(lib):
     assert provenance.library_source_hash() == provenance.kernel_source_hash() == provenance.checked_hash()
 
 
-def test_gemm4w_accumulators_are_never_overwritten_before_they_are_read():
+@pytest.mark.parametrize("dtype_flag", [[], ["--f16"]])
+def test_gemm4w_accumulators_are_never_overwritten_before_they_are_read(dtype_flag):
     """gemm4w.hip keeps its accumulators in AGPRs behind the compiler's back (clobbers of the K-loop statement, read back by asm
     statements in the epilogue).  tools/check_gemm4w_agpr.py walks the compiler's own assembly of all eight kernels and proves that
     nothing writes an AGPR before the epilogue has consumed it (round 6: the register allocator once parked the W piece offsets in
     a2..a9).  Needs hipcc (cross-compiles without a GPU); ~40 s."""
     import shutil as _sh
     if not (_sh.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        import pytest
         pytest.skip("no hipcc")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm4w_agpr.py")], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_gemm4w_agpr.py")] + dtype_flag, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok ") == 8

@@ -394,3 +394,27 @@ def test_vqa_engine_reports_errors(cuda):
     # a sequence of one row and an empty want list are legal
     lg, arg = eng.forward([Seq([7], kv_slot=2)], [])
     assert lg is None and len(arg) == 0
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (2048, 4096, 4096, 0), (1280, 8192, 1024, 4)])
+def test_fp16_gemm4w_equals_gemm256(M, N, K, epi):
+    """Round 6: the fp16 instantiation of the 4-wave / AGPR 256^2 kernel (v_mfma_f32_16x16x32_f16 in the generated K loop) against the
+    8-wave gemm256 on the same operands: bit-identical, three repetitions (the VQA-LLM's prefill linears take it at M % 256 == 0)."""
+    import ctypes
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).half().cuda()
+    res = (torch.randn(M, n_out, generator=g) * 0.5).half().cuda() if epi == 0 else None
+    P = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    outs = {}
+    for kernel in (5, 4, 4, 4):
+        C = torch.full((M, n_out), float("nan"), dtype=torch.float16, device="cuda")
+        rc = lib.vstar_vqa_op_gemm(P(A), P(W), None, P(res), P(C), M, N, K, epi, kernel, None, 0.0)
+        assert rc == 0, lib.vstar_vqa_last_error(None)
+        if kernel == 5:
+            outs[5] = C
+        else:
+            assert torch.equal(C.view(torch.int16), outs[5].view(torch.int16))
+    assert not torch.isnan(outs[5].float()).any()

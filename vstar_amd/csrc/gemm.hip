@@ -374,19 +374,24 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   if (force != 0 && force != 128 && force != 256 && force != GEMM_TILE_4W) return hipErrorInvalidValue;
   const bool elig = gemm256_eligible(p);
   if (p.tile_force == 256 && !elig) return hipErrorInvalidValue;   // an explicit per-call request must not be silently re-routed
-  // The 4-wave / AGPR kernel (gemm4w.hip): launches made of interior 256^2 tiles with the in-register epilogue.  Same k order and
-  // epilogue arithmetic as gemm256: bit-identical (tests/test_ops_gpu.py::test_gemm4w_equals_gemm256).  tile_force = 256 keeps the
-  // 8-wave kernel (A/B, tests), GEMM_TILE_4W demands this one; VSTAR_GEMM4W=0/1 sets the default for unforced calls.
-  {
-    static const int env4w = [] { const char* e = getenv("VSTAR_GEMM4W"); return e ? atoi(e) : GEMM4W_DEFAULT; }();
-    const bool elig4 = elig && gemm4w_eligible(p, epilogue, out_f32);
-    if (p.tile_force == GEMM_TILE_4W && !elig4) return hipErrorInvalidValue;
-    if (elig4 && (force == GEMM_TILE_4W || (force == 0 && env4w != 0))) {
-      t_last_tile = GEMM_TILE_4W;
-      return gemm4w_lp(p, epilogue, s);
-    }
-    if (force == GEMM_TILE_4W) return hipErrorInvalidValue;      // (environment-forced onto a shape outside the domain)
+  // The 4-wave / AGPR kernel (gemm4w.hip) takes the launches made of interior 256^2 tiles with the in-register epilogue — WHERE the
+  // dispatcher would run the 256^2 kernel at all (below: under-filled grids still go to the 128^2 family, ragged rounds are still
+  // split).  Same k order and epilogue arithmetic as gemm256: bit-identical (tests/test_ops_gpu.py::test_gemm4w_equals_gemm256).
+  // tile_force = 256 keeps the 8-wave kernel (A/B, tests), GEMM_TILE_4W demands this one; VSTAR_GEMM4W=0/1 sets the default.
+  static const int env4w = [] { const char* e = getenv("VSTAR_GEMM4W"); return e ? atoi(e) : GEMM4W_DEFAULT; }();
+  if (force == GEMM_TILE_4W) {
+    if (!(elig && gemm4w_eligible(p, epilogue, out_f32))) return hipErrorInvalidValue;
+    t_last_tile = GEMM_TILE_4W;
+    return gemm4w_lp(p, epilogue, s);
   }
+  auto big = [&](const GemmParams& q) -> hipError_t {       // the 256^2 launch of this call (whole, or the leading part of a split)
+    if (force == 0 && env4w != 0 && gemm4w_eligible(q, epilogue, out_f32)) {
+      t_last_tile = GEMM_TILE_4W;
+      return gemm4w_lp(q, epilogue, s);
+    }
+    t_last_tile = 256;
+    return gemm256_lp(q, epilogue, out_f32, s);
+  };
   if (force != 128 && elig) {   // W is padded to 256 rows
     // Under-filled grids (small batches: e.g. o_proj at 1280 rows = 80 tiles of 256^2 on 256 CUs): the 128^2 kernel has four
     // times the tiles; one of its tiles takes ~0.36 of a 256^2 tile (1/4 of the work at ~0.7 of the efficiency), so compare
@@ -421,15 +426,14 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
           if (p.row_scale) b.row_scale = p.row_scale + M1;
           if (p.sumsq_out) b.sumsq_out = p.sumsq_out + M1 * p.sumsq_ld;      // (stats_sum is an offset inside a partial row: unchanged)
           b.tile_force = 128;
-          hipError_t e = gemm256_lp(a, epilogue, out_f32, s);
+          hipError_t e = big(a);
           if (e != hipSuccess) return e;
           e = gemm_lp(b, epilogue, out_f32, s);
           t_last_tile = 256 + 128;                                 // observable: split launch
           return e;
         }
       }
-      t_last_tile = 256;
-      return gemm256_lp(p, epilogue, out_f32, s);
+      return big(p);
     }
   }
   if (p.rope_cs || p.a_scale) return hipErrorInvalidValue;   // fused RoPE / W8A8 exist only in the 256^2 kernel: callers check gemm256_eligible

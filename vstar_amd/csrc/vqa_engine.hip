@@ -283,6 +283,8 @@ int vstar_vqa_op_gemm(const void* A, const void* W, const void* bias, const void
   p.norm_w = (const lp_t*)norm_w; p.norm_eps = norm_eps;
   hipError_t e;
   if (kernel == 3) p.tile_force = -1;      // the register-streaming skinny kernel even where the LDS-ring variant would run
+  if (kernel == 4) p.tile_force = GEMM_TILE_4W;      // round 6: the 4-wave / AGPR 256^2 kernel, error outside its domain
+  if (kernel == 5) p.tile_force = 256;               // the 8-wave 256^2 kernel
   if (kernel == 1 || kernel == 3 || (kernel == 0 && gemm_skinny_eligible(p))) e = gemm_skinny_lp(p, epilogue, false, nullptr);
   else e = gemm_lp(p, epilogue, false, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
