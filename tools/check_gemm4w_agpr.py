@@ -36,9 +36,9 @@ def main():
         consumed, parked, offenders = set(), set(), []
         for x in window:
             x = x.strip()
-            m = re.match(r"v_accvgpr_read_b32 v\d+, a\[?(\d+)\]?", x)
+            m = re.match(r"v_accvgpr_read_b32 v\d+, a\[?(\d+)(?:\+(\d+))?\]?", x)      # (the epilogue's statements print a[B+i])
             if m:
-                n = int(m.group(1))
+                n = int(m.group(1)) + int(m.group(2) or 0)
                 if n in parked:
                     parked.discard(n)            # the compiler reading back what it parked
                 else:

@@ -58,25 +58,20 @@ __device__ unsigned long long g4w_timeline[2][64][8];
 #define G4W_STAMP(pt) do { } while (0)
 #endif
 
-template <int IDX>
-__device__ __forceinline__ float agpr_read() {
-  float x;
-  asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(IDX) : G4W_ALL_AGPRS);
-  return x;
-}
-// fragment (m, n') of the wave's 8 x 8: a[(m * 8 + n') * 4 ..+3] (tools/gen_gemm4w_asm.py::mfma)
-template <int M, int NP>
-__device__ __forceinline__ f32x4 acc_frag() {
-  constexpr int B = (M * 8 + NP) * 4;
-  return (f32x4){agpr_read<B>(), agpr_read<B + 1>(), agpr_read<B + 2>(), agpr_read<B + 3>()};
-}
-// row m of the 128 x 64 half H of the wave's tile, as one row of gemm256's acc[8][4]
+// fragment (m, n') of the wave's 8 x 8 lives in a[(m * 8 + n') * 4 ..+3] (tools/gen_gemm4w_asm.py::mfma).  Row m of the 128 x 64 half H of
+// the wave's tile = fragments n' = 4 H .. 4 H + 3 = SIXTEEN CONSECUTIVE AGPRs a[(m * 8 + 4 H) * 4 ..+15], read by ONE statement: the
+// compiler puts an `s_nop` behind every inline-asm statement it cannot see into — one statement per register was 256 of them per tile.
 template <int H, int M>
 __device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
-  a[0] = acc_frag<M, H * 4 + 0>();
-  a[1] = acc_frag<M, H * 4 + 1>();
-  a[2] = acc_frag<M, H * 4 + 2>();
-  a[3] = acc_frag<M, H * 4 + 3>();
+  constexpr int B = (M * 8 + H * 4) * 4;
+  asm volatile("v_accvgpr_read_b32 %0, a[%c16]\n\tv_accvgpr_read_b32 %1, a[%c16+1]\n\tv_accvgpr_read_b32 %2, a[%c16+2]\n\tv_accvgpr_read_b32 %3, a[%c16+3]\n\t"
+               "v_accvgpr_read_b32 %4, a[%c16+4]\n\tv_accvgpr_read_b32 %5, a[%c16+5]\n\tv_accvgpr_read_b32 %6, a[%c16+6]\n\tv_accvgpr_read_b32 %7, a[%c16+7]\n\t"
+               "v_accvgpr_read_b32 %8, a[%c16+8]\n\tv_accvgpr_read_b32 %9, a[%c16+9]\n\tv_accvgpr_read_b32 %10, a[%c16+10]\n\tv_accvgpr_read_b32 %11, a[%c16+11]\n\t"
+               "v_accvgpr_read_b32 %12, a[%c16+12]\n\tv_accvgpr_read_b32 %13, a[%c16+13]\n\tv_accvgpr_read_b32 %14, a[%c16+14]\n\tv_accvgpr_read_b32 %15, a[%c16+15]"
+               : "=v"(a[0][0]), "=v"(a[0][1]), "=v"(a[0][2]), "=v"(a[0][3]), "=v"(a[1][0]), "=v"(a[1][1]), "=v"(a[1][2]), "=v"(a[1][3]),
+                 "=v"(a[2][0]), "=v"(a[2][1]), "=v"(a[2][2]), "=v"(a[2][3]), "=v"(a[3][0]), "=v"(a[3][1]), "=v"(a[3][2]), "=v"(a[3][3])
+               : "n"(B)
+               : G4W_ALL_AGPRS);
 }
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
