@@ -21,11 +21,12 @@
 //
 // Epilogue (round 5).  Interior tiles of a launch with aligned operands finish IN THE ACCUMULATOR REGISTERS: the wave's 64 W
 // rows are DMA'd in a permuted order so that a lane's four fragments are two runs of 8 consecutive output columns — see
-// `dir_launch` below.  Edge tiles, row-mapped outputs, fp32 outputs and the erf GELU keep the LDS-transposed epilogue.  No
+// `dir_launch` below and gemm256_direct_epilogue.hpp (the code, shared with gemm4w.hip since round 6).  Edge tiles, row-mapped outputs, fp32 outputs and the erf GELU keep the LDS-transposed epilogue.  No
 // per-lane value lives across the K loop (the lane id is re-read after it), so no instantiation spills.
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
+#include "gemm256_direct_epilogue.hpp"
 #include <type_traits>
 
 namespace VS_NS {
@@ -426,144 +427,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const GemmParams p) {
       }
     }
   } else if (edirect) {
-    constexpr bool SILU = (EPI == VSTAR_EPI_SILU_MUL);
-    bool rope_tile = false;
-    if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
-    // first output column of this lane's two 8-column chunks (SiLU: one chunk)
-    int col_a, col_b;
-    if (SILU) { col_a = (en0 + wc * 64) / 2 + fq * 8; col_b = col_a; }
-    else if (rope_tile) { col_a = en0 + (wc >> 1) * 128 + (wc & 1) * 32 + fq * 8; col_b = col_a + 64; }
-    else { col_a = en0 + wc * 64 + fq * 8; col_b = col_a + 32; }
-    const int row0 = em0 + wr * 128 + fr;                     // interior tile: rows row0 + 16 m < M, identity row map
-    lp_t* crow = (lp_t*)p.C + (int64_t)row0 * p.ldc;
-    if constexpr (SILU) {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        lpx8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = (short)f2lp(act_silu_bf16(rlp(acc[m][0][e])) * rlp(acc[m][1][e]));
-          v[4 + e] = (short)f2lp(act_silu_bf16(rlp(acc[m][2][e])) * rlp(acc[m][3][e]));
-        }
-        __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
-        crow += 16 * p.ldc;
-      }
-    } else {
-      // ---- stage 1 for the WHOLE wave tile: bf16(acc + bias), packed — 64 registers; the 128 accumulators are dead after it ----
-      lpx8 pa[8], pb[8];
-      {
-        float bia[8], bib[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
-        if (p.bias) {
-          const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
-        }
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pa[m][e] = (short)f2lp(acc[m][0][e] + bia[e]);
-            pa[m][4 + e] = (short)f2lp(acc[m][1][e] + bia[4 + e]);
-            pb[m][e] = (short)f2lp(acc[m][2][e] + bib[e]);
-            pb[m][4 + e] = (short)f2lp(acc[m][3][e] + bib[4 + e]);
-          }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- stage 2 on the packed values: RoPE / activation, in place ----
-      if constexpr (EPI == VSTAR_EPI_NONE) {
-        if (rope_tile) {
-          const int rope_d = (wc & 1) * 32 + fq * 8;          // rotary index of chunk a (chunk b: the same index, second half)
-#pragma unroll
-          for (int m = 0; m < 8; ++m) {
-            const int row = row0 + m * 16;
-            int pos = row % p.rope_S;
-            if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);      // grouped sequences
-            if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;   // shared prefix
-            const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + rope_d);
-            const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + rope_d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float c = lp2f((lp_t)c8[e]), sn = lp2f((lp_t)s8[e]);
-              const float xa = lp2f((lp_t)pa[m][e]), xb = lp2f((lp_t)pb[m][e]);
-              pa[m][e] = (short)f2lp(rlp(xa * c) + rlp(-1.0f * xb * sn));      // first half of the head: x*cos - partner*sin
-              pb[m][e] = (short)f2lp(rlp(xb * c) + rlp(1.0f * xa * sn));       // second half: x*cos + partner*sin
-            }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          gemm_epilogue_act8<EPI>(pa[m]);
-          gemm_epilogue_act8<EPI>(pb[m]);
-        }
-      }
-      // ---- residual: all sixteen 16-byte pieces of this lane in flight together, ONE wait.  Requested row by row where they are
-      // used they were eight memory round trips in series — 6 us of a 10-us epilogue (tools/gemm_timeline.py: o_proj + residual
-      // 10.5 us per tile, without 4.0) — and requested next to the live fp32 accumulators they spill; next to the packed values
-      // they fit (64 + 64 registers).
-      if (p.res) {
-        __builtin_amdgcn_sched_barrier(0);
-        lpx8 ra[8], rb[8];
-        const lp_t* rrow = p.res + (int64_t)row0 * p.ldr;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          ra[m] = *(const lpx8*)(rrow + col_a);
-          rb[m] = *(const lpx8*)(rrow + col_b);
-          rrow += 16 * p.ldr;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < 8; ++m)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            pa[m][e] = (short)f2lp(lp2f((lp_t)pa[m][e]) + lp2f((lp_t)ra[m][e]));
-            pb[m][e] = (short)f2lp(lp2f((lp_t)pb[m][e]) + lp2f((lp_t)rb[m][e]));
-          }
-      }
-      // ---- stores (+ the statistics of the stored values), row by row ----
-      float* sq = nullptr;
-      if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
-        if (p.sumsq_out) sq = p.sumsq_out + (int64_t)row0 * p.sumsq_ld + (en0 + wc * 64) / 64;
-      }
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        __builtin_amdgcn_sched_barrier(0);      // pa / pb die as they are stored
-        if (p.sumsq_out) {          // the rows are the next linear's A operand right away: keep them cache-resident
-          *(lpx8*)(crow + col_a) = pa[m];
-          *(lpx8*)(crow + col_b) = pb[m];
-        } else {
-          __builtin_nontemporal_store(pa[m], (lpx8*)(crow + col_a));
-          __builtin_nontemporal_store(pb[m], (lpx8*)(crow + col_b));
-        }
-        crow += 16 * p.ldc;
-        if constexpr (EPI == VSTAR_EPI_NONE && !F8) {
-          if (sq) {
-            // canonical tree (gemm_epilogue.hpp): chunk = (4 + 4 columns), chunk pairs across fq ^ 1, pairs of pairs across
-            // fq ^ 2, the two 32-column halves inside the lane
-            float fa[8], fb[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)pa[m][e]); fb[e] = lp2f((lp_t)pb[m][e]); }
-            float qa = (((fa[0] * fa[0] + fa[1] * fa[1]) + fa[2] * fa[2]) + fa[3] * fa[3]) +
-                       (((fa[4] * fa[4] + fa[5] * fa[5]) + fa[6] * fa[6]) + fa[7] * fa[7]);
-            float qb = (((fb[0] * fb[0] + fb[1] * fb[1]) + fb[2] * fb[2]) + fb[3] * fb[3]) +
-                       (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
-            qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
-            qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
-            if (fq == 0) sq[0] = qa + qb;
-            if (p.stats_sum) {
-              float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
-              float sb = (((fb[0] + fb[1]) + fb[2]) + fb[3]) + (((fb[4] + fb[5]) + fb[6]) + fb[7]);
-              sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-              sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-              if (fq == 0) sq[p.stats_sum] = sa + sb;
-            }
-            sq += 16 * p.sumsq_ld;
-          }
-        }
-      }
-    }
+    // the in-register epilogue (gemm256_direct_epilogue.hpp, shared with gemm4w.hip): this wave IS one virtual wave (wr, wc)
+    gemm256_direct_epilogue<EPI, !F8>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
+      constexpr int m = decltype(mc)::value;
+      a[0] = acc[m][0]; a[1] = acc[m][1]; a[2] = acc[m][2]; a[3] = acc[m][3];
+    });
   } else {
     // bf16 outputs: bias in the accumulator layout, transpose through this wave's private LDS slab — 32 rows at a time, in
     // ring buffer 1 (dead: every wave is past the last barrier; buffer 0 is already receiving the next tile) — then

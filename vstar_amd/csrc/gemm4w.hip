@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
+#include "gemm256_direct_epilogue.hpp"
 #include <type_traits>
 #include <utility>
 
@@ -73,15 +74,9 @@ __device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
                : "n"(B)
                : G4W_ALL_AGPRS);
 }
-template <int... I, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
-
-// The in-register epilogue of ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid: 128 rows x 64 W rows, accumulators in
-// gemm256's layout.  Same arithmetic, rounding points, statistics tree and store pattern as gemm256.hip's direct epilogue (see the
-// comments there: W rows are DMA'd in a permuted order so that a lane's fragments are runs of 8 consecutive output columns).
-// The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes them (16 registers at a time instead of the half's 128).
+// The in-register epilogue of the 128 x 64 half H of the wave's tile = ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid
+// (gemm256_direct_epilogue.hpp, shared with gemm256.hip).  The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes
+// them (16 registers at a time instead of the half's 128), with the folded-norm row scale applied on the way.
 template <int EPI, int H>
 __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
   float rs_v[8];            // RMSNorm / LayerNorm folded into this linear: rstd[row] * (x . (W * norm_w)^T)
@@ -89,7 +84,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
     for (int m = 0; m < 8; ++m) rs_v[m] = p.row_scale[em0 + wr * 128 + m * 16 + fr];
   }
-  auto acc_row = [&](auto mc, f32x4 (&a)[4]) {
+  gemm256_direct_epilogue<EPI, true>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
     constexpr int m = decltype(mc)::value;
     load_acc_row<H, m>(a);
     if (p.row_scale) {
@@ -98,169 +93,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
         for (int e = 0; e < 4; ++e) a[n][e] *= rs_v[m];
     }
-  };
-  constexpr bool SILU = (EPI == VSTAR_EPI_SILU_MUL);
-  bool rope_tile = false;
-  if constexpr (EPI == VSTAR_EPI_NONE) rope_tile = p.rope_cs != nullptr && en0 < p.rope_cols;
-  int col_a, col_b;
-  if (SILU) { col_a = (en0 + wc * 64) / 2 + fq * 8; col_b = col_a; }
-  else if (rope_tile) { col_a = en0 + (wc >> 1) * 128 + (wc & 1) * 32 + fq * 8; col_b = col_a + 64; }
-  else { col_a = en0 + wc * 64 + fq * 8; col_b = col_a + 32; }
-  const int row0 = em0 + wr * 128 + fr;
-  lp_t* crow = (lp_t*)p.C + (int64_t)row0 * p.ldc;
-  if constexpr (SILU) {
-    static_for<8>([&](auto mc) {
-      f32x4 a[4];
-      acc_row(mc, a);
-      lpx8 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = (short)f2lp(act_silu_bf16(rlp(a[0][e])) * rlp(a[1][e]));
-        v[4 + e] = (short)f2lp(act_silu_bf16(rlp(a[2][e])) * rlp(a[3][e]));
-      }
-#ifdef G4W_ABL_NOSTORE
-      asm volatile("" :: "v"(v));
-#else
-      __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
-#endif
-      crow += 16 * p.ldc;
-    });
-  } else {
-    lpx8 pa[8], pb[8];
-    {
-      float bia[8], bib[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) bia[e] = bib[e] = 0.f;
-      if (p.bias) {
-        const lpx8 b0 = *(const lpx8*)(p.bias + col_a), b1 = *(const lpx8*)(p.bias + col_b);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { bia[e] = lp2f((lp_t)b0[e]); bib[e] = lp2f((lp_t)b1[e]); }
-      }
-      if (p.bias) {
-        static_for<8>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          f32x4 a[4];
-          acc_row(mc, a);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pa[m][e] = (short)f2lp(a[0][e] + bia[e]);
-            pa[m][4 + e] = (short)f2lp(a[1][e] + bia[4 + e]);
-            pb[m][e] = (short)f2lp(a[2][e] + bib[e]);
-            pb[m][4 + e] = (short)f2lp(a[3][e] + bib[4 + e]);
-          }
-        });
-      } else {
-        // no bias (every LLaMA linear): 256 adds of +0.0f less per lane on a path that is VALU-bound with one wave per SIMD
-        // (tools/gemm4w_timeline.py: 3.9 us of epilogue arithmetic per tile).  Same bits: an MFMA chain that starts from +0 never
-        // yields -0, the only value x + 0.0f would change.
-        static_for<8>([&](auto mc) {
-          constexpr int m = decltype(mc)::value;
-          f32x4 a[4];
-          acc_row(mc, a);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            pa[m][e] = (short)f2lp(a[0][e]);
-            pa[m][4 + e] = (short)f2lp(a[1][e]);
-            pb[m][e] = (short)f2lp(a[2][e]);
-            pb[m][4 + e] = (short)f2lp(a[3][e]);
-          }
-        });
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (EPI == VSTAR_EPI_NONE) {
-      if (rope_tile) {
-        const int rope_d = (wc & 1) * 32 + fq * 8;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int row = row0 + m * 16;
-          int pos = row % p.rope_S;
-          if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);
-          if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;
-          const lpx8 c8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + rope_d);
-          const lpx8 s8 = *(const lpx8*)(p.rope_cs + (int64_t)pos * 128 + 64 + rope_d);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float c = lp2f((lp_t)c8[e]), sn = lp2f((lp_t)s8[e]);
-            const float xa = lp2f((lp_t)pa[m][e]), xb = lp2f((lp_t)pb[m][e]);
-            pa[m][e] = (short)f2lp(rlp(xa * c) + rlp(-1.0f * xb * sn));
-            pb[m][e] = (short)f2lp(rlp(xb * c) + rlp(1.0f * xa * sn));
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        gemm_epilogue_act8<EPI>(pa[m]);
-        gemm_epilogue_act8<EPI>(pb[m]);
-      }
-    }
-    if (p.res) {
-      __builtin_amdgcn_sched_barrier(0);
-      lpx8 ra[8], rb[8];
-      const lp_t* rrow = p.res + (int64_t)row0 * p.ldr;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        ra[m] = *(const lpx8*)(rrow + col_a);
-        rb[m] = *(const lpx8*)(rrow + col_b);
-        rrow += 16 * p.ldr;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          pa[m][e] = (short)f2lp(lp2f((lp_t)pa[m][e]) + lp2f((lp_t)ra[m][e]));
-          pb[m][e] = (short)f2lp(lp2f((lp_t)pb[m][e]) + lp2f((lp_t)rb[m][e]));
-        }
-    }
-    float* sq = nullptr;
-    if constexpr (EPI == VSTAR_EPI_NONE) {
-      if (p.sumsq_out) sq = p.sumsq_out + (int64_t)row0 * p.sumsq_ld + (en0 + wc * 64) / 64;
-    }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      __builtin_amdgcn_sched_barrier(0);
-#ifdef G4W_ABL_NOSTORE
-      asm volatile("" :: "v"(pa[m]), "v"(pb[m]));
-#else
-#ifdef G4W_PLAIN_STORES
-      if (true) {
-#else
-      if (p.sumsq_out) {
-#endif
-        *(lpx8*)(crow + col_a) = pa[m];
-        *(lpx8*)(crow + col_b) = pb[m];
-      } else {
-        __builtin_nontemporal_store(pa[m], (lpx8*)(crow + col_a));
-        __builtin_nontemporal_store(pb[m], (lpx8*)(crow + col_b));
-      }
-#endif
-      crow += 16 * p.ldc;
-      if constexpr (EPI == VSTAR_EPI_NONE) {
-        if (sq) {
-          float fa[8], fb[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { fa[e] = lp2f((lp_t)pa[m][e]); fb[e] = lp2f((lp_t)pb[m][e]); }
-          float qa = (((fa[0] * fa[0] + fa[1] * fa[1]) + fa[2] * fa[2]) + fa[3] * fa[3]) +
-                     (((fa[4] * fa[4] + fa[5] * fa[5]) + fa[6] * fa[6]) + fa[7] * fa[7]);
-          float qb = (((fb[0] * fb[0] + fb[1] * fb[1]) + fb[2] * fb[2]) + fb[3] * fb[3]) +
-                     (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
-          qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
-          qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
-          if (fq == 0) sq[0] = qa + qb;
-          if (p.stats_sum) {
-            float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
-            float sb = (((fb[0] + fb[1]) + fb[2]) + fb[3]) + (((fb[4] + fb[5]) + fb[6]) + fb[7]);
-            sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
-            sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-            if (fq == 0) sq[p.stats_sum] = sa + sb;
-          }
-          sq += 16 * p.sumsq_ld;
-        }
-      }
-    }
-  }
+  });
 }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
