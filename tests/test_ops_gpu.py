@@ -396,6 +396,30 @@ def test_gemm4w_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res):
         assert bad == 0, (rep, bad)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (2048, 4096, 4096, 0), (1280, 8192, 1024, 4), (20480, 4096, 11008, 0)])
+def test_gemm4w_w8a8_equals_gemm256_w8a8(lib, cuda, M, N, K, epi):
+    """Round 6: the W8A8 instantiation of the 4-wave kernel (v_mfma_scale_f32_16x16x128_f8f6f4 in its own generated K loop: two A
+    fragment sets, W fragments refilled on a rolling basis) against gemm256's on the same quantised operands: same k order per
+    MFMA, same dequantisation and epilogue -> BIT-identical; three repetitions (hand-placed waits)."""
+    g = torch.Generator(device=cuda).manual_seed(M + N + K + epi)
+    n_out = N // 2 if epi == 4 else N
+    A = (torch.randn(M, K, generator=g, device=cuda) * (0.2 + 3 * torch.rand(M, 1, generator=g, device=cuda))).bfloat16()
+    W = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    bias = (torch.randn(N, generator=g, device=cuda) * 0.1).bfloat16() if epi == 0 else None
+    res = (torch.randn(M, n_out, generator=g, device=cuda) * 0.5).bfloat16() if epi == 0 else None
+    outs = []
+    for flag in (_lib.EPI_TILE256, _lib.EPI_TILE4W, _lib.EPI_TILE4W, _lib.EPI_TILE4W):
+        C = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16, device=cuda)
+        rc = lib.vstar_op_gemm_fp8(None, P(A), P(W), P(bias), P(res), P(C), M, N, K, epi | flag, 0, None)
+        assert rc == 0, lib.vstar_last_error(None)
+        torch.cuda.synchronize()
+        assert lib.vstar_op_gemm_last_tile() == (256 if flag == _lib.EPI_TILE256 else _lib.TILE_4W)
+        outs.append(C)
+    assert not torch.isnan(outs[0].float()).any()
+    for c in outs[1:]:
+        assert torch.equal(c.view(torch.int16), outs[0].view(torch.int16))
+
+
 @pytest.mark.parametrize("M,N,K", [(1024, 4096, 256), (2048, 512, 1024)])
 def test_gemm4w_row_scale_and_statistics(lib, cuda, M, N, K):
     """Folded-norm row scale in, sum-of-squares partials out (the LLaMA o_proj / down / q|k|v forms): bit-identical to gemm256."""

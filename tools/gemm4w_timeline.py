@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Where a gemm4w tile's time goes (diagnostic build: tools/build_variant.sh tl4 "-DG4W_TIMELINE" gemm4w [+ -DG4W_ABL_NOSTORE]):
+"""Where a gemm4w tile's time goes (diagnostic build: tools/build_variant.sh tl4 "-DG4W_TIMELINE" gemm4w; the no-store arm of
+profiles/r06_gemm4w_timeline.txt was a switch of the epilogue at that commit):
 wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of workgroups 0 and 100 at
   0 tile start (before the loop statement) | 1 K loop done | 2 next tile's pipeline head issued | 3 epilogue issued (stores in flight)
   | 4 everything this wave issued has completed (vmcnt(0))

@@ -225,6 +225,128 @@ def loop_text(shape, use_pf):
     return L
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# W8A8 text (BASELINE config 5): v_mfma_scale_f32_16x16x128_f8f6f4 (OCP e4m3, block scales fixed at 1.0).  A K-tile is still 128 BYTES
+# of every row (= 128 fp8 elements), the LDS image and the DMA are the bf16 kernel's — but one MFMA eats BOTH 16-byte halves of a
+# lane's fragment (8 consecutive registers: [k 16 fq .. | k 64 + 16 fq ..]), so the two k-halves cannot be double-buffered against each
+# other.  Register plan instead: A fragments of the CURRENT tile in one set of 64 registers while the NEXT tile's are read into the
+# other; the eight W fragments live in ONE set of 64 and are refilled on a rolling basis — W[n] is dead after MFMA 8 n + 7 (W
+# fragment n is srcA of eight consecutive MFMAs), so its registers take tile T+1's W[n] later in the same tile.  64 MFMAs of 32 cycles
+# per K-tile; two barriers per K-tile:
+#     MFMA 0..63 | W[7] of THIS tile read @0,1 (its registers were busy until the previous tile's last MFMA)
+#                | lgkmcnt(0) @3, s_barrier @4         [B1: buffer b fully read -> DMA of tile T+2 into it, 16 pieces @6,8,..,36]
+#                | vmcnt(16) @42, s_barrier @43        [B3: tile T+1 has landed]
+#                | reads for tile T+1 from buffer b^1: A -> the other A set (16 reads), W[0..6] -> the W set (14 reads; W[n] behind MFMA 8n+7)
+#                | lgkmcnt(0) @63
+F8_ASET = [0, 64]          # A fragment m of set s: v[F8_ASET[s] + 8 m ..+7]  (lo = k-chunk fq, hi = k-chunk 4 + fq)
+F8_W = 128                 # W fragment n: v[128 + 8 n ..+7]
+F8_RD = 192                # v192..195 buffer 0 [A lo, A hi, W lo, W hi], v196..199 buffer 1
+F8_VOFF_A, F8_VOFF_W = 200, 208
+F8_PF_DST, F8_PF_OFF, F8_PF_MAX = 216, 218, 220
+F8_SCALE = 222             # 0x7f7f7f7f: E8M0 1.0 for every block
+F8_NV = 223
+
+
+def f8_mfma(j, s):
+    n, m = j >> 3, j & 7
+    acc = (m * 8 + n) * 4
+    w, a = F8_W + 8 * n, F8_ASET[s] + 8 * m
+    return (f"v_mfma_scale_f32_16x16x128_f8f6f4 a[{acc}:{acc + 3}], v[{w}:{w + 7}], v[{a}:{a + 7}], a[{acc}:{acc + 3}], "
+            f"v{F8_SCALE}, v{F8_SCALE} op_sel_hi:[0,0,0]")
+
+
+def f8_rd_a(buf, s):
+    out = []
+    for m in range(8):
+        d = F8_ASET[s] + 8 * m
+        out.append(f"ds_read_b128 v[{d}:{d + 3}], v{F8_RD + buf * 4} offset:{m * 2048}")
+        out.append(f"ds_read_b128 v[{d + 4}:{d + 7}], v{F8_RD + buf * 4 + 1} offset:{m * 2048}")
+    return out
+
+
+def f8_rd_w(buf, n):
+    d = F8_W + 8 * n
+    return [f"ds_read_b128 v[{d}:{d + 3}], v{F8_RD + buf * 4 + 2} offset:{n * 2048}",
+            f"ds_read_b128 v[{d + 4}:{d + 7}], v{F8_RD + buf * 4 + 3} offset:{n * 2048}"]
+
+
+def f8_dma(buf):
+    a = [[f"s_add_u32 m0, %[ldsw], {buf * BUF + i * 1024}", f"buffer_load_dwordx4 v{F8_VOFF_A + i}, %[srda], %[koff] offen lds"] for i in range(8)]
+    w = [[f"s_add_u32 m0, %[ldsw], {buf * BUF + W_REGION + i * 1024}", f"buffer_load_dwordx4 v{F8_VOFF_W + i}, %[srdw], %[koff] offen lds"] for i in range(8)]
+    return a + w
+
+
+F8_SHAPE = dict(w7=[0, 1], b1=4, d=every(6, 2, 16), b3=43, pf=45,
+                # 30 reads of tile T+1: A lo/hi of the eight fragments (slots 44..51), W[0..4] (52..56), W[5] (57: behind MFMA 47), W[6] (58, 59: behind 55)
+                ra=[44 + i // 2 for i in range(16)], rw=[52, 52, 53, 53, 54, 54, 55, 55, 56, 56, 57, 57, 58, 59])
+
+
+def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False):
+    """One K-tile in buffer `buf`, A fragments in set `buf`.  The W[7] reads of THIS tile sit in its first two slots (prologue: `first`
+    tiles find W[7] loaded already)."""
+    sh = F8_SHAPE
+    slots = [[] for _ in range(64)]
+    if not first:
+        for k, r in enumerate(f8_rd_w(buf, 7)):
+            slots[sh["w7"][k]].append(r)
+    slots[sh["b1"] - 1].append("s_waitcnt lgkmcnt(0)")           # W[7] of this tile (needed from MFMA 56 on; also frees buffer `buf`)
+    if next2:
+        slots[sh["b1"]].append("s_barrier")
+        for g, pos in zip(f8_dma(buf), sh["d"]):
+            slots[pos - 1].append(g[0])
+            slots[pos].append(g[1])
+        slots[max(sh["d"]) + 2].append("s_add_u32 %[koff], %[koff], 128")
+    if last:
+        slots[sh["b1"]].append("s_barrier")                      # every wave is done with LDS: the caller may DMA the next output tile's head
+    if next_tile:
+        if use_pf:
+            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({18 if next2 else 0})")
+            if next2:
+                ops = [f"buffer_load_dword v{F8_PF_DST}, v{F8_PF_OFF}, %[srda], 0 offen", f"buffer_load_dword v{F8_PF_DST + 1}, v{F8_PF_OFF + 1}, %[srdw], 0 offen",
+                       f"v_add_u32 v{F8_PF_OFF}, 128, v{F8_PF_OFF}", f"v_add_u32 v{F8_PF_OFF + 1}, 128, v{F8_PF_OFF + 1}",
+                       f"v_min_u32 v{F8_PF_OFF}, v{F8_PF_OFF}, v{F8_PF_MAX}", f"v_min_u32 v{F8_PF_OFF + 1}, v{F8_PF_OFF + 1}, v{F8_PF_MAX + 1}"]
+                for k, op in enumerate(ops):
+                    slots[sh["pf"] + k // 2].append(op)
+        else:
+            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({16 if next2 else 0})")
+        slots[sh["b3"]].append("s_barrier")
+        for k, r in enumerate(f8_rd_a(buf ^ 1, buf ^ 1)):
+            slots[sh["ra"][k]].append(r)
+        wr = [r for n in range(7) for r in f8_rd_w(buf ^ 1, n)]
+        for k, r in enumerate(wr):
+            n = k // 2
+            assert sh["rw"][k] > 8 * n + 7 or sh["rw"][k] >= 8 * n + 7 + 1, (k, n)
+            slots[sh["rw"][k]].append(r)
+        slots[63].append("s_waitcnt lgkmcnt(0)")
+    out = [f"; ---- fp8 K-tile in buffer {buf} ----"]
+    for j in range(64):
+        out.append(f8_mfma(j, buf))
+        out += slots[j]
+    return out
+
+
+def loop_text_f8(use_pf):
+    L = []
+    # the per-lane operands arrive PINNED (gemm4w.hip): v192..195 read addresses of buffer 0, v200..215 piece offsets, v218..221 prefetch
+    for i in range(4):
+        L.append(f"v_add_u32 v{F8_RD + 4 + i}, {BUF}, v{F8_RD + i}")
+    L += [f"v_mov_b32 v{F8_SCALE}, 0x7f7f7f7f"]
+    for a in range(256):
+        L.append(f"v_accvgpr_write_b32 a{a}, 0")
+    # K-tiles 0 and 1 were DMA'd by the caller: wait, publish, fragments of tile 0: A -> set 0, W[0..7]
+    L += ["s_waitcnt vmcnt(0)", "s_barrier"]
+    L += f8_rd_a(0, 0) + [r for n in range(8) for r in f8_rd_w(0, n)]
+    L += ["s_waitcnt lgkmcnt(0)"]
+    # first pair peeled off the loop?  No: tile 0 only differs in not re-reading W[7]; run it as the loop's first iteration with a flag
+    # -> simpler: the text reads W[7] of tile 0 twice (prologue + slots 0, 1 of the tile): 2 redundant reads per OUTPUT tile.
+    L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%=", ".Lg4w_loop_%=:"]
+    L += f8_tile(0, True, True, use_pf) + f8_tile(1, True, True, use_pf)
+    L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%=", ".Lg4w_tail_%=:"]
+    L += f8_tile(0, True, False, use_pf) + f8_tile(1, False, False, use_pf, last=True)
+    L += ["s_nop 15", "s_nop 15"]
+    return L
+
+
 def as_macro(name, L):
     body = "".join('  "%s\\n\\t"\n' % x for x in L if not x.startswith(";"))
     return "#define " + name + " \\\n" + body.replace("\n", " \\\n").rstrip(" \\\n") + "\n\n"
@@ -242,7 +364,11 @@ def main(out_path=None):
         f.write("// GENERATED by tools/gen_gemm4w_asm.py (schedules %s / %s) — do not edit.  The hand-scheduled K loops of gemm4w.hip.\n" % (name, name_pf))
         f.write(as_macro("GEMM4W_LOOP_ASM", L))
         f.write(as_macro("GEMM4W_LOOP_ASM_PF", Lp))
+        f.write(as_macro("GEMM4W_LOOP_ASM_F8", loop_text_f8(False)))
+        f.write(as_macro("GEMM4W_LOOP_ASM_F8_PF", loop_text_f8(True)))
         f.write("#define GEMM4W_CLOBBERS " + clob + ', "memory", "scc"\n')
+        pinned = set(range(192, 196)) | set(range(200, 216)) | set(range(218, 222))
+        f.write("#define GEMM4W_CLOBBERS_F8 " + ", ".join(f'"v{i}"' for i in range(F8_NV) if i not in pinned) + ", " + ", ".join(f'"a{i}"' for i in range(256)) + ', "memory", "scc"\n')
     print(os.path.normpath(path), len(L), "+", len(Lp), "instructions,", sum("v_mfma" in x for x in L), "MFMAs per text")
     return L
 

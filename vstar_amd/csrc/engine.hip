@@ -1512,7 +1512,7 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* A, const uint16_t* W, const 
   if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   const int Npad = (N + 255) / 256 * 256;
-  const int n_out = epilogue == VSTAR_EPI_SILU_MUL ? N / 2 : N;
+  const int n_out = (epilogue & 0xff) == VSTAR_EPI_SILU_MUL ? N / 2 : N;
   uint8_t *Aq = nullptr, *Wq = nullptr;
   float *sa = nullptr, *sw = nullptr;
   hipError_t e = hipMalloc((void**)&Aq, (size_t)M * K);
@@ -1524,6 +1524,9 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* A, const uint16_t* W, const 
   GemmParams p{};
   p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.bias = bias; p.res = res; p.ldr = n_out; p.C = C; p.ldc = n_out;
   p.M = M; p.N = N; p.K = K; p.a_scale = sa; p.w_scale = sw;
+  // VSTAR_EPI_TILE256 / VSTAR_EPI_TILE4W OR-ed into `epilogue`: force the 8-wave / the 4-wave W8A8 kernel (round 6; bit-identity tests)
+  p.tile_force = (epilogue & VSTAR_EPI_TILE4W) ? GEMM_TILE_4W : (epilogue & VSTAR_EPI_TILE256) ? 256 : 0;
+  epilogue &= 0xff;
   if (e == hipSuccess && !gemm256_eligible(p)) { tls_error() = "shape not accepted by the W8A8 kernel"; e = hipErrorInvalidValue; }
   if (e == hipSuccess) e = gemm_lp(p, epilogue, false, s);
   if (e == hipSuccess && iters > 0 && gemm_ms) {

@@ -77,14 +77,43 @@ __device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
 // The in-register epilogue of the 128 x 64 half H of the wave's tile = ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid
 // (gemm256_direct_epilogue.hpp, shared with gemm256.hip).  The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes
 // them (16 registers at a time instead of the half's 128), with the folded-norm row scale applied on the way.
-template <int EPI, int H>
+template <int EPI, int H, bool F8>
 __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
+  if constexpr (F8) {
+    // W8A8: per-row activation scale x per-output-channel weight scale, the latter in the permuted-row order of the direct tile (gemm256.hip)
+    float sa[8], sw[4][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) sa[m] = p.a_scale[em0 + wr * 128 + m * 16 + fr];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      int sc;
+      if (EPI == VSTAR_EPI_SILU_MUL) { const int jo = fq * 8 + (n >> 1) * 4; sc = wc * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15); }
+      else if (EPI == VSTAR_EPI_NONE && p.rope_cs != nullptr && en0 < p.rope_cols) sc = (wc >> 1) * 128 + (n >> 1) * 64 + (wc & 1) * 32 + fq * 8 + (n & 1) * 4;
+      else sc = wc * 64 + (n >> 1) * 32 + fq * 8 + (n & 1) * 4;
+      const f32x4 t = *(const f32x4*)(p.w_scale + en0 + sc);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sw[n][e] = t[e];
+    }
+    gemm256_direct_epilogue<EPI, false>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
+      // (no contraction: gemm256 dequantises in a loop of its own, far from the bias add; here the two meet after inlining and
+      // `acc * scale + bias` as ONE fma rounds differently — 4 of 524288 outputs in the first W8A8 bias test)
+#pragma clang fp contract(off)
+      constexpr int m = decltype(mc)::value;
+      load_acc_row<H, m>(a);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[n][e] *= sa[m] * sw[n][e];
+    });
+    return;
+  }
   float rs_v[8];            // RMSNorm / LayerNorm folded into this linear: rstd[row] * (x . (W * norm_w)^T)
   if (p.row_scale) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) rs_v[m] = p.row_scale[em0 + wr * 128 + m * 16 + fr];
   }
   gemm256_direct_epilogue<EPI, true>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
+#pragma clang fp contract(off)      // (row scale x accumulator must not fuse with the bias add that follows after inlining, see the W8A8 branch)
     constexpr int m = decltype(mc)::value;
     load_acc_row<H, m>(a);
     if (p.row_scale) {
@@ -103,9 +132,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define G4W_PF_LEAD 4      // the L2 prefetch of a K-tile runs this many K-tiles ahead of the tile being computed (its DMA: two ahead)
 #endif
 
-// PF: the loop text with the L2 prefetch duty (long K: the launcher decides)
-template <int EPI, bool PF>
+// PF: the loop text with the L2 prefetch duty (long K: the launcher decides).  F8: W8A8 (BASELINE config 5) — A and W are OCP fp8 e4m3
+// bytes, a K-tile is still 128 bytes of every row (128 elements), one v_mfma_scale_f32_16x16x128_f8f6f4 replaces four bf16 MFMAs, the
+// accumulators are dequantised (per-row x per-output-channel scale) on their way out of the AGPRs.
+template <int EPI, bool PF, bool F8>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
+  constexpr int ES = F8 ? 1 : 2;                       // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   int lane = tid & 63;
@@ -118,7 +150,34 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   int cur_wkind = -1;
   uint32_t va[8], vw[8];
   int m0 = 0, n0 = 0, pi = 0;
-  const lp_t *abase = nullptr, *wbase = nullptr;
+  const char *abase = nullptr, *wbase = nullptr;
+  // wave w moves the 8-row pieces g = 8 w + i of the A tile and of the W tile: per-lane byte offsets at k = 0, W rows in the order of
+  // the tile's kind `cur_wkind` (1 plain / SiLU, 2 RoPE)
+  auto piece_offsets = [&](int ln) {
+    const int st_r = ln >> 3, st_c = ln & 7;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (wave * 8 + i) * 8 + st_r;
+      const int cg = st_c ^ ((row >> 1) & 7);
+      va[i] = (uint32_t)((int64_t)row * p.lda * ES + cg * 16);
+      const int wcr = row >> 6, n = (row >> 4) & 3, ii = row & 15;
+      int wrow;
+      if (EPI == VSTAR_EPI_SILU_MUL) {
+        const int jo = (ii >> 2) * 8 + (n >> 1) * 4 + (ii & 3);
+        wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);
+      } else if (cur_wkind == 2) {
+        wrow = (wcr >> 1) * 128 + (n >> 1) * 64 + (wcr & 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
+      } else {
+        wrow = wcr * 64 + (n >> 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
+      }
+      vw[i] = (uint32_t)((int64_t)wrow * p.K * ES + cg * 16);
+    }
+  };
+  auto fresh_lane = []() {      // the lane id through an opaque instruction pair: ends every live range that derives from the old one
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    return ln;
+  };
   // ---- tile id -> (m0, n0): XCD-aware bijective remap, then GROUP_M ordering (gemm256.hip); DMA source offsets of that tile ----
   auto set_tile = [&](int bid) {
     int t;
@@ -138,31 +197,14 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     bool rope_t = false;
     if constexpr (EPI == VSTAR_EPI_NONE) rope_t = p.rope_cs != nullptr && n0 < p.rope_cols;
     const int wkind = (EPI != VSTAR_EPI_SILU_MUL && rope_t) ? 2 : 1;
-    // wave w moves the 8-row pieces g = 8 w + i of the A tile and of the W tile; the per-lane part of a source offset does not
-    // depend on the tile (the scalar bases carry it), only on the W row order of the tile's kind
+    // the per-lane part of a DMA source offset does not depend on the tile (the scalar bases carry it), only on the W row order of the
+    // tile's kind.  (W8A8: recomputed around every loop statement anyway, see there.)
     if (wkind != cur_wkind) {
       cur_wkind = wkind;
-      const int st_r = lane >> 3, st_c = lane & 7;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int row = (wave * 8 + i) * 8 + st_r;
-        const int cg = st_c ^ ((row >> 1) & 7);
-        va[i] = (uint32_t)((int64_t)row * p.lda * 2 + cg * 16);
-        const int wcr = row >> 6, n = (row >> 4) & 3, ii = row & 15;
-        int wrow;
-        if (EPI == VSTAR_EPI_SILU_MUL) {
-          const int jo = (ii >> 2) * 8 + (n >> 1) * 4 + (ii & 3);
-          wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);
-        } else if (wkind == 2) {
-          wrow = (wcr >> 1) * 128 + (n >> 1) * 64 + (wcr & 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
-        } else {
-          wrow = wcr * 64 + (n >> 1) * 32 + (ii >> 2) * 8 + (n & 1) * 4 + (ii & 3);
-        }
-        vw[i] = (uint32_t)((int64_t)wrow * p.K * 2 + cg * 16);
-      }
+      piece_offsets(lane);
     }
-    abase = p.A + (int64_t)m0 * p.lda;
-    wbase = p.W + (int64_t)n0 * p.K;
+    abase = (const char*)p.A + (int64_t)m0 * p.lda * ES;
+    wbase = (const char*)p.W + (int64_t)n0 * p.K * ES;
   };
   // K-tiles 0 and 1 of the current tile -> LDS buffers 0 and 1 (32 DMA pieces per wave); the loop text starts behind a vmcnt(0)
   auto issue_head = [&]() {
@@ -170,10 +212,10 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)abase + va[i] + t * 128), (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(abase + va[i] + t * 128), (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, 0, 0);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)wbase + vw[i] + t * 128), (lptr_t)(smem + t * 65536 + 32768 + wave * 8192 + i * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wbase + vw[i] + t * 128), (lptr_t)(smem + t * 65536 + 32768 + wave * 8192 + i * 1024), 16, 0, 0);
     }
   };
   int bid = blockIdx.x;
@@ -199,27 +241,48 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     // tiles; of the A row-tile's 256 lines per K-tile this CU touches the 32 of its patch column, of the W column-tile's 256 lines
     // the 64 of its patch row.  A wrong guess of the patch position (ragged groups, drifted workgroups) costs speed, never results.
     const int pj = ((bid >> 3) >> 2) & 7;
-    const uint32_t kb_last = (uint32_t)(p.K - 64) * 2;
+    const uint32_t kb_last = (uint32_t)(p.K * ES - 128);
     const uint32_t pf_lead = (uint32_t)G4W_PF_LEAD * 128 < kb_last ? (uint32_t)G4W_PF_LEAD * 128 : kb_last;
-    const uint32_t pfa0 = (uint32_t)((int64_t)(pj * 32 + wave * 8 + (lane & 7)) * p.lda * 2);
-    const uint32_t pfw0 = (uint32_t)((int64_t)((pi & 3) * 64 + wave * 16 + (lane & 15)) * p.K * 2);
+    const uint32_t pfa0 = (uint32_t)((int64_t)(pj * 32 + wave * 8 + (lane & 7)) * p.lda * ES);
+    const uint32_t pfw0 = (uint32_t)((int64_t)((pi & 3) * 64 + wave * 16 + (lane & 15)) * p.K * ES);
     const uint32_t pfa = pfa0 + pf_lead, pfw = pfw0 + pf_lead, pfamax = pfa0 + kb_last, pfwmax = pfw0 + kb_last;
-    uint32_t cnt = (uint32_t)(p.K / 128 - 1);          // two K-tiles per loop iteration, the last pair is peeled
+    uint32_t cnt = (uint32_t)(p.K * ES / 256 - 1);     // two K-tiles (of 128 bytes per row) per loop iteration, the last pair is peeled
     // buffer resource descriptors over the tile's rows (raw buffer: stride 0, no bound in practice, dword 3 = the gfx9 raw-buffer word)
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     const i32x4 srda = {(int)(uint32_t)(uintptr_t)abase, (int)(((uintptr_t)abase >> 32) & 0xffff), -1, 0x00020000};
     const i32x4 srdw = {(int)(uint32_t)(uintptr_t)wbase, (int)(((uintptr_t)wbase >> 32) & 0xffff), -1, 0x00020000};
     uint32_t koff = 256;                               // K-tiles 0 and 1 are in flight (issue_head): the loop's first pieces are K-tile 2
-#define G4W_OPERANDS                                                                                                                 \
+#define G4W_OPERANDS(CLOB)                                                                                                           \
     : [cnt] "+s"(cnt), [koff] "+s"(koff)                                                                                             \
     : [srda] "s"(srda), [srdw] "s"(srdw), [ldsw] "s"(ldsw), [rd0] "v"(rd[0]), [rd1] "v"(rd[1]), [rd2] "v"(rd[2]),                    \
       [rd3] "v"(rd[3]), [va0] "v"(va[0]), [va1] "v"(va[1]), [va2] "v"(va[2]), [va3] "v"(va[3]),                                    \
       [va4] "v"(va[4]), [va5] "v"(va[5]), [va6] "v"(va[6]), [va7] "v"(va[7]), [vw0] "v"(vw[0]),                                    \
       [vw1] "v"(vw[1]), [vw2] "v"(vw[2]), [vw3] "v"(vw[3]), [vw4] "v"(vw[4]), [vw5] "v"(vw[5]),                                    \
       [vw6] "v"(vw[6]), [vw7] "v"(vw[7]), [pfa] "v"(pfa), [pfw] "v"(pfw), [pfamax] "v"(pfamax), [pfwmax] "v"(pfwmax)               \
-    : GEMM4W_CLOBBERS
-    if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_PF G4W_OPERANDS);
-    else asm volatile(GEMM4W_LOOP_ASM G4W_OPERANDS);
+    : CLOB
+    if constexpr (F8) {
+      // The W8A8 text uses 223 VGPRs (two A fragment sets + the rolling W set = 192): its per-lane operands are PINNED to the
+      // registers the text reads them from, and everything per-lane is recomputed from a fresh lane id right here and again behind the
+      // statement — a value that lives across it (or an input that needs a register of its own) has nowhere to be.
+      typedef __attribute__((ext_vector_type(8))) int i32x8;
+      piece_offsets(fresh_lane());
+      i32x8 va8 = {(int)va[0], (int)va[1], (int)va[2], (int)va[3], (int)va[4], (int)va[5], (int)va[6], (int)va[7]};
+      i32x8 vw8 = {(int)vw[0], (int)vw[1], (int)vw[2], (int)vw[3], (int)vw[4], (int)vw[5], (int)vw[6], (int)vw[7]};
+      i32x4 rd4 = {(int)rd[0], (int)rd[1], (int)rd[2], (int)rd[3]};
+      i32x4 pf4 = {(int)pfa, (int)pfw, (int)pfamax, (int)pfwmax};
+#define G4W_OPERANDS_F8                                                                                                              \
+    : [cnt] "+s"(cnt), [koff] "+s"(koff), [va] "+{v[200:207]}"(va8), [vw] "+{v[208:215]}"(vw8), [pf] "+{v[218:221]}"(pf4)            \
+    : [srda] "s"(srda), [srdw] "s"(srdw), [ldsw] "s"(ldsw), [rd] "{v[192:195]}"(rd4)                                                \
+    : GEMM4W_CLOBBERS_F8
+      if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_F8_PF G4W_OPERANDS_F8);
+      else asm volatile(GEMM4W_LOOP_ASM_F8 G4W_OPERANDS_F8);
+#undef G4W_OPERANDS_F8
+      cur_wkind = -1;             // the offsets died with the statement: the next set_tile recomputes them (from the fresh lane id below)
+      lane = fresh_lane();
+    } else {
+      if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_PF G4W_OPERANDS(GEMM4W_CLOBBERS));
+      else asm volatile(GEMM4W_LOOP_ASM G4W_OPERANDS(GEMM4W_CLOBBERS));
+    }
 #undef G4W_OPERANDS
     G4W_STAMP(1);
     // ---- next tile: its K-tiles 0 and 1 go into the (dead: the loop text ends behind a barrier) LDS buffers NOW, so that the
@@ -239,8 +302,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     if (!(p.debug_flags & 2)) {
 #endif
       const int fr = lane & 15, fq = lane >> 4;
-      direct_epilogue_half<EPI, 0>(p, em0, en0, wr, wc2 * 2, fr, fq);
-      direct_epilogue_half<EPI, 1>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
+      direct_epilogue_half<EPI, 0, F8>(p, em0, en0, wr, wc2 * 2, fr, fq);
+      direct_epilogue_half<EPI, 1, F8>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
     }
     G4W_STAMP(3);
 #ifdef G4W_TIMELINE
@@ -252,11 +315,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   }
 }
 
-template <int EPI, bool PF>
+template <int EPI, bool PF, bool F8 = false>
 hipError_t launch(const GemmParams& p, hipStream_t s) {
   if (gemm_plan_only()) return hipSuccess;
   static bool attr_done = false;
-  auto kern = gemm4w_kernel<EPI, PF>;
+  auto kern = gemm4w_kernel<EPI, PF, F8>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return e;
@@ -278,7 +341,15 @@ extern "C" int vstar_debug_gemm4w_timeline(unsigned long long* out) {     // 2 x
 
 // Launches made of interior tiles that take gemm256's direct epilogue (see the header comment for the domain).
 bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
-  if (out_f32 || p.a_scale || p.norm_w) return false;
+#ifdef VSTAR_LP_F16
+  if (p.a_scale) return false;
+#endif
+  if (out_f32 || p.norm_w) return false;
+  if (p.a_scale) {      // W8A8: the two epilogues the LLaMA linears use; K counts fp8 elements, two K-tiles of 128 per loop iteration
+    if (!p.w_scale || (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_SILU_MUL) || p.K % 256 || p.row_scale || p.sumsq_out) return false;
+    static const bool f8_on = [] { const char* e = getenv("VSTAR_GEMM4W_F8"); return !e || atoi(e) != 0; }();
+    if (!f8_on) return false;
+  }
   if (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_QUICK_GELU && epilogue != VSTAR_EPI_RELU && epilogue != VSTAR_EPI_SILU_MUL) return false;
   if (p.M < 1024 || p.M % BM || p.N % BN || p.K % 128 || p.K < 128) return false;
   if (p.a_group > 0 || p.c_group > 0 || (p.debug_flags & 5)) return false;
@@ -296,7 +367,14 @@ hipError_t gemm4w_lp(const GemmParams& p, int epilogue, hipStream_t s) {
   // operand of 451 MB, past the Infinity Cache) +2 - 5 %, K = 4096 -1 - 2 % (its extra requests cost more energy than the shorter
   // stalls return).  VSTAR_GEMM4W_PF = 0 / 1 forces it off / on (A/B runs).
   static const int env_pf = [] { const char* e = getenv("VSTAR_GEMM4W_PF"); return e ? atoi(e) : -1; }();
-  const bool pf = env_pf >= 0 ? env_pf != 0 : p.K >= 8192;
+  const bool pf = env_pf >= 0 ? env_pf != 0 : (int64_t)p.K * (p.a_scale ? 1 : 2) >= 16384;      // K-tiles >= 128
+#ifndef VSTAR_LP_F16
+  if (p.a_scale) {
+    if (epilogue == VSTAR_EPI_NONE) return pf ? launch<VSTAR_EPI_NONE, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true>(p, s);
+    if (epilogue == VSTAR_EPI_SILU_MUL) return pf ? launch<VSTAR_EPI_SILU_MUL, true, true>(p, s) : launch<VSTAR_EPI_SILU_MUL, false, true>(p, s);
+    return hipErrorInvalidValue;
+  }
+#endif
 #define G4W_CASE(E) case E: return pf ? launch<E, true>(p, s) : launch<E, false>(p, s);
   switch (epilogue) {
     G4W_CASE(VSTAR_EPI_NONE)
