@@ -312,6 +312,29 @@ int vstar_op_gemm_plan(int M, int N, int K, int epilogue, int has_residual, int 
  * iters > 0: the GEMM alone is repeated `iters` times between HIP events and *gemm_ms receives the mean (benchmarks). */
 int vstar_op_gemm_fp8(void* stream, const uint16_t* dev_A, const uint16_t* dev_W, const uint16_t* dev_bias,
                       const uint16_t* dev_residual, uint16_t* dev_C, int M, int N, int K, int epilogue, int iters, float* gemm_ms);
+/* Block-scaled W8A8 (round 6; csrc/mx.hpp): the inputs of o_proj / down_proj as OCP e4m3 bytes with ONE E8M0 byte per row and 32
+ * consecutive k (the smallest power of two that brings the block's largest magnitude to <= 448), applied inside
+ * v_mfma_scale_f32_16x16x128_f8f6f4 per lane — so the PRODUCERS (attention epilogue, gate|up epilogue) quantise, and the two stand-alone
+ * per-token passes of the round-3 scheme disappear.  The engine uses it when llm_w8a8 is set and the step's row count is a multiple of
+ * 256 (VSTAR_W8A8_MX=0 in the environment keeps the per-token scheme); vstar_w8a8_mx_active tells which one the last step ran.
+ * Scale bytes are TILE-MAJOR (vstar_op_mx_scale_offset(row, k / 32, rows)); rows % 128 == 0, cols % 128 == 0.  The reference has no
+ * fp8 path: oracle/vsm_oracle.py::mx_fake_quant restates the arithmetic.  Op-level doors (device pointers, synchronous):
+ *   vstar_op_quantize_mx     X [rows, cols] bf16 -> q [rows, cols] fp8 + scales (the stand-alone form the fused producers must equal)
+ *   vstar_op_gemm_mx         C [M, N] bf16 = (Aq, a_scales) . quant_per_channel(W)^T (+ residual); M % 256 == 0, N % 256 == 0, K % 256 == 0
+ *   vstar_op_gemm_fp8_mxout  per-token-quantised A . W^T with W rows interleaved gate|up (16 | 16), SiLU(gate) * up written as fp8 + scales
+ *                            [M, N / 2] — same bytes as vstar_op_gemm_fp8(..., VSTAR_EPI_SILU_MUL) followed by vstar_op_quantize_mx
+ *                            (iters / gemm_ms as in vstar_op_gemm_fp8)
+ *   vstar_op_attention_mx    causal D = 128 attention on a fused qkv buffer, output [B*S, H*128] as fp8 + scales — same bytes as
+ *                            vstar_op_attention(rope_theta = 0) followed by vstar_op_quantize_mx */
+size_t vstar_op_mx_scale_bytes(int rows, int cols);
+int64_t vstar_op_mx_scale_offset(int row, int k_block, int rows);
+int vstar_op_quantize_mx(void* stream, const uint16_t* dev_X, uint8_t* dev_q, uint8_t* dev_scales, int rows, int cols);
+int vstar_op_gemm_mx(void* stream, const uint8_t* dev_Aq, const uint8_t* dev_a_scales, const uint16_t* dev_W, const uint16_t* dev_residual,
+                     uint16_t* dev_C, int M, int N, int K, int iters, float* gemm_ms);
+int vstar_op_gemm_fp8_mxout(void* stream, const uint16_t* dev_A, const uint16_t* dev_W, uint8_t* dev_C8, uint8_t* dev_c_scales, int M, int N,
+                            int K, int iters, float* gemm_ms);
+int vstar_op_attention_mx(void* stream, const uint16_t* dev_qkv, uint8_t* dev_out8, uint8_t* dev_scales, int B, int S, int H);
+int vstar_w8a8_mx_active(vstar_handle* h);
 /* LayerNorm over the last dim (eps, affine) / LLaMA RMSNorm.  bf16 in/out. */
 int vstar_op_layernorm(void* stream, const uint16_t* dev_x, const uint16_t* dev_gamma, const uint16_t* dev_beta,
                        uint16_t* dev_y, int rows, int cols, float eps);

@@ -135,12 +135,37 @@ def linear_w8a8(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return ((xq @ wq.T) * sx * sw.transpose(-1, -2)).to(x.dtype)
 
 
+def mx_fake_quant(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Block-scaled (MX style) OCP e4m3 quantisation as the engine's W8A8 mode does it for the inputs of o_proj / down_proj since round 6
+    (vstar_amd/csrc/mx.hpp; the reference has no fp8 path): blocks of 32 consecutive values along the last dim, ONE E8M0 byte e per
+    block = the smallest power of two 2^(e - 127) with amax / 2^(e - 127) <= 448 — in integer arithmetic on the fp32 bits of amax
+    (= 1.f x 2^E): e = E + 127 - 8, plus one when 1.f > 1.75 — and value * 2^(127 - e) rounded to nearest-even e4m3.  Returns the
+    DECODED values (fp32, code x block scale) and the E8M0 bytes [..., n / 32]."""
+    xf = x.float()
+    blk = xf.reshape(*xf.shape[:-1], xf.shape[-1] // 32, 32)
+    amax = blk.abs().amax(dim=-1, keepdim=True).contiguous()
+    bits = amax.view(torch.int32)
+    e = ((bits >> 23) - 8 + ((bits & 0x7FFFFF) > 0x600000).to(torch.int32)).clamp_min(0)
+    inv = ((254 - e) << 23).view(torch.float32)                      # 2^(127 - e), exact
+    codes = (blk * inv).to(torch.float8_e4m3fn).float()
+    scale = torch.ldexp(torch.ones_like(amax), e - 127)
+    return (codes * scale).reshape(xf.shape), e.squeeze(-1).to(torch.uint8)
+
+
+def linear_w8a8_mx(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """x @ w.T with block-scaled activations (mx_fake_quant) and per-output-channel weight scales, fp32 accumulation."""
+    xd, _ = mx_fake_quant(x)
+    wq, sw = fp8_fake_quant(w)
+    return ((xd @ wq.T) * sw.transpose(-1, -2)).to(x.dtype)
+
+
 def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, theta: float,
-                  final_norm: bool = True, w8a8: bool = False) -> torch.Tensor:
+                  final_norm: bool = True, w8a8: bool = False, mx: bool = False) -> torch.Tensor:
     """w8a8: the four big linears of every block on fake-quantised operands, as the engine's config-5 mode runs them —
-    except o_proj / MLP of the LAST block, which the engine evaluates on the few needed rows with the 16-bit weights."""
+    except o_proj / MLP of the LAST block, which the engine evaluates on the few needed rows with the 16-bit weights.
+    mx (with w8a8): the inputs of o_proj and down_proj block-scaled (the engine's scheme when the step's rows are a multiple of 256)."""
     B, S, H = x.shape
-    lin8 = (lambda key, t: linear_w8a8(t, sd[key + ".weight"])) if w8a8 else None
+    lin8 = (lambda key, t: (linear_w8a8_mx if mx and key.endswith(("o_proj", "down_proj")) else linear_w8a8)(t, sd[key + ".weight"])) if w8a8 else None
     hd = H // heads
     cos, sin = rope_tables(S, hd, theta, x.dtype, x.device)
     mask = torch.full((S, S), float("-inf"), device=x.device).triu(1)
@@ -329,16 +354,17 @@ def upsample_mask(low_res: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
 # The whole path
 # ------------------------------------------------------------------------------------------------------------
 def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.Tensor], input_ids: torch.Tensor,
-                loc_token_idx: int, verify_pos: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                loc_token_idx: int, verify_pos: Optional[torch.Tensor] = None, w8a8_mx: bool = False) -> Dict[str, torch.Tensor]:
     """model_forward(inference=True) batched over independent crops (each crop = one reference call with batch 1).
-    `cfg` is a vstar_amd.config.VSMConfig (only its integer fields are read)."""
+    `cfg` is a vstar_amd.config.VSMConfig (only its integer fields are read).  w8a8_mx: with cfg.llm_w8a8, the block-scaled scheme for
+    the inputs of o_proj / down_proj (what the engine ran: VstarEngine.w8a8_mx_active())."""
     dt = sd["model.norm.weight"].dtype
     P = (cfg.clip_image_size // cfg.clip_patch) ** 2
     feats = clip_features(sd, images_clip.to(dt), cfg.clip_heads, cfg.clip_layers, cfg.clip_select_layer)
     proj = _lin(sd, "model.mm_projector", feats)
     x = splice(sd, input_ids, proj)
     hidden = llama_prefill(sd, x, cfg.llm_heads, cfg.llm_layers, cfg.llm_rms_eps, cfg.llm_rope_theta,
-                           w8a8=bool(getattr(cfg, "llm_w8a8", 0)))
+                           w8a8=bool(getattr(cfg, "llm_w8a8", 0)), mx=w8a8_mx)
     # loc_token_mask = (input_ids[:,1:] == loc) shifted right by P-1 (VSM.py:224-235,465-473): selects the hidden
     # state at spliced index idx([LOC]) - 1 + (P - 1)
     B = input_ids.shape[0]

@@ -382,6 +382,7 @@ def test_w8a8_mode_matches_fake_quant_oracle(cuda):
     e8.load_state_dict(sd)
     out8 = e8.score_batch(clip, owl, ids.numpy(), loc)
     h8 = e8.debug_read("llm_hidden_loc", B * base.llm_hidden).reshape(B, -1)
+    assert not e8.w8a8_mx_active()                                     # 4 x 279 rows: not a multiple of 256 -> the per-token scheme
     e16 = engine_for(base, 0)
     out16 = e16.score_batch(clip, owl, ids.numpy(), loc)
     h16 = e16.debug_read("llm_hidden_loc", B * base.llm_hidden).reshape(B, -1)
@@ -425,9 +426,11 @@ def test_w8a8_real_widths(cuda):
         eng.load_state_dict(sd)
         out = eng.score_batch(clip, owl, ids.numpy(), loc)
         res[name] = (eng.debug_read("llm_hidden_loc", B * cfg.llm_hidden).reshape(B, -1), out)
+        mx = eng.w8a8_mx_active()
         eng.close()
+    assert mx == (os.environ.get("VSTAR_W8A8_MX", "1") != "0")          # 2 x 640 rows: the block-scaled scheme (round 6) unless switched off
     sd32 = {k: v.float() for k, v in sd.items()}
-    ref8 = vsm_oracle.vsm_forward(sd32, cfg8, clip.float(), owl.float(), ids, loc_id)
+    ref8 = vsm_oracle.vsm_forward(sd32, cfg8, clip.float(), owl.float(), ids, loc_id, w8a8_mx=mx)
     rep = {"hidden w8a8 vs fake-quant oracle": rel_l2(res["w8a8"][0], ref8["llm_hidden_loc"].numpy()),
            "hidden w8a8 vs bf16 engine": rel_l2(res["w8a8"][0], res["bf16"][0]),
            "logits w8a8 vs fake-quant oracle": rel_l2(res["w8a8"][1]["pred_logits"], ref8["pred_logits"].numpy()),

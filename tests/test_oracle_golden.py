@@ -65,3 +65,23 @@ def test_fp8_fake_quant_helpers():
     w = torch.randn(64, 512, generator=g) / 512 ** 0.5
     y, ref = vsm_oracle.linear_w8a8(x, w), x @ w.T
     assert float((y - ref).norm() / ref.norm()) < 0.05
+
+
+def test_mx_fake_quant_and_scale_layout(lib):
+    """Block-scaled fp8 (round 6, vstar_amd/csrc/mx.hpp): the oracle's restatement picks the SMALLEST power of two that brings a block's
+    largest magnitude to <= 448, decodes within e4m3's rounding error, and the tile-major scale layout the library exports is a bijection
+    (host arithmetic only: no GPU needed)."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(128, 256, generator=g) * torch.rand(128, 1, generator=g) * 5).bfloat16()
+    x[3, 64:96] = 0
+    dec, e = vsm_oracle.mx_fake_quant(x)
+    amax = x.float().view(128, 8, 32).abs().amax(-1)
+    ratio = amax / torch.ldexp(torch.ones(1), e.int() - 127)
+    assert ratio.max() <= 448 and ratio[amax > 0].min() > 224
+    assert e[3, 2] == 0 and dec[3, 64:96].abs().max() == 0
+    assert (dec - x.float()).norm() / x.float().norm() < 0.04            # three mantissa bits
+    y = vsm_oracle.linear_w8a8_mx(x, torch.randn(64, 256, generator=g).bfloat16())
+    assert y.shape == (128, 64) and torch.isfinite(y.float()).all()
+    offs = {lib.vstar_op_mx_scale_offset(r, kb, 256) for r in range(256) for kb in range(8)}
+    assert offs == set(range(256 * 8)) and lib.vstar_op_mx_scale_bytes(256, 256) == 2048
+    assert lib.vstar_op_mx_scale_bytes(100, 256) == 0

@@ -31,5 +31,22 @@ for name, N, K, epi in [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate_up
             t = ctypes.c_float(0)
             assert lib.vstar_op_gemm_fp8(None, P(a), P(w), None, None, P(c), M, N, Kp, epi | flag, 10, ctypes.byref(t)) == 0, lib.vstar_last_error(None)
             best[flag] = min(best[flag], t.value)
+    # block-scaled activations (csrc/mx.hpp): o / down CONSUME them (scales inside the MFMA), gate|up PRODUCES them (quantising epilogue)
+    mxs = ""
+    if Kp == K and M % 256 == 0:
+        t = ctypes.c_float(0); bm = 1e9
+        if epi == 4:
+            q8 = torch.empty(M, n_out, device=dev, dtype=torch.uint8); sc = torch.empty(lib.vstar_op_mx_scale_bytes(M, n_out), device=dev, dtype=torch.uint8)
+            for _ in range(3):
+                assert lib.vstar_op_gemm_fp8_mxout(None, P(a), P(w), P(q8), P(sc), M, N, K, 10, ctypes.byref(t)) == 0, lib.vstar_last_error(None)
+                bm = min(bm, t.value)
+            mxs = f"  | mx out {fl / bm / 1e9:7.0f} x{best[0x800] / bm:.3f}"
+        elif name != "qkv":
+            q8 = torch.empty(M, K, device=dev, dtype=torch.uint8); sc = torch.empty(lib.vstar_op_mx_scale_bytes(M, K), device=dev, dtype=torch.uint8)
+            assert lib.vstar_op_quantize_mx(None, P(a), P(q8), P(sc), M, K) == 0
+            for _ in range(3):
+                assert lib.vstar_op_gemm_mx(None, P(q8), P(sc), P(w), None, P(c), M, N, K, 10, ctypes.byref(t)) == 0, lib.vstar_last_error(None)
+                bm = min(bm, t.value)
+            mxs = f"  | mx in  {fl / bm / 1e9:7.0f} x{best[0x800] / bm:.3f}"
     print(f"{name:22s} {N:6d} {K:6d} {ms.value:8.3f} {fl / ms.value / 1e9:9.1f} {bms:8.3f} {fl / bms / 1e9:9.1f} {bms / ms.value:5.2f}   | "
-          f"{fl / best[0x400] / 1e9:7.0f} {fl / best[0x800] / 1e9:7.0f}  x{best[0x400] / best[0x800]:.3f}")
+          f"{fl / best[0x400] / 1e9:7.0f} {fl / best[0x800] / 1e9:7.0f}  x{best[0x400] / best[0x800]:.3f}" + mxs)

@@ -245,14 +245,26 @@ F8_VOFF_A, F8_VOFF_W = 200, 208
 F8_PF_DST, F8_PF_OFF, F8_PF_MAX = 216, 218, 220
 F8_SCALE = 222             # 0x7f7f7f7f: E8M0 1.0 for every block
 F8_NV = 223
+# MX variant (block-scaled activations): the E8M0 bytes of the A rows, one per (row, 32 k), arrive TILE-MAJOR — for K-tile T the 256 rows
+# of the tile are 1 KiB [row block of 128][lane = k-block * 16 + row % 16][fragment m = 0..7] (quant.hip::mx_scale_offset) — as a 17th DMA
+# piece per K-tile (256 B per wave) behind the operand pieces; every lane reads ITS eight bytes (ds_read_b64) with the A fragments, and
+# MFMA (m, n) takes byte m & 3 of register m >> 2 through op_sel / op_sel_hi (profiles/r06_mfma_scale_probe.txt: the byte of lane l scales
+# row l % 16, k-block l / 16 of src1; byte index = op_sel + 2 op_sel_hi).  W keeps block scale 1.0 and its per-channel fp32 scale.
+F8_SC = [224, 226]         # scale bytes of A set s: v[F8_SC[s] .. +1]
+F8_SRD, F8_SOFF = 228, 229 # pinned: scale read address (buffer 0), per-lane byte offset of the scale DMA
+F8_NV_MX = 230
+F8_SCALE_LDS = 2 * 65536   # the two 1-KiB scale slots sit behind the two operand buffers
 
 
-def f8_mfma(j, s):
+def f8_mfma(j, s, mx=False):
     n, m = j >> 3, j & 7
     acc = (m * 8 + n) * 4
     w, a = F8_W + 8 * n, F8_ASET[s] + 8 * m
-    return (f"v_mfma_scale_f32_16x16x128_f8f6f4 a[{acc}:{acc + 3}], v[{w}:{w + 7}], v[{a}:{a + 7}], a[{acc}:{acc + 3}], "
-            f"v{F8_SCALE}, v{F8_SCALE} op_sel_hi:[0,0,0]")
+    head = f"v_mfma_scale_f32_16x16x128_f8f6f4 a[{acc}:{acc + 3}], v[{w}:{w + 7}], v[{a}:{a + 7}], a[{acc}:{acc + 3}], "
+    if not mx:
+        return head + f"v{F8_SCALE}, v{F8_SCALE} op_sel_hi:[0,0,0]"
+    b = m & 3
+    return head + f"v{F8_SCALE}, v{F8_SC[s] + (m >> 2)} op_sel:[0,{b & 1},0] op_sel_hi:[0,{b >> 1},0]"
 
 
 def f8_rd_a(buf, s):
@@ -276,12 +288,18 @@ def f8_dma(buf):
     return a + w
 
 
-F8_SHAPE = dict(w7=[0, 1], b1=4, d=every(6, 2, 16), b3=43, pf=45,
-                # 30 reads of tile T+1: A lo/hi of the eight fragments (slots 44..51), W[0..4] (52..56), W[5] (57: behind MFMA 47), W[6] (58, 59: behind 55)
-                ra=[44 + i // 2 for i in range(16)], rw=[52, 52, 53, 53, 54, 54, 55, 55, 56, 56, 57, 57, 58, 59])
+F8_SHAPES = {
+    # f1: 30 reads of tile T+1: A lo/hi of the eight fragments (slots 44..51), W[0..4] (52..56), W[5] (57: behind MFMA 47), W[6] (58, 59: behind 55)
+    "f1": dict(w7=[0, 1], b1=4, d=every(6, 2, 16), b3=43, pf=45,
+               ra=[44 + i // 2 for i in range(16)], rw=[52, 52, 53, 53, 54, 54, 55, 55, 56, 56, 57, 57, 58, 59]),
+    # f3: the wait early (38), the reads spread over the rest of the tile — measured equal to f1 within the run-to-run noise (64-crop shapes)
+    "f3": dict(w7=[0, 1], b1=3, d=every(5, 2, 16), b3=38, pf=40,
+               ra=[39 + i // 2 for i in range(16)], rw=[47, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59]),
+}
+F8_SHAPE = F8_SHAPES[os.environ.get("G4W_F8_SHAPE", "f1")]
 
 
-def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False):
+def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False, mx=False):
     """One K-tile in buffer `buf`, A fragments in set `buf`.  The W[7] reads of THIS tile sit in its first two slots (prologue: `first`
     tiles find W[7] loaded already)."""
     sh = F8_SHAPE
@@ -296,11 +314,16 @@ def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False):
             slots[pos - 1].append(g[0])
             slots[pos].append(g[1])
         slots[max(sh["d"]) + 2].append("s_add_u32 %[koff], %[koff], 128")
+        if mx:
+            assert max(sh["d"]) + 4 < sh["b3"] - 1
+            slots[max(sh["d"]) + 2].append(f"s_add_u32 m0, %[ldss], {buf * 1024}")
+            slots[max(sh["d"]) + 3].append(f"buffer_load_dword v{F8_SOFF}, %[srds], %[soff] offen lds")
+            slots[max(sh["d"]) + 4].append("s_add_u32 %[soff], %[soff], %[sstr]")
     if last:
         slots[sh["b1"]].append("s_barrier")                      # every wave is done with LDS: the caller may DMA the next output tile's head
     if next_tile:
         if use_pf:
-            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({18 if next2 else 0})")
+            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({18 + mx if next2 else 0})")
             if next2:
                 ops = [f"buffer_load_dword v{F8_PF_DST}, v{F8_PF_OFF}, %[srda], 0 offen", f"buffer_load_dword v{F8_PF_DST + 1}, v{F8_PF_OFF + 1}, %[srdw], 0 offen",
                        f"v_add_u32 v{F8_PF_OFF}, 128, v{F8_PF_OFF}", f"v_add_u32 v{F8_PF_OFF + 1}, 128, v{F8_PF_OFF + 1}",
@@ -308,10 +331,12 @@ def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False):
                 for k, op in enumerate(ops):
                     slots[sh["pf"] + k // 2].append(op)
         else:
-            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({16 if next2 else 0})")
+            slots[sh["b3"] - 1].append(f"s_waitcnt vmcnt({16 + mx if next2 else 0})")
         slots[sh["b3"]].append("s_barrier")
         for k, r in enumerate(f8_rd_a(buf ^ 1, buf ^ 1)):
             slots[sh["ra"][k]].append(r)
+        if mx:
+            slots[sh["ra"][0]].append(f"ds_read_b64 v[{F8_SC[buf ^ 1]}:{F8_SC[buf ^ 1] + 1}], v{F8_SRD} offset:{(buf ^ 1) * 1024}")
         wr = [r for n in range(7) for r in f8_rd_w(buf ^ 1, n)]
         for k, r in enumerate(wr):
             n = k // 2
@@ -320,12 +345,12 @@ def f8_tile(buf, next_tile, next2, use_pf, last=False, first=False):
         slots[63].append("s_waitcnt lgkmcnt(0)")
     out = [f"; ---- fp8 K-tile in buffer {buf} ----"]
     for j in range(64):
-        out.append(f8_mfma(j, buf))
+        out.append(f8_mfma(j, buf, mx))
         out += slots[j]
     return out
 
 
-def loop_text_f8(use_pf):
+def loop_text_f8(use_pf, mx=False):
     L = []
     # the per-lane operands arrive PINNED (gemm4w.hip): v192..195 read addresses of buffer 0, v200..215 piece offsets, v218..221 prefetch
     for i in range(4):
@@ -336,13 +361,15 @@ def loop_text_f8(use_pf):
     # K-tiles 0 and 1 were DMA'd by the caller: wait, publish, fragments of tile 0: A -> set 0, W[0..7]
     L += ["s_waitcnt vmcnt(0)", "s_barrier"]
     L += f8_rd_a(0, 0) + [r for n in range(8) for r in f8_rd_w(0, n)]
+    if mx:
+        L += [f"ds_read_b64 v[{F8_SC[0]}:{F8_SC[0] + 1}], v{F8_SRD}"]
     L += ["s_waitcnt lgkmcnt(0)"]
     # first pair peeled off the loop?  No: tile 0 only differs in not re-reading W[7]; run it as the loop's first iteration with a flag
     # -> simpler: the text reads W[7] of tile 0 twice (prologue + slots 0, 1 of the tile): 2 redundant reads per OUTPUT tile.
     L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%=", ".Lg4w_loop_%=:"]
-    L += f8_tile(0, True, True, use_pf) + f8_tile(1, True, True, use_pf)
+    L += f8_tile(0, True, True, use_pf, mx=mx) + f8_tile(1, True, True, use_pf, mx=mx)
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%=", ".Lg4w_tail_%=:"]
-    L += f8_tile(0, True, False, use_pf) + f8_tile(1, False, False, use_pf, last=True)
+    L += f8_tile(0, True, False, use_pf, mx=mx) + f8_tile(1, False, False, use_pf, last=True, mx=mx)
     L += ["s_nop 15", "s_nop 15"]
     return L
 
@@ -366,9 +393,13 @@ def main(out_path=None):
         f.write(as_macro("GEMM4W_LOOP_ASM_PF", Lp))
         f.write(as_macro("GEMM4W_LOOP_ASM_F8", loop_text_f8(False)))
         f.write(as_macro("GEMM4W_LOOP_ASM_F8_PF", loop_text_f8(True)))
+        f.write(as_macro("GEMM4W_LOOP_ASM_MX", loop_text_f8(False, mx=True)))
+        f.write(as_macro("GEMM4W_LOOP_ASM_MX_PF", loop_text_f8(True, mx=True)))
         f.write("#define GEMM4W_CLOBBERS " + clob + ', "memory", "scc"\n')
         pinned = set(range(192, 196)) | set(range(200, 216)) | set(range(218, 222))
         f.write("#define GEMM4W_CLOBBERS_F8 " + ", ".join(f'"v{i}"' for i in range(F8_NV) if i not in pinned) + ", " + ", ".join(f'"a{i}"' for i in range(256)) + ', "memory", "scc"\n')
+        pinned |= {F8_SRD, F8_SOFF}
+        f.write("#define GEMM4W_CLOBBERS_MX " + ", ".join(f'"v{i}"' for i in range(F8_NV_MX) if i not in pinned) + ", " + ", ".join(f'"a{i}"' for i in range(256)) + ', "memory", "scc"\n')
     print(os.path.normpath(path), len(L), "+", len(Lp), "instructions,", sum("v_mfma" in x for x in L), "MFMAs per text")
     return L
 

@@ -21,7 +21,8 @@ EXPORTS = [
     "vstar_op_attention_workspace", "vstar_image_set", "vstar_preprocess_crops", "vstar_heatmap_stats", "vstar_heatmap_stats_batch", "vstar_vsm_generate", "vstar_op_gemm_fp8",
     "vstar_op_gemm_last_tile", "vstar_op_gemm_plan", "vstar_op_gemm_norm", "vstar_op_rms_rstd", "vstar_op_ln_fold", "vstar_upsample_mask_ex", "vstar_vsm_score_grouped",
     "vstar_image_set_slot", "vstar_image_set_slot_async", "vstar_preprocess_crops_slots", "vstar_comm_unique_id", "vstar_comm_init", "vstar_allgather_results",
-    "vstar_comm_destroy", "vstar_build_source_hash",
+    "vstar_comm_destroy", "vstar_build_source_hash", "vstar_op_mx_scale_bytes", "vstar_op_mx_scale_offset", "vstar_op_quantize_mx",
+    "vstar_op_gemm_mx", "vstar_op_gemm_fp8_mxout", "vstar_op_attention_mx", "vstar_w8a8_mx_active",
 ]
 
 # every symbol include/vstar_vqa.h declares
@@ -143,6 +144,20 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_gemm_fp8.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                       POINTER(c_float)]
     lib.vstar_op_gemm_fp8.restype = c_int
+    lib.vstar_op_mx_scale_bytes.argtypes = [c_int, c_int]
+    lib.vstar_op_mx_scale_bytes.restype = c_size_t
+    lib.vstar_op_mx_scale_offset.argtypes = [c_int, c_int, c_int]
+    lib.vstar_op_mx_scale_offset.restype = ctypes.c_int64
+    lib.vstar_op_quantize_mx.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]
+    lib.vstar_op_quantize_mx.restype = c_int
+    lib.vstar_op_gemm_mx.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float)]
+    lib.vstar_op_gemm_mx.restype = c_int
+    lib.vstar_op_gemm_fp8_mxout.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float)]
+    lib.vstar_op_gemm_fp8_mxout.restype = c_int
+    lib.vstar_op_attention_mx.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int]
+    lib.vstar_op_attention_mx.restype = c_int
+    lib.vstar_w8a8_mx_active.argtypes = [c_void_p]
+    lib.vstar_w8a8_mx_active.restype = c_int
     lib.vstar_op_layernorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]
     lib.vstar_op_layernorm.restype = c_int
     lib.vstar_op_rmsnorm.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]

@@ -14,6 +14,7 @@
 //   ds_read_b64_tr_b16 (two transpose reads per PV operand fragment): no V^T pass, no V^T buffer.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "mx.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -65,9 +66,12 @@ __global__ void rope_kernel(lp_t* __restrict__ qkv, const lp_t* __restrict__ cos
 // every wave issuing fragment-shaped global loads (32 cache lines per instruction).  XOR chunk swizzles (applied on the
 // DMA source address and on the read address) keep the ds_read_b128 K-fragment reads conflict-free and the ds_read_b64
 // V^T reads at most 2-way.  One counted vmcnt + two barriers per 64-key tile; next tile's DMA is in flight during compute.
-template <int D, bool CAUSAL>
+// MXO (W8A8 mode, mx.hpp): the output leaves block-scaled — fp8 bytes to (uint8_t*)out and one E8M0 byte per (row, 32 d) to `mxs`
+// (tile-major for the o_proj GEMM: a head = one K-tile, m128 = rows / 128) — quantised from the 16-bit value the plain kernel stores.
+template <int D, bool CAUSAL, bool MXO = false>
 __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv, lp_t* __restrict__ out, int S, int H,
-                                                    float scale_log2e, int grp_R0, int grp_Lc, int nqb) {
+                                                    float scale_log2e, int grp_R0, int grp_Lc, int nqb, uint8_t* __restrict__ mxs = nullptr,
+                                                    int m128 = 0) {
   // Grouped sequences (causal only; grp_R0 > 0): rows [0, grp_Lc) are a SHARED prefix, rows [grp_R0, S) are independent 32-row
   // suffix blocks (one per search target) that each attend to the shared prefix and, causally, to themselves — the prefill of
   // T prompts that share their first grp_Lc tokens, with the prefix's K/V computed once (engine.hip::score_grouped).  A query
@@ -313,6 +317,38 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   }
   l += __shfl_xor(l, 32, 64);
 
+  if constexpr (MXO) {
+    // lane (query, h2) holds d = db * 32 + g * 8 + 4 * h2 + e of its row: a block of 32 d = this lane's 16 values + lane ^ 32's
+    const float inv = 1.0f / l;
+    const int row = b * S + query;
+    uint8_t* op8 = (uint8_t*)out + (int64_t)row * ((int64_t)H * D) + h * D + 16 * h2;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      float f[16], mx = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        f[r] = rlp(oacc[db][r] * inv);
+        mx = fmaxf(mx, fabsf(f[r]));
+      }
+      mx = mx_max_halves(mx);                       // (every lane takes part)
+      const uint32_t e8 = mx_e8m0(mx);
+      const float is = mx_inv_scale(e8);
+      // this lane's four 4-byte pieces sit at d = g * 8 + 4 * h2; two half swaps with lane ^ 32 turn them into 16 CONSECUTIVE bytes per
+      // lane (h2 = 0: bytes 0..15 of the block, h2 = 1: 16..31) — one 16-byte store instead of four 4-byte ones
+      uint32_t pk[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) pk[g] = mx_pack4(f[g * 4] * is, f[g * 4 + 1] * is, f[g * 4 + 2] * is, f[g * 4 + 3] * is);
+      const auto s02 = __builtin_amdgcn_permlane32_swap(pk[0], pk[2], false, false);
+      const auto s13 = __builtin_amdgcn_permlane32_swap(pk[1], pk[3], false, false);
+      if (active && query < S) {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        const u32x4 o = {s02[0], s02[1], s13[0], s13[1]};
+        *(u32x4*)(op8 + db * 32) = o;
+        if (h2 == 0) mxs[mx_scale_offset(row, h * DB + db, m128)] = (uint8_t)e8;
+      }
+    }
+    return;
+  }
   if (active && query < S) {
     const float inv = 1.0f / l;
     lp_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 4 * h2;
@@ -478,12 +514,12 @@ hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin, int B, int S, int H, int
   return hipGetLastError();
 }
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool MXO = false>
 static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, float sl, hipStream_t s, int grp_R0 = 0,
-                               int grp_Lc = 0) {
+                               int grp_Lc = 0, uint8_t* mxs = nullptr) {
   constexpr int LDS = 4 * 64 * D * 2;
   static bool attr_done = false;
-  auto kern = attn2_kernel<D, CAUSAL>;
+  auto kern = attn2_kernel<D, CAUSAL, MXO>;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return e;
@@ -491,7 +527,7 @@ static hipError_t launch_attn2(const lp_t* qkv, lp_t* out, int B, int S, int H, 
   }
   const int nqb = (S + 127) / 128;
   dim3 grid((unsigned)(nqb * H * B));
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl, grp_R0, grp_Lc, nqb);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS, s, qkv, out, S, H, sl, grp_R0, grp_Lc, nqb, mxs, (B * S) >> 7);
   return hipGetLastError();
 }
 
@@ -502,6 +538,17 @@ hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, 
   const float sl = scale * 1.4426950408889634f;
   if (D == 64) return causal ? launch_attn2<64, true>(qkv, out, B, S, H, sl, s) : launch_attn2<64, false>(qkv, out, B, S, H, sl, s);
   return causal ? launch_attn2<128, true>(qkv, out, B, S, H, sl, s, grp_R0, grp_Lc) : launch_attn2<128, false>(qkv, out, B, S, H, sl, s);
+}
+
+hipError_t attn_forward_mx(const lp_t* qkv, uint8_t* out8, uint8_t* scales, int B, int S, int H, float scale, hipStream_t s, int grp_R0,
+                           int grp_Lc) {
+#ifdef VSTAR_LP_F16
+  return hipErrorInvalidValue;
+#else
+  if ((int64_t)B * S % 128 || !out8 || !scales) return hipErrorInvalidValue;
+  if (grp_R0 > 0 && (grp_R0 % 128 || grp_Lc <= 0 || grp_Lc > grp_R0 || (S - grp_R0) % 32)) return hipErrorInvalidValue;
+  return launch_attn2<128, true, true>(qkv, (lp_t*)out8, B, S, H, scale * 1.4426950408889634f, s, grp_R0, grp_Lc, scales);
+#endif
 }
 
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,

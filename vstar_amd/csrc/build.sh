@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused
 mkdir -p build
 rm -f build/gemm256a.o build/f16_gemm256a.o     # (round-3 experiment, moved to tools/experiments/gemm256a)
 pids=()
-HDRS="common.hpp kernels.hpp gemm_epilogue.hpp gemm256_direct_epilogue.hpp gemm4w_loop.inc engine_base.hpp llm_cached.hpp ../../include/vstar_hip.h ../../include/vstar_vqa.h"
+HDRS="common.hpp kernels.hpp gemm_epilogue.hpp gemm256_direct_epilogue.hpp mx.hpp gemm4w_loop.inc engine_base.hpp llm_cached.hpp ../../include/vstar_hip.h ../../include/vstar_vqa.h"
 stale() {  # stale <object> <source>
   [ ! -f "$1" ] && return 0
   [ "$2" -nt "$1" ] && return 0

@@ -3,6 +3,7 @@
 // (VisualSearch/model/VSM.py:201-364, 438-553) with the generate() loop collapsed into one teacher-forced prefill
 // (SURVEY.md §7 "hard parts"; the lm_head argmax at the verify positions lets the caller prove the collapse is exact).
 #include "llm_cached.hpp"
+#include "mx.hpp"
 #include <atomic>
 #include <tuple>
 #include <cstring>
@@ -35,9 +36,12 @@ struct vstar_engine : EngineBase {
   // LLM activations
   int Smax = 0;
   uint8_t* lq8 = nullptr; float* lsa = nullptr;      // W8A8: quantised activation rows + per-token scales
+  uint8_t* lmx = nullptr;                            // W8A8, block-scaled activations (mx.hpp): E8M0 bytes of the o_proj / down_proj inputs
   int make_lin8(const Lin& L, Lin8* out);
   int lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
-           const lp_t* res, int64_t ldr, const lp_t* rope_cs = nullptr, int rope_S = 0, int rope_cols = 0);
+           const lp_t* res, int64_t ldr, const lp_t* rope_cs = nullptr, int rope_S = 0, int rope_cols = 0, const uint8_t* a_mx = nullptr,
+           uint8_t* c_mx = nullptr);
+  bool last_w8a8_mx = false;   // whether the last llm_forward ran o_proj / down_proj on block-scaled activations (vstar_w8a8_mx_active)
   bool fused_rope = true;      // VSTAR_FUSED_ROPE=0 keeps RoPE as a separate pass (A/B and the bit-identity test)
   // RMSNorms of the LLaMA blocks folded into the linears that consume them (default; VSTAR_FOLD_NORMS=0 before vstar_create keeps
   // the norm kernels): weight folded into W's columns at load, 1/rms applied to the accumulators, statistics from the epilogue
@@ -173,10 +177,10 @@ int vstar_engine::make_lin8(const Lin& L, Lin8* out) {
 }
 
 int vstar_engine::lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
-                       const lp_t* res, int64_t ldr, const lp_t* rope_cs, int rope_S, int rope_cols) {
+                       const lp_t* res, int64_t ldr, const lp_t* rope_cs, int rope_S, int rope_cols, const uint8_t* a_mx, uint8_t* c_mx) {
   GemmParams p{};
   p.A = (const lp_t*)Aq; p.lda = L.K; p.W = (const lp_t*)L8.W; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
-  p.M = M; p.N = L.N; p.K = L.K; p.a_scale = sa; p.w_scale = L8.s;
+  p.M = M; p.N = L.N; p.K = L.K; p.a_scale = a_mx ? nullptr : sa; p.w_scale = L8.s; p.a_mx = a_mx; p.c_mx = c_mx;
   p.rope_cs = rope_cs; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc;
   return gemm(p, epi, false);
 }
@@ -263,6 +267,7 @@ int vstar_engine::finalize() {
   if (c.llm_w8a8) {
     RC(dalloc(&lq8, lrows * (size_t)(c.llm_mlp > H ? c.llm_mlp : H)));
     RC(dalloc(&lsa, lrows));
+    RC(dalloc(&lmx, (lrows + 127) / 128 * 128 * (size_t)((c.llm_mlp > H ? c.llm_mlp : H) / 32 + 1)));
   }
   RC(dalloc(&hsel, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_att, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
@@ -555,6 +560,25 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
   // kernel; activations are quantised per token right where they are produced (inside the RMSNorm for q|k|v and gate|up,
   // by one pass over the attention output / the SiLU*up product for o_proj and down_proj)
   const bool w8 = c.llm_w8a8 && rows >= 1024;
+  // Block-scaled activations (mx.hpp, round 6) for the inputs of o_proj and down_proj: quantised by their PRODUCERS (the attention
+  // epilogue, the gate|up epilogue) per 32 values, scales applied inside the MFMA — no stand-alone quantisation pass.  Needs the
+  // 4-wave kernel's domain (rows % 256 == 0 ...); otherwise the per-token scheme with its two passes.  VSTAR_W8A8_MX=0: A/B runs.
+  static const bool mx_env = [] { const char* e = getenv("VSTAR_W8A8_MX"); return !e || atoi(e) != 0; }();
+  bool mx = false;
+  if (w8 && mx_env && c.llm_layers > 1) {
+    GemmParams q{};
+    LlmBlock& b0 = llm[0];
+    q.A = (const lp_t*)latt; q.lda = H; q.W = (const lp_t*)b0.o8.W; q.C = lx; q.ldc = H; q.res = lx; q.ldr = H; q.M = rows; q.N = H; q.K = H;
+    q.w_scale = b0.o8.s; q.a_mx = lmx;
+    mx = gemm_mx_supported(q, VSTAR_EPI_NONE);
+    q.A = (const lp_t*)lact; q.lda = c.llm_mlp; q.W = (const lp_t*)b0.down8.W; q.K = c.llm_mlp; q.w_scale = b0.down8.s;
+    mx = mx && gemm_mx_supported(q, VSTAR_EPI_NONE);
+    q = GemmParams{};
+    q.A = (const lp_t*)lq8; q.lda = H; q.W = (const lp_t*)b0.gate_up8.W; q.C = lact; q.ldc = c.llm_mlp; q.M = rows; q.N = b0.gate_up.N; q.K = H;
+    q.a_scale = lsa; q.w_scale = b0.gate_up8.s; q.c_mx = lmx;
+    mx = mx && gemm_mx_supported(q, VSTAR_EPI_SILU_MUL);
+  }
+  last_w8a8_mx = mx;
   // Shared prefix (VSTAR_F_SHARE_PREFIX, psh_Lp > 0): the first Lp positions of every sequence are the same tokens, so they run
   // ONCE, as a sequence of their own in the rows [Lp, 2 Lp) of slot `nseq` of the activation buffers.  The linears see the
   // compact row set {rows [Lp, S) of every sequence} + {the prefix rows} through a periodic row map (group S - Lp, stride S,
@@ -613,7 +637,8 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       KCHK(bcast_rows(lqkv + pre * 3 * H, lqkv, nseq, S, Lp, 3 * H, 3 * H, stream));
       KCHK(attn_forward(lqkv + pre * 3 * H, latt + pre * H, 1, Lp, c.llm_heads, 128, 1, att_scale, stream, 0, 0));
     }
-    KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream, grp_R0, grp_Lc));
+    if (mx && i + 1 < c.llm_layers) KCHK(attn_forward_mx(lqkv, (uint8_t*)latt, lmx, nseq, S, c.llm_heads, att_scale, stream, grp_R0, grp_Lc));
+    else KCHK(attn_forward(lqkv, latt, nseq, S, c.llm_heads, 128, 1, att_scale, stream, grp_R0, grp_Lc));
     if (i + 1 == c.llm_layers) {
       // Last block: only the [LOC]-1 row and the verify rows are ever read (VSM.py:465-473), and every op after the
       // attention is row-wise, so o_proj / MLP run on those gathered rows only (row-wise ops: bit-identical).
@@ -627,7 +652,12 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
       break;
     }
-    if (w8) {
+    if (mx) {
+      RC(lin8((const uint8_t*)latt, nullptr, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H, nullptr, 0, 0, lmx, nullptr));
+      KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
+      RC(lin8(lq8, lsa, b.gate_up, b.gate_up8, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0, nullptr, 0, 0, nullptr, lmx));
+      RC(lin8((const uint8_t*)lact, nullptr, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H, nullptr, 0, 0, lmx, nullptr));
+    } else if (w8) {
       KCHK(quantize_rows_fp8(latt, H, lq8, H, lsa, rows, H, stream));
       RC(lin8(lq8, lsa, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H));
       KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
@@ -1545,6 +1575,86 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* A, const uint16_t* W, const 
   hipFree(Aq); hipFree(Wq); hipFree(sa); hipFree(sw);
   return op_rc(e);
 }
+// ---- block-scaled W8A8 (mx.hpp), op level ----
+size_t vstar_op_mx_scale_bytes(int rows, int cols) { return (rows % 128 || cols % 128) ? 0 : mx_scale_bytes(rows, cols); }
+int64_t vstar_op_mx_scale_offset(int row, int k_block, int rows) { return mx_scale_offset(row, k_block, rows >> 7); }
+int vstar_op_quantize_mx(void* stream, const uint16_t* X, uint8_t* q, uint8_t* scales, int rows, int cols) {
+  hipError_t e = quantize_rows_mx(X, cols, q, cols, scales, rows, cols, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return op_rc(e);
+}
+int vstar_op_gemm_mx(void* stream, const uint8_t* Aq, const uint8_t* a_scales, const uint16_t* W, const uint16_t* res, uint16_t* C, int M,
+                     int N, int K, int iters, float* gemm_ms) {
+  if (!Aq || !a_scales || !W || !C || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const int Npad = (N + 255) / 256 * 256;
+  uint8_t* Wq = nullptr;
+  float* sw = nullptr;
+  hipError_t e = hipMalloc((void**)&Wq, (size_t)Npad * K);
+  if (e == hipSuccess) e = hipMalloc((void**)&sw, (size_t)Npad * 4);
+  if (e == hipSuccess) e = quantize_rows_fp8(W, K, Wq, K, sw, Npad, K, s);
+  GemmParams p{};
+  p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.res = res; p.ldr = N; p.C = C; p.ldc = N;
+  p.M = M; p.N = N; p.K = K; p.w_scale = sw; p.a_mx = a_scales;
+  if (e == hipSuccess && !gemm_mx_supported(p, VSTAR_EPI_NONE)) { tls_error() = "shape not accepted by the block-scaled W8A8 kernel"; e = hipErrorInvalidValue; }
+  if (e == hipSuccess) e = gemm_lp(p, VSTAR_EPI_NONE, false, s);
+  if (e == hipSuccess && iters > 0 && gemm_ms) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = gemm_lp(p, VSTAR_EPI_NONE, false, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *gemm_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(Wq); hipFree(sw);
+  return op_rc(e);
+}
+int vstar_op_gemm_fp8_mxout(void* stream, const uint16_t* A, const uint16_t* W, uint8_t* C8, uint8_t* c_scales, int M, int N, int K, int iters,
+                            float* gemm_ms) {
+  if (!A || !W || !C8 || !c_scales || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+  hipStream_t s = (hipStream_t)stream;
+  const int Npad = (N + 255) / 256 * 256;
+  uint8_t *Aq = nullptr, *Wq = nullptr;
+  float *sa = nullptr, *sw = nullptr;
+  hipError_t e = hipMalloc((void**)&Aq, (size_t)M * K);
+  if (e == hipSuccess) e = hipMalloc((void**)&Wq, (size_t)Npad * K);
+  if (e == hipSuccess) e = hipMalloc((void**)&sa, (size_t)M * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&sw, (size_t)Npad * 4);
+  if (e == hipSuccess) e = quantize_rows_fp8(A, K, Aq, K, sa, M, K, s);
+  if (e == hipSuccess) e = quantize_rows_fp8(W, K, Wq, K, sw, Npad, K, s);
+  GemmParams p{};
+  p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.C = C8; p.ldc = N / 2;
+  p.M = M; p.N = N; p.K = K; p.a_scale = sa; p.w_scale = sw; p.c_mx = c_scales;
+  if (e == hipSuccess && !gemm_mx_supported(p, VSTAR_EPI_SILU_MUL)) { tls_error() = "shape not accepted by the block-scaled W8A8 kernel"; e = hipErrorInvalidValue; }
+  if (e == hipSuccess) e = gemm_lp(p, VSTAR_EPI_SILU_MUL, false, s);
+  if (e == hipSuccess && iters > 0 && gemm_ms) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = gemm_lp(p, VSTAR_EPI_SILU_MUL, false, s);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *gemm_ms = ms / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(Aq); hipFree(Wq); hipFree(sa); hipFree(sw);
+  return op_rc(e);
+}
+int vstar_op_attention_mx(void* stream, const uint16_t* qkv, uint8_t* out8, uint8_t* scales, int B, int S, int H) {
+  hipError_t e = attn_forward_mx(qkv, out8, scales, B, S, H, 1.0f / sqrtf(128.0f), (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  return op_rc(e);
+}
+int vstar_w8a8_mx_active(vstar_handle* h) { return h ? (h->last_w8a8_mx ? 1 : 0) : VSTAR_ERR_INVALID; }
+
 size_t vstar_op_attention_workspace(int B, int S, int H, int D) {
   (void)B; (void)H;
   return (size_t)S * D * 2 + 256;     // the RoPE cos|sin table only: V is transposed inside the kernel (no V^T buffer)

@@ -203,9 +203,9 @@ struct EngineBase {
       hipEventRecord(e1, stream);
       const double fl = 2.0 * p.M * (double)p.N * p.K;
       pending_flops += fl;
-      ev_flops.push_back(p.a_scale ? -fl : fl);
+      ev_flops.push_back((p.a_scale || p.a_mx) ? -fl : fl);
       prof_launches++;
-      if (p.a_scale) prof_launches8++;
+      if (p.a_scale || p.a_mx) prof_launches8++;
     }
     return 0;
   }

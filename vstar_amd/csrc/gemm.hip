@@ -372,6 +372,11 @@ hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t 
   static const int env_force = [] { const char* e = getenv("VSTAR_GEMM_TILE"); return e ? atoi(e) : 0; }();
   const int force = p.tile_force ? p.tile_force : env_force;
   if (force != 0 && force != 128 && force != 256 && force != GEMM_TILE_4W) return hipErrorInvalidValue;
+  if (p.a_mx || p.c_mx) {      // block-scaled W8A8 (mx.hpp) exists in the 4-wave kernel only: callers check gemm_mx_supported
+    if (out_f32 || (force != 0 && force != GEMM_TILE_4W) || !gemm4w_eligible(p, epilogue, out_f32)) return hipErrorInvalidValue;
+    t_last_tile = GEMM_TILE_4W;
+    return gemm4w_lp(p, epilogue, s);
+  }
   const bool elig = gemm256_eligible(p);
   if (p.tile_force == 256 && !elig) return hipErrorInvalidValue;   // an explicit per-call request must not be silently re-routed
   // The 4-wave / AGPR kernel (gemm4w.hip) takes the launches made of interior 256^2 tiles with the in-register epilogue — WHERE the

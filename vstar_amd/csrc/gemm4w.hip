@@ -17,6 +17,7 @@
 #include "kernels.hpp"
 #include "gemm_epilogue.hpp"
 #include "gemm256_direct_epilogue.hpp"
+#include "mx.hpp"
 #include <type_traits>
 #include <utility>
 
@@ -77,13 +78,14 @@ __device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
 // The in-register epilogue of the 128 x 64 half H of the wave's tile = ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid
 // (gemm256_direct_epilogue.hpp, shared with gemm256.hip).  The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes
 // them (16 registers at a time instead of the half's 128), with the folded-norm row scale applied on the way.
-template <int EPI, int H, bool F8>
+template <int EPI, int H, bool F8, bool MX>
 __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
   if constexpr (F8) {
     // W8A8: per-row activation scale x per-output-channel weight scale, the latter in the permuted-row order of the direct tile (gemm256.hip)
+    // (MX: the activation's block scales were applied inside the MFMAs — only the weight scale is left)
     float sa[8], sw[4][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) sa[m] = p.a_scale[em0 + wr * 128 + m * 16 + fr];
+    for (int m = 0; m < 8; ++m) sa[m] = MX ? 1.0f : p.a_scale[em0 + wr * 128 + m * 16 + fr];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       int sc;
@@ -103,7 +105,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[n][e] *= sa[m] * sw[n][e];
+        for (int e = 0; e < 4; ++e) a[n][e] *= MX ? sw[n][e] : sa[m] * sw[n][e];
     });
     return;
   }
@@ -125,6 +127,66 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
   });
 }
 
+#ifndef VSTAR_LP_F16
+// gate|up with a BLOCK-SCALED fp8 output (GemmParams::c_mx, mx.hpp): SiLU(gate) * up leaves as e4m3 bytes + one E8M0 byte per row and 32
+// outputs — the down_proj input, quantised where it is produced.  The W rows of such a tile are DMA'd in an order of their own
+// (piece_offsets) so that lane (fr, fq) ends up with SIXTEEN consecutive outputs of row group m — 8 from each 128 x 64 half of the
+// wave's tile — i.e. one 16-byte store per row (4 lanes = 64 contiguous bytes; 8-byte stores measured -6.5 % on the whole GEMM), and a
+// block of 32 = this lane's 16 values + lane ^ 16's.  Values are quantised from the 16-bit value the plain epilogue stores: same bytes as
+// store + quantize_rows_mx (tests/test_mx_gpu.py).
+__device__ __forceinline__ void mx_silu_epilogue(const GemmParams& p, int em0, int en0, int wr, int wc2, int fr, int fq) {
+  float sa[8], sw[2][4][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) sa[m] = p.a_scale[em0 + wr * 128 + m * 16 + fr];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 t = *(const f32x4*)(p.w_scale + en0 + wc2 * 128 + fq * 32 + (n & 1) * 16 + h * 8 + (n >> 1) * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sw[h][n][e] = t[e];
+    }
+  const int row0 = em0 + wr * 128 + fr;
+  const int col0 = (en0 + wc2 * 128) / 2;
+  uint8_t* qrow = (uint8_t*)p.C + (int64_t)row0 * p.ldc + col0 + fq * 16;
+  uint32_t sc_lo = 0, sc_hi = 0;
+  gemm_static_for<8>([&](auto mc) {
+#pragma clang fp contract(off)      // the dequantisation of direct_epilogue_half, operation for operation
+    constexpr int m = decltype(mc)::value;
+    f32x4 a[2][4];
+    load_acc_row<0, m>(a[0]);
+    load_acc_row<1, m>(a[1]);
+    float f[16], mx = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[h][n][e] *= sa[m] * sw[h][n][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[h * 8 + e] = rlp(act_silu_bf16(rlp(a[h][0][e])) * rlp(a[h][1][e]));
+        f[h * 8 + 4 + e] = rlp(act_silu_bf16(rlp(a[h][2][e])) * rlp(a[h][3][e]));
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fabsf(f[e]));
+    mx = mx_max_row_pairs(mx);
+    const uint32_t e8 = mx_e8m0(mx);
+    const float inv = mx_inv_scale(e8);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 o;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) o[g] = mx_pack4(f[4 * g] * inv, f[4 * g + 1] * inv, f[4 * g + 2] * inv, f[4 * g + 3] * inv);
+    __builtin_nontemporal_store(o, (u32x4*)qrow);
+    qrow += 16 * p.ldc;
+    if (m < 4) sc_lo |= e8 << (8 * (m & 3)); else sc_hi |= e8 << (8 * (m & 3));
+  });
+  if (!(fq & 1))      // rows row0 + 16 m, m = 0..7: eight consecutive bytes of the tile-major scale layout
+    *(uint2*)(p.c_mx + mx_scale_offset(row0, (col0 >> 5) + (fq >> 1), p.M >> 7)) = make_uint2(sc_lo, sc_hi);
+}
+#endif
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -135,8 +197,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // PF: the loop text with the L2 prefetch duty (long K: the launcher decides).  F8: W8A8 (BASELINE config 5) — A and W are OCP fp8 e4m3
 // bytes, a K-tile is still 128 bytes of every row (128 elements), one v_mfma_scale_f32_16x16x128_f8f6f4 replaces four bf16 MFMAs, the
 // accumulators are dequantised (per-row x per-output-channel scale) on their way out of the AGPRs.
-template <int EPI, bool PF, bool F8>
+// MX (with F8): the A operand's E8M0 block scales (mx.hpp) ride along as a 17th DMA piece per K-tile and enter the MFMAs per lane.
+template <int EPI, bool PF, bool F8, bool MX>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
+  static_assert(!MX || F8, "block scales exist for the fp8 operands only");
   constexpr int ES = F8 ? 1 : 2;                       // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -151,6 +215,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   uint32_t va[8], vw[8];
   int m0 = 0, n0 = 0, pi = 0;
   const char *abase = nullptr, *wbase = nullptr;
+  const uint8_t* sbase = nullptr;                      // MX: the scale bytes of this tile's two row blocks, K-tile 0
+  const uint32_t sstr = MX ? (uint32_t)(p.M >> 7) * 512u : 0u;      // ... and the distance to the next K-tile's
   // wave w moves the 8-row pieces g = 8 w + i of the A tile and of the W tile: per-lane byte offsets at k = 0, W rows in the order of
   // the tile's kind `cur_wkind` (1 plain / SiLU, 2 RoPE)
   auto piece_offsets = [&](int ln) {
@@ -162,7 +228,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       va[i] = (uint32_t)((int64_t)row * p.lda * ES + cg * 16);
       const int wcr = row >> 6, n = (row >> 4) & 3, ii = row & 15;
       int wrow;
-      if (EPI == VSTAR_EPI_SILU_MUL) {
+      if (EPI == VSTAR_EPI_SILU_MUL && F8 && p.c_mx) {      // block-scaled fp8 out: 16 consecutive outputs per lane (mx_silu_epilogue)
+        wrow = (wcr >> 1) * 128 + (ii >> 2) * 32 + (n & 1) * 16 + (wcr & 1) * 8 + (n >> 1) * 4 + (ii & 3);
+      } else if (EPI == VSTAR_EPI_SILU_MUL) {
         const int jo = (ii >> 2) * 8 + (n >> 1) * 4 + (ii & 3);
         wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);
       } else if (cur_wkind == 2) {
@@ -205,6 +273,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     }
     abase = (const char*)p.A + (int64_t)m0 * p.lda * ES;
     wbase = (const char*)p.W + (int64_t)n0 * p.K * ES;
+    if constexpr (MX) sbase = p.a_mx + (int64_t)(m0 >> 7) * 512;
   };
   // K-tiles 0 and 1 of the current tile -> LDS buffers 0 and 1 (32 DMA pieces per wave); the loop text starts behind a vmcnt(0)
   auto issue_head = [&]() {
@@ -216,6 +285,9 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wbase + vw[i] + t * 128), (lptr_t)(smem + t * 65536 + 32768 + wave * 8192 + i * 1024), 16, 0, 0);
+      if constexpr (MX)      // 1 KiB of scale bytes per K-tile: 256 B per wave, 4 B per lane
+        __builtin_amdgcn_global_load_lds((gptr_t)(sbase + (int64_t)t * sstr + wave * 256 + (threadIdx.x & 63) * 4),
+                                         (lptr_t)(smem + LDS_TOTAL + t * 1024 + wave * 256), 4, 0, 0);
     }
   };
   int bid = blockIdx.x;
@@ -274,8 +346,25 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     : [cnt] "+s"(cnt), [koff] "+s"(koff), [va] "+{v[200:207]}"(va8), [vw] "+{v[208:215]}"(vw8), [pf] "+{v[218:221]}"(pf4)            \
     : [srda] "s"(srda), [srdw] "s"(srdw), [ldsw] "s"(ldsw), [rd] "{v[192:195]}"(rd4)                                                \
     : GEMM4W_CLOBBERS_F8
-      if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_F8_PF G4W_OPERANDS_F8);
-      else asm volatile(GEMM4W_LOOP_ASM_F8 G4W_OPERANDS_F8);
+      if constexpr (MX) {
+        const i32x4 srds = {(int)(uint32_t)(uintptr_t)sbase, (int)(((uintptr_t)sbase >> 32) & 0xffff), -1, 0x00020000};
+        uint32_t soff = 2 * sstr;                        // K-tiles 0 and 1 are in flight
+        const uint32_t ldss = __builtin_amdgcn_readfirstlane(lds0 + LDS_TOTAL + wave * 256);
+        const int ln = fresh_lane();
+        int sr = (int)(lds0 + LDS_TOTAL + wr * 512 + ln * 8), so = wave * 256 + ln * 4;
+#define G4W_OPERANDS_MX                                                                                                              \
+    : [cnt] "+s"(cnt), [koff] "+s"(koff), [soff] "+s"(soff), [va] "+{v[200:207]}"(va8), [vw] "+{v[208:215]}"(vw8),                    \
+      [pf] "+{v[218:221]}"(pf4)                                                                                                      \
+    : [srda] "s"(srda), [srdw] "s"(srdw), [srds] "s"(srds), [ldsw] "s"(ldsw), [ldss] "s"(ldss), [sstr] "s"(sstr),                   \
+      [rd] "{v[192:195]}"(rd4), [sr] "{v228}"(sr), [so] "{v229}"(so)                                                                \
+    : GEMM4W_CLOBBERS_MX
+        if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_MX_PF G4W_OPERANDS_MX);
+        else asm volatile(GEMM4W_LOOP_ASM_MX G4W_OPERANDS_MX);
+#undef G4W_OPERANDS_MX
+      } else {
+        if constexpr (PF) asm volatile(GEMM4W_LOOP_ASM_F8_PF G4W_OPERANDS_F8);
+        else asm volatile(GEMM4W_LOOP_ASM_F8 G4W_OPERANDS_F8);
+      }
 #undef G4W_OPERANDS_F8
       cur_wkind = -1;             // the offsets died with the statement: the next set_tile recomputes them (from the fresh lane id below)
       lane = fresh_lane();
@@ -302,8 +391,19 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     if (!(p.debug_flags & 2)) {
 #endif
       const int fr = lane & 15, fq = lane >> 4;
-      direct_epilogue_half<EPI, 0, F8>(p, em0, en0, wr, wc2 * 2, fr, fq);
-      direct_epilogue_half<EPI, 1, F8>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
+      bool done = false;
+#ifndef VSTAR_LP_F16
+      if constexpr (F8 && !MX && EPI == VSTAR_EPI_SILU_MUL) {
+        if (p.c_mx) {
+          mx_silu_epilogue(p, em0, en0, wr, wc2, fr, fq);
+          done = true;
+        }
+      }
+#endif
+      if (!done) {
+        direct_epilogue_half<EPI, 0, F8, MX>(p, em0, en0, wr, wc2 * 2, fr, fq);
+        direct_epilogue_half<EPI, 1, F8, MX>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
+      }
     }
     G4W_STAMP(3);
 #ifdef G4W_TIMELINE
@@ -315,19 +415,20 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   }
 }
 
-template <int EPI, bool PF, bool F8 = false>
+template <int EPI, bool PF, bool F8 = false, bool MX = false>
 hipError_t launch(const GemmParams& p, hipStream_t s) {
   if (gemm_plan_only()) return hipSuccess;
   static bool attr_done = false;
-  auto kern = gemm4w_kernel<EPI, PF, F8>;
+  auto kern = gemm4w_kernel<EPI, PF, F8, MX>;
+  constexpr int LDS_BYTES = LDS_TOTAL + (MX ? 2048 : 0);
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int n_cu = gemm_device_cus();
   const int tiles = (p.M / BM) * (p.N / BN);
-  hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(256), LDS_TOTAL, s, p);
+  hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(256), LDS_BYTES, s, p);
   return hipGetLastError();
 }
 
@@ -342,10 +443,12 @@ extern "C" int vstar_debug_gemm4w_timeline(unsigned long long* out) {     // 2 x
 // Launches made of interior tiles that take gemm256's direct epilogue (see the header comment for the domain).
 bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
 #ifdef VSTAR_LP_F16
-  if (p.a_scale) return false;
+  if (p.a_scale || p.a_mx || p.c_mx) return false;
 #endif
   if (out_f32 || p.norm_w) return false;
-  if (p.a_scale) {      // W8A8: the two epilogues the LLaMA linears use; K counts fp8 elements, two K-tiles of 128 per loop iteration
+  if (p.a_mx && (p.a_scale || epilogue != VSTAR_EPI_NONE || p.rope_cs || ((uintptr_t)p.a_mx & 3))) return false;      // MX consumer: o_proj / down_proj
+  if (p.c_mx && (epilogue != VSTAR_EPI_SILU_MUL || !p.a_scale || ((uintptr_t)p.c_mx & 7) || p.ldc % 16)) return false;   // MX producer: gate|up (16-byte stores)
+  if (p.a_scale || p.a_mx) {      // W8A8: the two epilogues the LLaMA linears use; K counts fp8 elements, two K-tiles of 128 per loop iteration
     if (!p.w_scale || (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_SILU_MUL) || p.K % 256 || p.row_scale || p.sumsq_out) return false;
     static const bool f8_on = [] { const char* e = getenv("VSTAR_GEMM4W_F8"); return !e || atoi(e) != 0; }();
     if (!f8_on) return false;
@@ -361,14 +464,18 @@ bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
   return true;
 }
 
+bool gemm_mx_supported(const GemmParams& p, int epilogue) { return gemm4w_eligible(p, epilogue, false); }
+
 hipError_t gemm4w_lp(const GemmParams& p, int epilogue, hipStream_t s) {
   // L2 prefetch duty: measured on the MI355X (profiles/r06_gemm4w_ab.txt) it gains 4 - 15 % with the clock unconstrained (zero
   // operands) but, on real operands under the 1400 W cap, only where the stalls it removes are long — K = 11008 (down_proj: an A
   // operand of 451 MB, past the Infinity Cache) +2 - 5 %, K = 4096 -1 - 2 % (its extra requests cost more energy than the shorter
   // stalls return).  VSTAR_GEMM4W_PF = 0 / 1 forces it off / on (A/B runs).
   static const int env_pf = [] { const char* e = getenv("VSTAR_GEMM4W_PF"); return e ? atoi(e) : -1; }();
-  const bool pf = env_pf >= 0 ? env_pf != 0 : (int64_t)p.K * (p.a_scale ? 1 : 2) >= 16384;      // K-tiles >= 128
+  // fp8: the same picture at 64 crops — K = 11008 +3 % (2828 -> 2911 TFLOP/s), K = 4096 within +-1 %
+  const bool pf = env_pf >= 0 ? env_pf != 0 : (p.a_scale || p.a_mx) ? p.K >= 8192 : (int64_t)p.K * 2 >= 16384;
 #ifndef VSTAR_LP_F16
+  if (p.a_mx) return pf ? launch<VSTAR_EPI_NONE, true, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true, true>(p, s);
   if (p.a_scale) {
     if (epilogue == VSTAR_EPI_NONE) return pf ? launch<VSTAR_EPI_NONE, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true>(p, s);
     if (epilogue == VSTAR_EPI_SILU_MUL) return pf ? launch<VSTAR_EPI_SILU_MUL, true, true>(p, s) : launch<VSTAR_EPI_SILU_MUL, false, true>(p, s);

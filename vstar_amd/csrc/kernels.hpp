@@ -54,7 +54,14 @@ struct GemmParams {
   // 1 KiB, each in the lane order of the LDS-DMA request that fetches it (skinny_pack_tiles): a workgroup then streams ONE sequential
   // region of HBM instead of 16 / 32 row streams 2 K bytes apart (tools/probes/stream_layout_probe.hip: gate|up 5.4 -> 7.0 TB/s)
   const lp_t* W_tiled;
+  // gemm4w only, W8A8 with block-scaled activations (mx.hpp; round 6).  a_mx != null (a_scale == null): A holds fp8 bytes whose E8M0
+  // block scales (one per row and 32 k, tile-major: mx_scale_offset with m128 = M / 128) are applied inside the MFMA; w_scale as above.
+  // c_mx != null (VSTAR_EPI_SILU_MUL): the epilogue writes SiLU(gate) * up as fp8 bytes to (uint8_t*)C (ldc in bytes) and the block
+  // scales to c_mx (same layout, consumer K = N / 2) instead of 16-bit values — bit-identical to storing them and running
+  // quantize_rows_mx over the result.  Both fail with hipErrorInvalidValue outside gemm4w's domain (gemm_mx_supported).
+  const uint8_t* a_mx; uint8_t* c_mx;
 };
+bool gemm_mx_supported(const GemmParams& p, int epilogue);
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);
 // GemmParams::tile_force / gemm_last_tile() value of the 4-wave / AGPR 256 x 256 kernel (gemm4w.hip; "256, 4 waves")
 constexpr int GEMM_TILE_4W = 2564;
@@ -113,6 +120,9 @@ hipError_t quantize_rows_fp8(const lp_t* x, int64_t ldx, uint8_t* q, int64_t ldq
 hipError_t rmsnorm_quant_fp8(const lp_t* x, const lp_t* gamma, uint8_t* q, float* scale, int rows, int cols, float eps,
                              hipStream_t s);
 
+// block-scaled twin (mx.hpp): x [rows, cols] 16-bit -> fp8 bytes q [rows, ldq] + E8M0 scales (tile-major, rows % 128 == 0, cols % 128 == 0)
+hipError_t quantize_rows_mx(const lp_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int rows, int cols, hipStream_t s);
+
 // ---- norms (norm.hip) ----
 // y[r] = LN(x[row_index ? row_index[r] : r]) ; act: 0 none, 1 exact GELU after the affine (LayerNorm2d+GELU)
 hipError_t layernorm_lp(const lp_t* x, const lp_t* gamma, const lp_t* beta, lp_t* y, int rows, int cols,
@@ -143,6 +153,10 @@ hipError_t attn_prepare(lp_t* qkv, const lp_t* cos_sin /*[S, D] = cos(D/2)|sin(D
                         hipStream_t s, int grp_R0 = 0, int grp_Lc = 0);
 hipError_t attn_forward(const lp_t* qkv, lp_t* out, int B, int S, int H, int D, int causal, float scale, hipStream_t s,
                         int grp_R0 = 0, int grp_Lc = 0);
+// causal D = 128 with the output written block-scaled (mx.hpp): fp8 bytes out8 [B*S, H*128] + E8M0 scales (m128 = B*S / 128; B*S % 128
+// == 0) — bit-identical to attn_forward followed by quantize_rows_mx
+hipError_t attn_forward_mx(const lp_t* qkv, uint8_t* out8, uint8_t* scales, int B, int S, int H, float scale, hipStream_t s,
+                           int grp_R0 = 0, int grp_Lc = 0);
 // generic small attention for the SAM head: q[B,Nq,H*D] k[B,Nk,H*D] v[B,Nk,H*D] -> out[B,Nq,H*D]; D <= 32, fp32 math
 hipError_t small_attention(const lp_t* q, const lp_t* k, const lp_t* v, lp_t* out, int B, int Nq, int Nk, int H,
                            int D, hipStream_t s);

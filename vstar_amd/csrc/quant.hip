@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include "common.hpp"
 #include "kernels.hpp"
+#include "mx.hpp"
 
 namespace VS_NS {
 
@@ -111,7 +112,40 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_kernel(const lp_t* __restri
   }
 }
 
+// block-scaled quantisation (mx.hpp): one thread per 8 values, four threads per block of 32
+__global__ __launch_bounds__(256) void quantize_rows_mx_kernel(const lp_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
+                                                               uint8_t* __restrict__ scales, int rows, int cols) {
+  const int per_row = cols >> 3;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)rows * per_row) return;            // (per_row % 4 == 0: a block's four threads leave together)
+  const int row = (int)(idx / per_row), c8 = (int)(idx - (int64_t)row * per_row);
+  const lpx8 v = *(const lpx8*)(x + (int64_t)row * ldx + c8 * 8);
+  float f[8], mx = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    f[e] = lp2f((lp_t)v[e]);
+    mx = fmaxf(mx, fabsf(f[e]));
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+  const uint32_t e8 = mx_e8m0(mx);
+  const float inv = mx_inv_scale(e8);
+  uint2 o;
+  o.x = mx_pack4(f[0] * inv, f[1] * inv, f[2] * inv, f[3] * inv);
+  o.y = mx_pack4(f[4] * inv, f[5] * inv, f[6] * inv, f[7] * inv);
+  *(uint2*)(q + (int64_t)row * ldq + c8 * 8) = o;
+  if ((c8 & 3) == 0) scales[mx_scale_offset(row, c8 >> 2, rows >> 7)] = (uint8_t)e8;
+}
+
 }  // namespace
+
+hipError_t quantize_rows_mx(const lp_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* scales, int rows, int cols, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if (rows % 128 || cols % 128 || ldx % 8 || ldq % 8) return hipErrorInvalidValue;
+  const int64_t n = (int64_t)rows * (cols / 8);
+  hipLaunchKernelGGL(quantize_rows_mx_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, ldx, q, ldq, scales, rows, cols);
+  return hipGetLastError();
+}
 
 hipError_t quantize_rows_fp8(const lp_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int cols,
                              hipStream_t s) {

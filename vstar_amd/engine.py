@@ -347,6 +347,11 @@ class VstarEngine:
         _lib.check(self.lib.vstar_profile_read_fp8(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.handle)
         return ms.value, n.value, fl.value
 
+    def w8a8_mx_active(self) -> bool:
+        """Whether the last scoring step ran o_proj / down_proj on block-scaled fp8 activations (csrc/mx.hpp; vstar_w8a8_mx_active):
+        W8A8 mode, >= 1024 rows, rows % 256 == 0 — else the per-token scheme (or bf16)."""
+        return self.lib.vstar_w8a8_mx_active(self.handle) == 1
+
     @property
     def stream(self) -> int:
         return int(self.lib.vstar_stream(self.handle) or 0)
