@@ -118,7 +118,16 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
   const int nsh = sfx ? (grp_Lc + KT - 1) / KT : 0;                   // key tiles of the shared prefix
   auto key0 = [&](int t) { return sfx ? (t < nsh ? t * KT : q0b + (t - nsh) * KT) : t * KT; };
 
-  // per-lane DMA sources
+  // per-lane DMA sources.  Round 6: buffer loads (SRD over the K / V columns of this sequence, per-lane byte offset fixed for the
+  // whole block, the tile's first key as the SCALAR offset) instead of one 64-bit address computation per instruction — the eight DMA
+  // instructions of a tile cost 1365 cycles of issue in round 5's timeline (profiles/r05_attn_timeline.txt), mostly VALU address
+  // arithmetic — and rows past the sequence's end fall outside the descriptor's range and read as ZERO (their probabilities are
+  // exactly 0 either way: masked keys) instead of being clamped per lane.
+#ifndef ATTN_BUFFER_DMA
+#define ATTN_BUFFER_DMA 1
+#endif
+  const int64_t ldb = ld * (int64_t)sizeof(lp_t);
+  uint32_t koffs[K_INST], voffs[K_INST];
   const lp_t* ksrc[K_INST];
   int krow_l[K_INST];
 #pragma unroll
@@ -128,6 +137,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
     const int sw = (D == 64) ? ((row >> 1) & 7) : (row & 15);
     krow_l[i] = row;
     ksrc[i] = Kg + (ch ^ sw) * 8;
+    koffs[i] = (uint32_t)(row * ldb + (ch ^ sw) * 16);
   }
   // V: the tile as it lies in the qkv buffer, [64 keys][D], DMA'd like the K tile and transposed on the way OUT of LDS by
   // ds_read_b64_tr_b16.  Its 16-byte chunks are swizzled per QUAD of chunks (64 bytes = what one half-wave reads of a key
@@ -140,10 +150,29 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
     const int ch = lane % KCH;
     const int gq = (D == 64) ? ((row >> 1) & 1) : (row & 3);
     vsrc[i] = Vg + (ch ^ (gq << 2)) * 8;
+    voffs[i] = (uint32_t)(row * ldb + (ch ^ (gq << 2)) * 16);
   }
+  // valid bytes from the first K (V) element of this sequence and head: rows 0 .. S - 1, D elements of the last row
+  const uint32_t span = (uint32_t)((int64_t)(S - 1) * ldb + D * (int)sizeof(lp_t));
+#if defined(__HIP_DEVICE_COMPILE__)      // (the resource type does not exist in the host pass, which would silently drop the kernel's stub)
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kg, 0, (int)span, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vg, 0, (int)span, 0x00020000);
+#endif
   auto stage = [&](int t) {
     char* base = smem + (t % NBUF) * 2 * KBYTES;
     const int kt0 = key0(t);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (ATTN_BUFFER_DMA) {
+      const int soff = __builtin_amdgcn_readfirstlane((int)(kt0 * ldb));
+#pragma unroll
+      for (int i = 0; i < K_INST; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, (lptr_t)(base + (i * 4 + wave) * 1024), 16, koffs[i], soff, 0, 0);
+#pragma unroll
+      for (int i = 0; i < K_INST; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, (lptr_t)(base + KBYTES + (i * 4 + wave) * 1024), 16, voffs[i], soff, 0, 0);
+      return;
+    }
+#endif
 #pragma unroll
     for (int i = 0; i < K_INST; ++i) {
       int kr = kt0 + krow_l[i];
@@ -345,6 +374,35 @@ __global__ __launch_bounds__(256) void attn2_kernel(const lp_t* __restrict__ qkv
         const u32x4 o = {s02[0], s02[1], s13[0], s13[1]};
         *(u32x4*)(op8 + db * 32) = o;
         if (h2 == 0) mxs[mx_scale_offset(row, h * DB + db, m128)] = (uint8_t)e8;
+      }
+    }
+    return;
+  }
+#ifndef ATTN_WIDE_STORES
+#define ATTN_WIDE_STORES 1
+#endif
+  if constexpr (ATTN_WIDE_STORES) {
+    // Round 6: this lane's 8-byte pieces (d = db * 32 + g * 8 + 4 * h2 + e) and lane ^ 32's interleave; two half swaps per dword turn
+    // them into 16 consecutive d per lane (h2 = 0: d = db * 32 + 0..15, h2 = 1: 16..31) = two 16-byte stores instead of four 8-byte
+    // ones — the store tail of a block is issue-bound (MI355X guide T21).  Same values, same addresses.
+    const float inv = 1.0f / l;
+    lp_t* op = out + ((int64_t)b * S + query) * ((int64_t)H * D) + h * D + 16 * h2;
+    const bool wr = active && query < S;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      uint32_t pk[4][2];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          pk[g][k] = (uint32_t)(uint16_t)f2lp(oacc[db][g * 4 + 2 * k] * inv) | ((uint32_t)(uint16_t)f2lp(oacc[db][g * 4 + 2 * k + 1] * inv) << 16);
+      typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+      for (int gp = 0; gp < 2; ++gp) {       // (g = gp, g = gp + 2): h2 = 0 keeps group gp of both lanes, h2 = 1 group gp + 2
+        const auto s0 = __builtin_amdgcn_permlane32_swap(pk[gp][0], pk[gp + 2][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(pk[gp][1], pk[gp + 2][1], false, false);
+        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+        if (wr) *(u32x4*)(op + db * 32 + gp * 8) = o;
       }
     }
     return;
