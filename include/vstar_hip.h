@@ -316,11 +316,18 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* dev_A, const uint16_t* dev_W
  * consecutive k (the smallest power of two that brings the block's largest magnitude to <= 448), applied inside
  * v_mfma_scale_f32_16x16x128_f8f6f4 per lane — so the PRODUCERS (attention epilogue, gate|up epilogue) quantise, and the two stand-alone
  * per-token passes of the round-3 scheme disappear.  The engine uses it when llm_w8a8 is set and the step's row count is a multiple of
- * 256 (VSTAR_W8A8_MX=0 in the environment keeps the per-token scheme); vstar_w8a8_mx_active tells which one the last step ran.
+ * 256.  Level 2 (default): the residual stream ALSO leaves o_proj / down_proj as a block-scaled fp8 copy with sum-of-squares partials,
+ * q|k|v and gate|up consume it with their RMSNorm folded (weight into the fp8 W, 1 / rms as the per-row scale) — no activation
+ * quantisation pass is left.  VSTAR_W8A8_MX=1 / 0 in the environment: only o_proj / down_proj inputs / the per-token scheme;
+ * vstar_w8a8_mx_active returns the level the last step ran (0 / 1 / 2).
  * Scale bytes are TILE-MAJOR (vstar_op_mx_scale_offset(row, k / 32, rows)); rows % 128 == 0, cols % 128 == 0.  The reference has no
  * fp8 path: oracle/vsm_oracle.py::mx_fake_quant restates the arithmetic.  Op-level doors (device pointers, synchronous):
  *   vstar_op_quantize_mx     X [rows, cols] bf16 -> q [rows, cols] fp8 + scales (the stand-alone form the fused producers must equal)
- *   vstar_op_gemm_mx         C [M, N] bf16 = (Aq, a_scales) . quant_per_channel(W)^T (+ residual); M % 256 == 0, N % 256 == 0, K % 256 == 0
+ *   vstar_op_gemm_mx         (Aq, a_scales) . quant_per_channel(W)^T, optionally x row_scale[m] (the folded RMSNorm's 1 / rms);
+ *                            M % 256 == 0, N % 256 == 0, K % 256 == 0.  epilogue NONE: C [M, N] bf16 (+ residual); with dev_C8 also the
+ *                            block-scaled fp8 copy of the stored rows (dev_c_scales) and, if dev_sumsq, their sums of squares per 64
+ *                            columns [M, N / 64] — same bytes as vstar_op_quantize_mx over C.  epilogue SILU_MUL (W rows interleaved
+ *                            gate|up 16 | 16): [M, N / 2] as bf16 (dev_C8 null) or as fp8 + scales (dev_C8: dev_C unused)
  *   vstar_op_gemm_fp8_mxout  per-token-quantised A . W^T with W rows interleaved gate|up (16 | 16), SiLU(gate) * up written as fp8 + scales
  *                            [M, N / 2] — same bytes as vstar_op_gemm_fp8(..., VSTAR_EPI_SILU_MUL) followed by vstar_op_quantize_mx
  *                            (iters / gemm_ms as in vstar_op_gemm_fp8)
@@ -329,8 +336,9 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* dev_A, const uint16_t* dev_W
 size_t vstar_op_mx_scale_bytes(int rows, int cols);
 int64_t vstar_op_mx_scale_offset(int row, int k_block, int rows);
 int vstar_op_quantize_mx(void* stream, const uint16_t* dev_X, uint8_t* dev_q, uint8_t* dev_scales, int rows, int cols);
-int vstar_op_gemm_mx(void* stream, const uint8_t* dev_Aq, const uint8_t* dev_a_scales, const uint16_t* dev_W, const uint16_t* dev_residual,
-                     uint16_t* dev_C, int M, int N, int K, int iters, float* gemm_ms);
+int vstar_op_gemm_mx(void* stream, const uint8_t* dev_Aq, const uint8_t* dev_a_scales, const float* dev_row_scale, const uint16_t* dev_W,
+                     const uint16_t* dev_residual, uint16_t* dev_C, uint8_t* dev_C8, uint8_t* dev_c_scales, float* dev_sumsq, int M, int N, int K,
+                     int epilogue, int iters, float* gemm_ms);
 int vstar_op_gemm_fp8_mxout(void* stream, const uint16_t* dev_A, const uint16_t* dev_W, uint8_t* dev_C8, uint8_t* dev_c_scales, int M, int N,
                             int K, int iters, float* gemm_ms);
 int vstar_op_attention_mx(void* stream, const uint16_t* dev_qkv, uint8_t* dev_out8, uint8_t* dev_scales, int B, int S, int H);

@@ -159,12 +159,23 @@ def linear_w8a8_mx(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return ((xd @ wq.T) * sw.transpose(-1, -2)).to(x.dtype)
 
 
+def linear_w8a8_mx_folded(x: torch.Tensor, w: torch.Tensor, g: torch.Tensor, eps: float) -> torch.Tensor:
+    """Linear(RMSNorm_g(x)) as the fully block-scaled chain runs it (engine level 2): the RAW rows x block-scaled, the norm weight folded
+    into the columns of W (rounded to the storage type, then per-output-channel e4m3), 1 / rms(x) applied to the accumulators."""
+    xd, _ = mx_fake_quant(x)
+    wq, sw = fp8_fake_quant((w.float() * g.float()).to(w.dtype))
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + eps)
+    return ((xd @ wq.T) * rstd * sw.transpose(-1, -2)).to(x.dtype)
+
+
 def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, theta: float,
-                  final_norm: bool = True, w8a8: bool = False, mx: bool = False) -> torch.Tensor:
+                  final_norm: bool = True, w8a8: bool = False, mx: int = 0) -> torch.Tensor:
     """w8a8: the four big linears of every block on fake-quantised operands, as the engine's config-5 mode runs them —
     except o_proj / MLP of the LAST block, which the engine evaluates on the few needed rows with the 16-bit weights.
-    mx (with w8a8): the inputs of o_proj and down_proj block-scaled (the engine's scheme when the step's rows are a multiple of 256)."""
+    mx (with w8a8; VstarEngine.w8a8_mx_active()): 0 = per-token activation scales everywhere; 1 = the inputs of o_proj and down_proj
+    block-scaled; 2 = also the inputs of q|k|v and gate|up (raw residual stream block-scaled, RMSNorm folded: linear_w8a8_mx_folded)."""
     B, S, H = x.shape
+    mx = int(mx)
     lin8 = (lambda key, t: (linear_w8a8_mx if mx and key.endswith(("o_proj", "down_proj")) else linear_w8a8)(t, sd[key + ".weight"])) if w8a8 else None
     hd = H // heads
     cos, sin = rope_tables(S, hd, theta, x.dtype, x.device)
@@ -174,6 +185,9 @@ def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, 
         h = rms_norm(x, sd[lp + "input_layernorm.weight"], eps)
         proj = (lambda key, t, last_ok=True: lin8(key, t)) if w8a8 else (lambda key, t, last_ok=True: _lin(sd, key, t, False))
         post = proj if (not w8a8 or i + 1 < layers) else (lambda key, t: _lin(sd, key, t, False))
+        if w8a8 and mx >= 2:      # q|k|v / gate|up straight from the raw rows (their norm folded); `h` is then unused by them
+            x_in = x
+            proj = lambda key, t, g=sd[lp + "input_layernorm.weight"], x_in=x_in: linear_w8a8_mx_folded(x_in, sd[key + ".weight"], g, eps)  # noqa: E731
         q = proj(lp + "self_attn.q_proj", h).view(B, S, heads, hd).transpose(1, 2)
         k = proj(lp + "self_attn.k_proj", h).view(B, S, heads, hd).transpose(1, 2)
         v = proj(lp + "self_attn.v_proj", h).view(B, S, heads, hd).transpose(1, 2)
@@ -184,7 +198,10 @@ def llama_prefill(sd: SD, x: torch.Tensor, heads: int, layers: int, eps: float, 
         att = (w @ v).transpose(1, 2).reshape(B, S, H)
         x = x + post(lp + "self_attn.o_proj", att)
         h = rms_norm(x, sd[lp + "post_attention_layernorm.weight"], eps)
-        x = x + post(lp + "mlp.down_proj", F.silu(post(lp + "mlp.gate_proj", h)) * post(lp + "mlp.up_proj", h))
+        gu = post
+        if w8a8 and mx >= 2 and i + 1 < layers:
+            gu = lambda key, t, g=sd[lp + "post_attention_layernorm.weight"], x_in=x: linear_w8a8_mx_folded(x_in, sd[key + ".weight"], g, eps)  # noqa: E731
+        x = x + post(lp + "mlp.down_proj", F.silu(gu(lp + "mlp.gate_proj", h)) * gu(lp + "mlp.up_proj", h))
     return rms_norm(x, sd["model.norm.weight"], eps) if final_norm else x
 
 
@@ -354,7 +371,7 @@ def upsample_mask(low_res: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
 # The whole path
 # ------------------------------------------------------------------------------------------------------------
 def vsm_forward(sd: SD, cfg, images_clip: torch.Tensor, images: Optional[torch.Tensor], input_ids: torch.Tensor,
-                loc_token_idx: int, verify_pos: Optional[torch.Tensor] = None, w8a8_mx: bool = False) -> Dict[str, torch.Tensor]:
+                loc_token_idx: int, verify_pos: Optional[torch.Tensor] = None, w8a8_mx: int = 0) -> Dict[str, torch.Tensor]:
     """model_forward(inference=True) batched over independent crops (each crop = one reference call with batch 1).
     `cfg` is a vstar_amd.config.VSMConfig (only its integer fields are read).  w8a8_mx: with cfg.llm_w8a8, the block-scaled scheme for
     the inputs of o_proj / down_proj (what the engine ran: VstarEngine.w8a8_mx_active())."""

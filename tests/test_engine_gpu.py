@@ -428,7 +428,7 @@ def test_w8a8_real_widths(cuda):
         res[name] = (eng.debug_read("llm_hidden_loc", B * cfg.llm_hidden).reshape(B, -1), out)
         mx = eng.w8a8_mx_active()
         eng.close()
-    assert mx == (os.environ.get("VSTAR_W8A8_MX", "1") != "0")          # 2 x 640 rows: the block-scaled scheme (round 6) unless switched off
+    assert mx == int(os.environ.get("VSTAR_W8A8_MX", "2"))              # 2 x 640 rows: the fully block-scaled chain (round 6) unless switched down
     sd32 = {k: v.float() for k, v in sd.items()}
     ref8 = vsm_oracle.vsm_forward(sd32, cfg8, clip.float(), owl.float(), ids, loc_id, w8a8_mx=mx)
     rep = {"hidden w8a8 vs fake-quant oracle": rel_l2(res["w8a8"][0], ref8["llm_hidden_loc"].numpy()),

@@ -74,7 +74,7 @@ def test_gemm_mx_matches_the_fake_quant_oracle(lib, cuda, M, N, K):
     outs = []
     for _ in range(3):
         C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=cuda)
-        rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), P(W), P(res), P(C), M, N, K, 0, None)
+        rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), None, P(W), P(res), P(C), None, None, None, M, N, K, 0, 0, None)
         assert rc == 0, lib.vstar_last_error(None)
         outs.append(C)
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)) and torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
@@ -124,6 +124,66 @@ def test_attention_epilogue_quantises_like_store_then_quantize(lib, cuda, B, S, 
     assert torch.equal(q, q_ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1280, 4096, 4096), (2560, 4096, 11008)])
+def test_residual_stream_epilogue_quantises_like_store_then_quantize(lib, cuda, M, N, K):
+    """o_proj / down_proj in the fully block-scaled chain: block-scaled A, optional per-row scale, + residual -> the 16-bit rows AND their
+    fp8 copy + scales AND sum-of-squares partials.  The 16-bit rows must equal the plain MX consumer's, the fp8 copy must equal
+    vstar_op_quantize_mx over them, the partials must give the RMSNorm statistics of the stored rows."""
+    g = torch.Generator(device=cuda).manual_seed(M + N + K + 1)
+    A = outlier_rows(g, M, K, cuda)
+    W = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K) * (0.5 + torch.rand(N, 1, generator=g, device=cuda))).bfloat16()
+    res = (torch.randn(M, N, generator=g, device=cuda) * 0.5).bfloat16()
+    rs = (0.25 + torch.rand(M, generator=g, device=cuda)).float()
+    q, sc = quantize_mx(lib, A)
+    for row_scale in (None, rs):
+        C0 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=cuda)
+        rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), P(row_scale), P(W), P(res), P(C0), None, None, None, M, N, K, 0, 0, None)
+        assert rc == 0, lib.vstar_last_error(None)
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=cuda)
+        C8 = torch.full((M, N), 0x7F, dtype=torch.uint8, device=cuda)
+        cs = torch.zeros(lib.vstar_op_mx_scale_bytes(M, N), dtype=torch.uint8, device=cuda)
+        ss = torch.full((M, N // 64), float("nan"), dtype=torch.float32, device=cuda)
+        rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), P(row_scale), P(W), P(res), P(C), P(C8), P(cs), P(ss), M, N, K, 0, 0, None)
+        assert rc == 0, lib.vstar_last_error(None)
+        assert torch.equal(C.view(torch.int16), C0.view(torch.int16))
+        q_ref, sc_ref = quantize_mx(lib, C)
+        assert torch.equal(cs, sc_ref) and torch.equal(C8, q_ref)
+        ref_ss = (C.float() ** 2).view(M, N // 64, 64).sum(-1)
+        assert torch.allclose(ss, ref_ss, rtol=1e-5, atol=1e-6)
+    if True:      # the per-row scale really multiplies the accumulators (before the residual)
+        Ca = torch.zeros(M, N, dtype=torch.bfloat16, device=cuda)
+        lib.vstar_op_gemm_mx(None, P(q), P(sc), P(rs), P(W), None, P(Ca), None, None, None, M, N, K, 0, 0, None)
+        Cb = torch.zeros(M, N, dtype=torch.bfloat16, device=cuda)
+        lib.vstar_op_gemm_mx(None, P(q), P(sc), None, P(W), None, P(Cb), None, None, None, M, N, K, 0, 0, None)
+        assert ((Ca.float() - Cb.float() * rs[:, None]).abs().max() <= 1e-2 * Cb.float().abs().max() * rs.max()).item()
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 256), (1280, 22016, 4096)])
+def test_gate_up_on_block_scaled_input(lib, cuda, M, N, K):
+    """gate|up consuming a block-scaled A with the folded norm's row scale: bf16 output vs the fake-quant oracle, and the fp8 output
+    equal to store + quantize."""
+    g = torch.Generator(device=cuda).manual_seed(M + N + K + 2)
+    A = outlier_rows(g, M, K, cuda)
+    W = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K) * 3).bfloat16()
+    rs = (1.0 / A.float().pow(2).mean(-1).sqrt()).float().contiguous()
+    q, sc = quantize_mx(lib, A)
+    C = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=cuda)
+    rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), P(rs), P(W), None, P(C), None, None, None, M, N, K, 4, 0, None)
+    assert rc == 0, lib.vstar_last_error(None)
+    dec = vsm_oracle.mx_fake_quant(A.cpu())[0].to(cuda)
+    wq, sw = (t.to(cuda) for t in vsm_oracle.fp8_fake_quant(W.cpu()))
+    y = ((dec @ wq.T) * sw.T * rs[:, None]).view(M, N // 32, 2, 16)
+    ref = (torch.nn.functional.silu(y[:, :, 0].bfloat16().float()).bfloat16().float() * y[:, :, 1].bfloat16().float()).reshape(M, N // 2)
+    err = (C.float() - ref).abs().max().item()
+    assert err <= 2e-2 * ref.abs().max().item(), (err, ref.abs().max().item())
+    q_ref, sc_ref = quantize_mx(lib, C)
+    C8 = torch.full((M, N // 2), 0x7F, dtype=torch.uint8, device=cuda)
+    cs = torch.zeros_like(sc_ref)
+    rc = lib.vstar_op_gemm_mx(None, P(q), P(sc), P(rs), P(W), None, None, P(C8), P(cs), None, M, N, K, 4, 0, None)
+    assert rc == 0, lib.vstar_last_error(None)
+    assert torch.equal(cs, sc_ref) and torch.equal(C8, q_ref)
+
+
 def test_mx_doors_refuse_shapes_outside_the_domain(lib, cuda):
     x = torch.zeros(100, 128, dtype=torch.bfloat16, device=cuda)
     assert lib.vstar_op_mx_scale_bytes(100, 128) == 0 and lib.vstar_op_mx_scale_bytes(128, 96) == 0
@@ -133,4 +193,4 @@ def test_mx_doors_refuse_shapes_outside_the_domain(lib, cuda):
     sc = torch.zeros(1152 * 8, dtype=torch.uint8, device=cuda)
     W = torch.zeros(256, 256, dtype=torch.bfloat16, device=cuda)
     C = torch.zeros(1152, 256, dtype=torch.bfloat16, device=cuda)
-    assert lib.vstar_op_gemm_mx(None, P(A), P(sc), P(W), None, P(C), 1152, 256, 256, 0, None) != 0
+    assert lib.vstar_op_gemm_mx(None, P(A), P(sc), None, P(W), None, P(C), None, None, None, 1152, 256, 256, 0, 0, None) != 0

@@ -45,7 +45,7 @@ for name, N, K, epi in [("qkv", 12288, 4096, 0), ("o", 4096, 4096, 0), ("gate_up
             q8 = torch.empty(M, K, device=dev, dtype=torch.uint8); sc = torch.empty(lib.vstar_op_mx_scale_bytes(M, K), device=dev, dtype=torch.uint8)
             assert lib.vstar_op_quantize_mx(None, P(a), P(q8), P(sc), M, K) == 0
             for _ in range(3):
-                assert lib.vstar_op_gemm_mx(None, P(q8), P(sc), P(w), None, P(c), M, N, K, 10, ctypes.byref(t)) == 0, lib.vstar_last_error(None)
+                assert lib.vstar_op_gemm_mx(None, P(q8), P(sc), None, P(w), None, P(c), None, None, None, M, N, K, 0, 10, ctypes.byref(t)) == 0, lib.vstar_last_error(None)
                 bm = min(bm, t.value)
             mxs = f"  | mx in  {fl / bm / 1e9:7.0f} x{best[0x800] / bm:.3f}"
     print(f"{name:22s} {N:6d} {K:6d} {ms.value:8.3f} {fl / ms.value / 1e9:9.1f} {bms:8.3f} {fl / bms / 1e9:9.1f} {bms / ms.value:5.2f}   | "

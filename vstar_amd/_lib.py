@@ -150,7 +150,7 @@ def load() -> ctypes.CDLL:
     lib.vstar_op_mx_scale_offset.restype = ctypes.c_int64
     lib.vstar_op_quantize_mx.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int]
     lib.vstar_op_quantize_mx.restype = c_int
-    lib.vstar_op_gemm_mx.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float)]
+    lib.vstar_op_gemm_mx.argtypes = [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, POINTER(c_float)]
     lib.vstar_op_gemm_mx.restype = c_int
     lib.vstar_op_gemm_fp8_mxout.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_float)]
     lib.vstar_op_gemm_fp8_mxout.restype = c_int

@@ -37,10 +37,12 @@ struct vstar_engine : EngineBase {
   int Smax = 0;
   uint8_t* lq8 = nullptr; float* lsa = nullptr;      // W8A8: quantised activation rows + per-token scales
   uint8_t* lmx = nullptr;                            // W8A8, block-scaled activations (mx.hpp): E8M0 bytes of the o_proj / down_proj inputs
-  int make_lin8(const Lin& L, Lin8* out);
+  int make_lin8(const Lin& L, Lin8* out, const lp_t* fold_g = nullptr);
+  uint8_t* lmxx = nullptr;                           // ... and of the residual stream (the q|k|v / gate|up inputs of the fully block-scaled chain)
+  int last_w8a8_chain = 0;                           // 0 per token, 1 block-scaled o_proj / down_proj inputs, 2 + q|k|v / gate|up inputs (norms folded)
   int lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
            const lp_t* res, int64_t ldr, const lp_t* rope_cs = nullptr, int rope_S = 0, int rope_cols = 0, const uint8_t* a_mx = nullptr,
-           uint8_t* c_mx = nullptr);
+           uint8_t* c_mx = nullptr, uint8_t* c8 = nullptr, float* sumsq = nullptr);
   bool last_w8a8_mx = false;   // whether the last llm_forward ran o_proj / down_proj on block-scaled activations (vstar_w8a8_mx_active)
   bool fused_rope = true;      // VSTAR_FUSED_ROPE=0 keeps RoPE as a separate pass (A/B and the bit-identity test)
   // RMSNorms of the LLaMA blocks folded into the linears that consume them (default; VSTAR_FOLD_NORMS=0 before vstar_create keeps
@@ -167,20 +169,33 @@ int vstar_engine::make_sam_attn(const std::string& pre, SamAttn* a) {
 }
 
 // W8A8 twin of a packed Linear: quantise the packed bf16 rows on the device (per output channel)
-int vstar_engine::make_lin8(const Lin& L, Lin8* out) {
+int vstar_engine::make_lin8(const Lin& L, Lin8* out, const lp_t* fold_g) {
   const int Npad = (L.N + 255) / 256 * 256;
   if (L.K % 256) { set_error("W8A8 needs K % 256 == 0"); return VSTAR_ERR_INVALID; }
   RC(dalloc(&out->W, (size_t)Npad * L.K));
   RC(dalloc(&out->s, (size_t)Npad));
+  if (fold_g) {      // fp8 of round16(W diag(g)): the consumer's RMSNorm weight folded into its columns (as the bf16 path folds it)
+    lp_t* tmp = nullptr;
+    HIPCHK(hipMalloc((void**)&tmp, (size_t)Npad * L.K * sizeof(lp_t)));
+    hipError_t e = hipMemcpyAsync(tmp, L.W, (size_t)Npad * L.K * sizeof(lp_t), hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = scale_cols_lp(tmp, fold_g, Npad, L.K, stream);
+    if (e == hipSuccess) e = quantize_rows_fp8(tmp, L.K, out->W, L.K, out->s, Npad, L.K, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(tmp);
+    HIPCHK(e);
+    return 0;
+  }
   KCHK(quantize_rows_fp8(L.W, L.K, out->W, L.K, out->s, Npad, L.K, stream));
   return 0;
 }
 
 int vstar_engine::lin8(const uint8_t* Aq, const float* sa, const Lin& L, const Lin8& L8, void* C, int64_t ldc, int M, int epi,
-                       const lp_t* res, int64_t ldr, const lp_t* rope_cs, int rope_S, int rope_cols, const uint8_t* a_mx, uint8_t* c_mx) {
+                       const lp_t* res, int64_t ldr, const lp_t* rope_cs, int rope_S, int rope_cols, const uint8_t* a_mx, uint8_t* c_mx,
+                       uint8_t* c8, float* sumsq) {
   GemmParams p{};
   p.A = (const lp_t*)Aq; p.lda = L.K; p.W = (const lp_t*)L8.W; p.res = res; p.ldr = ldr; p.C = C; p.ldc = ldc;
-  p.M = M; p.N = L.N; p.K = L.K; p.a_scale = a_mx ? nullptr : sa; p.w_scale = L8.s; p.a_mx = a_mx; p.c_mx = c_mx;
+  p.M = M; p.N = L.N; p.K = L.K; p.a_scale = sa; p.w_scale = L8.s; p.a_mx = a_mx; p.c_mx = c_mx;      // (sa next to a_mx: the folded norm's 1 / rms)
+  p.c8 = c8; p.ldc8 = L.N; p.sumsq_out = c8 ? sumsq : nullptr; p.sumsq_ld = L.N / 64;
   p.rope_cs = rope_cs; p.rope_S = rope_S; p.rope_cols = rope_cols; p.rope_R0 = grp_R0; p.rope_Lc = grp_Lc;
   return gemm(p, epi, false);
 }
@@ -237,6 +252,8 @@ int vstar_engine::finalize() {
       RC(make_lin8(b.o, &b.o8));
       RC(make_lin8(b.gate_up, &b.gate_up8));
       RC(make_lin8(b.down, &b.down8));
+      RC(make_lin8(b.qkv, &b.qkv8f, b.in_norm));
+      RC(make_lin8(b.gate_up, &b.gate_up8f, b.post_norm));
     }
   }
   RC(upload_vec("model.norm.weight", &final_norm, H));
@@ -268,6 +285,7 @@ int vstar_engine::finalize() {
     RC(dalloc(&lq8, lrows * (size_t)(c.llm_mlp > H ? c.llm_mlp : H)));
     RC(dalloc(&lsa, lrows));
     RC(dalloc(&lmx, (lrows + 127) / 128 * 128 * (size_t)((c.llm_mlp > H ? c.llm_mlp : H) / 32 + 1)));
+    RC(dalloc(&lmxx, (lrows + 127) / 128 * 128 * (size_t)(H / 32 + 1)));
   }
   RC(dalloc(&hsel, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
   RC(dalloc(&sel_att, (size_t)maxB * (1 + VSTAR_MAX_VERIFY) * H));
@@ -578,7 +596,25 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
     q.a_scale = lsa; q.w_scale = b0.gate_up8.s; q.c_mx = lmx;
     mx = mx && gemm_mx_supported(q, VSTAR_EPI_SILU_MUL);
   }
+  // Fully block-scaled chain (VSTAR_W8A8_MX=1 stops at the step above; default 2): the residual stream ALSO leaves o_proj / down_proj
+  // as a block-scaled fp8 copy with sum-of-squares partials (mx_none_epilogue), q|k|v and gate|up consume it with the RMSNorm folded
+  // (weight into their fp8 W, 1 / rms as the per-row scale) — no rmsnorm_quant pass either.
+  static const int mx_level = [] { const char* e = getenv("VSTAR_W8A8_MX"); return e ? atoi(e) : 2; }();
+  bool chain = false;
+  if (mx && mx_level >= 2 && H % 256 == 0) {
+    GemmParams q{};
+    LlmBlock& b0 = llm[0];
+    q.A = (const lp_t*)latt; q.lda = H; q.W = (const lp_t*)b0.o8.W; q.C = lx; q.ldc = H; q.res = lx; q.ldr = H; q.M = rows; q.N = H; q.K = H;
+    q.w_scale = b0.o8.s; q.a_mx = lmx; q.c_mx = lmxx; q.c8 = lq8; q.ldc8 = H; q.sumsq_out = lpart; q.sumsq_ld = H / 64;
+    chain = gemm_mx_supported(q, VSTAR_EPI_NONE);
+    q = GemmParams{};
+    q.A = (const lp_t*)lq8; q.lda = H; q.W = (const lp_t*)b0.qkv8f.W; q.C = lqkv; q.ldc = 3 * H; q.M = rows; q.N = b0.qkv.N; q.K = H;
+    q.a_scale = lr; q.w_scale = b0.qkv8f.s; q.a_mx = lmxx;
+    if (fused_rope) { q.rope_cs = rope; q.rope_S = S; q.rope_cols = 2 * H; }
+    chain = chain && gemm_mx_supported(q, VSTAR_EPI_NONE);
+  }
   last_w8a8_mx = mx;
+  last_w8a8_chain = chain ? 2 : mx ? 1 : 0;
   // Shared prefix (VSTAR_F_SHARE_PREFIX, psh_Lp > 0): the first Lp positions of every sequence are the same tokens, so they run
   // ONCE, as a sequence of their own in the rows [Lp, 2 Lp) of slot `nseq` of the activation buffers.  The linears see the
   // compact row set {rows [Lp, S) of every sequence} + {the prefix rows} through a periodic row map (group S - Lp, stride S,
@@ -603,7 +639,18 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
   for (int i = 0; i < c.llm_layers; ++i) {
     LlmBlock& b = llm[i];
     set_map(true);
-    if (w8) {
+    if (chain) {
+      // rows of lx as block-scaled fp8 (lq8 / lmxx) + their 1 / rms (lr): from the splice for the first block, from the previous
+      // block's down_proj epilogue afterwards
+      if (i == 0) {
+        KCHK(quantize_rows_mx(lx, H, lq8, H, lmxx, rows, H, stream));
+        KCHK(rms_rstd_rows(lx, rows, H, c.llm_rms_eps, lr, stream));
+      } else {
+        KCHK(rms_rstd_partials(lpart, H / 64, rows, H, c.llm_rms_eps, lr, stream));
+      }
+      RC(lin8(lq8, lr, b.qkv, b.qkv8f, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H, lmxx));
+      if (!fused_rope) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
+    } else if (w8) {
       KCHK(rmsnorm_quant_fp8(lx, b.in_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
       RC(lin8(lq8, lsa, b.qkv, b.qkv8, lqkv, 3 * H, rows, VSTAR_EPI_NONE, nullptr, 0, fused_rope ? rope : nullptr, S, 2 * H));
       if (!fused_rope) KCHK(attn_prepare(lqkv, rope, nseq, S, c.llm_heads, 128, stream, grp_R0, grp_Lc));
@@ -652,7 +699,12 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
       RC(lin(sel_act, c.llm_mlp, b.down, sel_x, H, nsel, VSTAR_EPI_NONE, sel_x, H));
       break;
     }
-    if (mx) {
+    if (chain) {
+      RC(lin8((const uint8_t*)latt, nullptr, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H, nullptr, 0, 0, lmx, lmxx, lq8, lpart));
+      KCHK(rms_rstd_partials(lpart, H / 64, rows, H, c.llm_rms_eps, lr, stream));
+      RC(lin8(lq8, lr, b.gate_up, b.gate_up8f, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0, nullptr, 0, 0, lmxx, lmx));
+      RC(lin8((const uint8_t*)lact, nullptr, b.down, b.down8, lx, H, rows, VSTAR_EPI_NONE, lx, H, nullptr, 0, 0, lmx, lmxx, lq8, lpart));
+    } else if (mx) {
       RC(lin8((const uint8_t*)latt, nullptr, b.o, b.o8, lx, H, rows, VSTAR_EPI_NONE, lx, H, nullptr, 0, 0, lmx, nullptr));
       KCHK(rmsnorm_quant_fp8(lx, b.post_norm, lq8, lsa, rows, H, c.llm_rms_eps, stream));
       RC(lin8(lq8, lsa, b.gate_up, b.gate_up8, lact, c.llm_mlp, rows, VSTAR_EPI_SILU_MUL, nullptr, 0, nullptr, 0, 0, nullptr, lmx));
@@ -1583,26 +1635,29 @@ int vstar_op_quantize_mx(void* stream, const uint16_t* X, uint8_t* q, uint8_t* s
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
-int vstar_op_gemm_mx(void* stream, const uint8_t* Aq, const uint8_t* a_scales, const uint16_t* W, const uint16_t* res, uint16_t* C, int M,
-                     int N, int K, int iters, float* gemm_ms) {
-  if (!Aq || !a_scales || !W || !C || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
+int vstar_op_gemm_mx(void* stream, const uint8_t* Aq, const uint8_t* a_scales, const float* row_scale, const uint16_t* W, const uint16_t* res,
+                     uint16_t* C, uint8_t* C8, uint8_t* c_scales, float* sumsq, int M, int N, int K, int epilogue, int iters, float* gemm_ms) {
+  if (!Aq || !a_scales || !W || (!C && !C8) || M <= 0 || N <= 0 || K <= 0) { tls_error() = "bad argument"; return VSTAR_ERR_INVALID; }
   hipStream_t s = (hipStream_t)stream;
   const int Npad = (N + 255) / 256 * 256;
+  const int n_out = epilogue == VSTAR_EPI_SILU_MUL ? N / 2 : N;
   uint8_t* Wq = nullptr;
   float* sw = nullptr;
   hipError_t e = hipMalloc((void**)&Wq, (size_t)Npad * K);
   if (e == hipSuccess) e = hipMalloc((void**)&sw, (size_t)Npad * 4);
   if (e == hipSuccess) e = quantize_rows_fp8(W, K, Wq, K, sw, Npad, K, s);
   GemmParams p{};
-  p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.res = res; p.ldr = N; p.C = C; p.ldc = N;
-  p.M = M; p.N = N; p.K = K; p.w_scale = sw; p.a_mx = a_scales;
-  if (e == hipSuccess && !gemm_mx_supported(p, VSTAR_EPI_NONE)) { tls_error() = "shape not accepted by the block-scaled W8A8 kernel"; e = hipErrorInvalidValue; }
-  if (e == hipSuccess) e = gemm_lp(p, VSTAR_EPI_NONE, false, s);
+  p.A = (const lp_t*)Aq; p.lda = K; p.W = (const lp_t*)Wq; p.res = res; p.ldr = n_out; p.M = M; p.N = N; p.K = K;
+  p.w_scale = sw; p.a_mx = a_scales; p.a_scale = row_scale;
+  if (epilogue == VSTAR_EPI_SILU_MUL && C8) { p.C = C8; p.ldc = n_out; p.c_mx = c_scales; }       // fp8 out only
+  else { p.C = C; p.ldc = n_out; p.c8 = C8; p.ldc8 = n_out; p.c_mx = C8 ? c_scales : nullptr; p.sumsq_out = C8 ? sumsq : nullptr; p.sumsq_ld = n_out / 64; }
+  if (e == hipSuccess && !gemm_mx_supported(p, epilogue)) { tls_error() = "shape not accepted by the block-scaled W8A8 kernel"; e = hipErrorInvalidValue; }
+  if (e == hipSuccess) e = gemm_lp(p, epilogue, false, s);
   if (e == hipSuccess && iters > 0 && gemm_ms) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, s);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) e = gemm_lp(p, VSTAR_EPI_NONE, false, s);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = gemm_lp(p, epilogue, false, s);
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -1653,7 +1708,7 @@ int vstar_op_attention_mx(void* stream, const uint16_t* qkv, uint8_t* out8, uint
   if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
   return op_rc(e);
 }
-int vstar_w8a8_mx_active(vstar_handle* h) { return h ? (h->last_w8a8_mx ? 1 : 0) : VSTAR_ERR_INVALID; }
+int vstar_w8a8_mx_active(vstar_handle* h) { return h ? h->last_w8a8_chain : VSTAR_ERR_INVALID; }
 
 size_t vstar_op_attention_workspace(int B, int S, int H, int D) {
   (void)B; (void)H;

@@ -43,7 +43,10 @@ struct VitTower {
 };
 // fp8 twin of a packed Linear (W8A8 mode): e4m3 rows + per-output-channel scales, same row order/padding as Lin::W
 struct Lin8 { uint8_t* W = nullptr; float* s = nullptr; };
-struct LlmBlock { lp_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; Lin8 qkv8, o8, gate_up8, down8; };
+struct LlmBlock {
+  lp_t *in_norm, *post_norm; Lin qkv, o, gate_up, down; Lin8 qkv8, o8, gate_up8, down8;
+  Lin8 qkv8f, gate_up8f;      // W8A8, fully block-scaled chain: fp8 of W diag(norm weight) (the RMSNorm folded into the linear)
+};
 
 #define HIPCHK(expr)                                                                         \
   do {                                                                                       \

@@ -82,10 +82,10 @@ template <int EPI, int H, bool F8, bool MX>
 __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
   if constexpr (F8) {
     // W8A8: per-row activation scale x per-output-channel weight scale, the latter in the permuted-row order of the direct tile (gemm256.hip)
-    // (MX: the activation's block scales were applied inside the MFMAs — only the weight scale is left)
+    // (MX: the activation's block scales were applied inside the MFMAs; a per-row scale is then optional — the folded RMSNorm's 1 / rms)
     float sa[8], sw[4][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) sa[m] = MX ? 1.0f : p.a_scale[em0 + wr * 128 + m * 16 + fr];
+    for (int m = 0; m < 8; ++m) sa[m] = (MX && !p.a_scale) ? 1.0f : p.a_scale[em0 + wr * 128 + m * 16 + fr];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       int sc;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
       for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[n][e] *= MX ? sw[n][e] : sa[m] * sw[n][e];
+        for (int e = 0; e < 4; ++e) a[n][e] *= sa[m] * sw[n][e];
     });
     return;
   }
@@ -137,7 +137,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 __device__ __forceinline__ void mx_silu_epilogue(const GemmParams& p, int em0, int en0, int wr, int wc2, int fr, int fq) {
   float sa[8], sw[2][4][4];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) sa[m] = p.a_scale[em0 + wr * 128 + m * 16 + fr];
+  for (int m = 0; m < 8; ++m) sa[m] = p.a_scale ? p.a_scale[em0 + wr * 128 + m * 16 + fr] : 1.0f;
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -187,6 +187,91 @@ __device__ __forceinline__ void mx_silu_epilogue(const GemmParams& p, int em0, i
 }
 #endif
 
+#ifndef VSTAR_LP_F16
+// o_proj / down_proj with the residual stream leaving TWICE (GemmParams::c8): the 16-bit rows (C, + residual, as always) and their
+// block-scaled fp8 copy — the A operand of the next q|k|v / gate|up, whose RMSNorm is folded (weight into W, 1 / rms as that GEMM's
+// row scale, from the sum-of-squares partials written here).  W rows DMA'd so that lane (fr, fq) owns 32 CONSECUTIVE columns of row
+// group m (fq * 32 + half * 16 + fragment * 4 + e): a block of 32 is one lane's — no cross-lane step — and the rows leave as four
+// 16-byte stores (16-bit) + two (fp8).  Rounding points of the plain epilogue (f2lp(acc), then f2lp(that + residual)); the fp8 bytes are
+// those of quantize_rows_mx over the stored rows (tests/test_mx_gpu.py).
+__device__ __forceinline__ void mx_none_epilogue(const GemmParams& p, int em0, int en0, int wr, int wc2, int fr, int fq) {
+  float sa[8], sw[2][4][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) sa[m] = p.a_scale ? p.a_scale[em0 + wr * 128 + m * 16 + fr] : 1.0f;
+  const int col = en0 + wc2 * 128 + fq * 32;
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const f32x4 t = *(const f32x4*)(p.w_scale + col + h * 16 + n * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sw[h][n][e] = t[e];
+    }
+  const int row0 = em0 + wr * 128 + fr;
+  lp_t* crow = (lp_t*)p.C + (int64_t)row0 * p.ldc + col;
+  const lp_t* rrow = p.res ? p.res + (int64_t)row0 * p.ldr + col : nullptr;
+  uint8_t* qrow = p.c8 + (int64_t)row0 * p.ldc8 + col;
+  float* sq = p.sumsq_out ? p.sumsq_out + (int64_t)row0 * p.sumsq_ld + (col >> 6) : nullptr;
+  uint32_t sc_lo = 0, sc_hi = 0;
+  gemm_static_for<8>([&](auto mc) {
+#pragma clang fp contract(off)
+    constexpr int m = decltype(mc)::value;
+    f32x4 a[2][4];
+    load_acc_row<0, m>(a[0]);
+    load_acc_row<1, m>(a[1]);
+    lpx8 r[4];
+    if (rrow) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) r[c] = *(const lpx8*)(rrow + c * 8);
+      rrow += 16 * p.ldr;
+    }
+    float f[32], mx = 0.f, ss = 0.f;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = h * 16 + n * 4 + e;
+          float v = rlp(a[h][n][e] * (sa[m] * sw[h][n][e]));
+          if (rrow) v = rlp(v + lp2f((lp_t)r[j >> 3][j & 7]));
+          f[j] = v;
+        }
+    lpx8 o[4];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      o[j >> 3][j & 7] = (short)f2lp(f[j]);
+      mx = fmaxf(mx, fabsf(f[j]));
+      ss += f[j] * f[j];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *(lpx8*)(crow + c * 8) = o[c];      // (cache-resident: the residual of the next epilogue)
+    crow += 16 * p.ldc;
+    if (sq) {
+      const uint32_t u = __float_as_uint(ss);
+      const auto w = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // lane ^ 16: the other half of the 64-column span
+      const float tot = __uint_as_float(w[0]) + __uint_as_float(w[1]);
+      if (!(fq & 1)) sq[0] = tot;
+      sq += 16 * p.sumsq_ld;
+    }
+    const uint32_t e8 = mx_e8m0(mx);
+    const float inv = mx_inv_scale(e8);
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 q;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        q[g] = mx_pack4(f[c * 16 + 4 * g] * inv, f[c * 16 + 4 * g + 1] * inv, f[c * 16 + 4 * g + 2] * inv, f[c * 16 + 4 * g + 3] * inv);
+      *(u32x4*)(qrow + c * 16) = q;
+    }
+    qrow += 16 * p.ldc8;
+    if (m < 4) sc_lo |= e8 << (8 * (m & 3)); else sc_hi |= e8 << (8 * (m & 3));
+  });
+  *(uint2*)(p.c_mx + mx_scale_offset(row0, col >> 5, p.M >> 7)) = make_uint2(sc_lo, sc_hi);
+}
+#endif
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -230,6 +315,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       int wrow;
       if (EPI == VSTAR_EPI_SILU_MUL && F8 && p.c_mx) {      // block-scaled fp8 out: 16 consecutive outputs per lane (mx_silu_epilogue)
         wrow = (wcr >> 1) * 128 + (ii >> 2) * 32 + (n & 1) * 16 + (wcr & 1) * 8 + (n >> 1) * 4 + (ii & 3);
+      } else if (EPI == VSTAR_EPI_NONE && F8 && p.c_mx) {   // ... 32 consecutive columns per lane (mx_none_epilogue)
+        wrow = (wcr >> 1) * 128 + (ii >> 2) * 32 + (wcr & 1) * 16 + n * 4 + (ii & 3);
       } else if (EPI == VSTAR_EPI_SILU_MUL) {
         const int jo = (ii >> 2) * 8 + (n >> 1) * 4 + (ii & 3);
         wrow = wcr * 64 + (jo >> 4) * 32 + (n & 1) * 16 + (jo & 15);
@@ -393,9 +480,15 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       const int fr = lane & 15, fq = lane >> 4;
       bool done = false;
 #ifndef VSTAR_LP_F16
-      if constexpr (F8 && !MX && EPI == VSTAR_EPI_SILU_MUL) {
+      if constexpr (F8 && EPI == VSTAR_EPI_SILU_MUL) {
         if (p.c_mx) {
           mx_silu_epilogue(p, em0, en0, wr, wc2, fr, fq);
+          done = true;
+        }
+      }
+      if constexpr (F8 && EPI == VSTAR_EPI_NONE) {
+        if (p.c_mx) {
+          mx_none_epilogue(p, em0, en0, wr, wc2, fr, fq);
           done = true;
         }
       }
@@ -446,10 +539,15 @@ bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
   if (p.a_scale || p.a_mx || p.c_mx) return false;
 #endif
   if (out_f32 || p.norm_w) return false;
-  if (p.a_mx && (p.a_scale || epilogue != VSTAR_EPI_NONE || p.rope_cs || ((uintptr_t)p.a_mx & 3))) return false;      // MX consumer: o_proj / down_proj
-  if (p.c_mx && (epilogue != VSTAR_EPI_SILU_MUL || !p.a_scale || ((uintptr_t)p.c_mx & 7) || p.ldc % 16)) return false;   // MX producer: gate|up (16-byte stores)
+  if (p.a_mx && ((epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_SILU_MUL) || ((uintptr_t)p.a_mx & 3))) return false;      // block-scaled A
+  if (p.c_mx) {      // block-scaled output: SiLU(gate) * up as fp8 only (C), or the residual stream as 16-bit rows (C) + fp8 copy (c8)
+    if (!(p.a_scale || p.a_mx) || ((uintptr_t)p.c_mx & 7)) return false;
+    if (epilogue == VSTAR_EPI_SILU_MUL) { if (p.ldc % 16 || p.c8) return false; }
+    else if (epilogue == VSTAR_EPI_NONE) { if (!p.c8 || ((uintptr_t)p.c8 & 15) || p.ldc8 % 16 || p.bias || p.rope_cs || p.stats_sum) return false; }
+    else return false;
+  } else if (p.c8) return false;
   if (p.a_scale || p.a_mx) {      // W8A8: the two epilogues the LLaMA linears use; K counts fp8 elements, two K-tiles of 128 per loop iteration
-    if (!p.w_scale || (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_SILU_MUL) || p.K % 256 || p.row_scale || p.sumsq_out) return false;
+    if (!p.w_scale || (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_SILU_MUL) || p.K % 256 || p.row_scale || (p.sumsq_out && !p.c8)) return false;
     static const bool f8_on = [] { const char* e = getenv("VSTAR_GEMM4W_F8"); return !e || atoi(e) != 0; }();
     if (!f8_on) return false;
   }
@@ -475,7 +573,11 @@ hipError_t gemm4w_lp(const GemmParams& p, int epilogue, hipStream_t s) {
   // fp8: the same picture at 64 crops — K = 11008 +3 % (2828 -> 2911 TFLOP/s), K = 4096 within +-1 %
   const bool pf = env_pf >= 0 ? env_pf != 0 : (p.a_scale || p.a_mx) ? p.K >= 8192 : (int64_t)p.K * 2 >= 16384;
 #ifndef VSTAR_LP_F16
-  if (p.a_mx) return pf ? launch<VSTAR_EPI_NONE, true, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true, true>(p, s);
+  if (p.a_mx) {
+    if (epilogue == VSTAR_EPI_NONE) return pf ? launch<VSTAR_EPI_NONE, true, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true, true>(p, s);
+    if (epilogue == VSTAR_EPI_SILU_MUL) return pf ? launch<VSTAR_EPI_SILU_MUL, true, true, true>(p, s) : launch<VSTAR_EPI_SILU_MUL, false, true, true>(p, s);
+    return hipErrorInvalidValue;
+  }
   if (p.a_scale) {
     if (epilogue == VSTAR_EPI_NONE) return pf ? launch<VSTAR_EPI_NONE, true, true>(p, s) : launch<VSTAR_EPI_NONE, false, true>(p, s);
     if (epilogue == VSTAR_EPI_SILU_MUL) return pf ? launch<VSTAR_EPI_SILU_MUL, true, true>(p, s) : launch<VSTAR_EPI_SILU_MUL, false, true>(p, s);

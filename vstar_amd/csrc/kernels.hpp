@@ -54,12 +54,16 @@ struct GemmParams {
   // 1 KiB, each in the lane order of the LDS-DMA request that fetches it (skinny_pack_tiles): a workgroup then streams ONE sequential
   // region of HBM instead of 16 / 32 row streams 2 K bytes apart (tools/probes/stream_layout_probe.hip: gate|up 5.4 -> 7.0 TB/s)
   const lp_t* W_tiled;
-  // gemm4w only, W8A8 with block-scaled activations (mx.hpp; round 6).  a_mx != null (a_scale == null): A holds fp8 bytes whose E8M0
+  // gemm4w only, W8A8 with block-scaled activations (mx.hpp; round 6).  a_mx != null: A holds fp8 bytes whose E8M0
   // block scales (one per row and 32 k, tile-major: mx_scale_offset with m128 = M / 128) are applied inside the MFMA; w_scale as above.
   // c_mx != null (VSTAR_EPI_SILU_MUL): the epilogue writes SiLU(gate) * up as fp8 bytes to (uint8_t*)C (ldc in bytes) and the block
   // scales to c_mx (same layout, consumer K = N / 2) instead of 16-bit values — bit-identical to storing them and running
   // quantize_rows_mx over the result.  Both fail with hipErrorInvalidValue outside gemm4w's domain (gemm_mx_supported).
   const uint8_t* a_mx; uint8_t* c_mx;
+  // ... and VSTAR_EPI_NONE with c_mx != null (o_proj / down_proj: residual stream out): C receives the 16-bit rows as usual AND c8
+  // [M, ldc8] their block-scaled fp8 copy (scales to c_mx) — the next linear's A operand, whose RMSNorm is folded: its weight into that
+  // linear's W, its 1 / rms applied as a_scale (allowed next to a_mx) from the sum-of-squares partials this epilogue writes (sumsq_out).
+  uint8_t* c8; int64_t ldc8;
 };
 bool gemm_mx_supported(const GemmParams& p, int epilogue);
 hipError_t gemm_lp(const GemmParams& p, int epilogue, bool out_f32, hipStream_t s);

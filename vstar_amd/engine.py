@@ -347,10 +347,11 @@ class VstarEngine:
         _lib.check(self.lib.vstar_profile_read_fp8(self.handle, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), self.handle)
         return ms.value, n.value, fl.value
 
-    def w8a8_mx_active(self) -> bool:
-        """Whether the last scoring step ran o_proj / down_proj on block-scaled fp8 activations (csrc/mx.hpp; vstar_w8a8_mx_active):
-        W8A8 mode, >= 1024 rows, rows % 256 == 0 — else the per-token scheme (or bf16)."""
-        return self.lib.vstar_w8a8_mx_active(self.handle) == 1
+    def w8a8_mx_active(self) -> int:
+        """Which W8A8 activation scheme the last scoring step ran (csrc/mx.hpp; vstar_w8a8_mx_active): 0 = per-token scales (or bf16:
+        fewer than 1024 rows / rows % 256 != 0), 1 = block-scaled inputs of o_proj / down_proj, 2 = the fully block-scaled chain
+        (q|k|v and gate|up too, RMSNorms folded)."""
+        return int(self.lib.vstar_w8a8_mx_active(self.handle))
 
     @property
     def stream(self) -> int:
