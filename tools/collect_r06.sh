@@ -9,6 +9,12 @@ if [ "$1" = "fp8" ]; then      # config 5 (W8A8, 64-crop batches): kernel statis
   rocprofv3 --kernel-trace --stats -d $RAW/stats8 -o k -- $B --fp8 --batch 64 --steps 3 --warmup 1 > /dev/null 2>&1
   cd $R
   python tools/rocpd_summary.py $(ls $RAW/stats8/*/k_results.db $RAW/stats8/k_results.db 2>/dev/null | head -1) > $OUT/kernel_stats_fp8.csv
+  for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES:m"; do
+    n=${c##*:}; ctr=${c%%:*}
+    (cd /tmp && rocprofv3 --pmc $ctr --kernel-trace -d $RAW/pmc8_$n -o pmc -- $B --fp8 --batch 64 --steps 1 --warmup 0 > /dev/null 2>&1) || echo "fp8 pass $n failed"
+  done
+  f8() { ls $RAW/pmc8_$1/*/pmc_results.db $RAW/pmc8_$1/pmc_results.db 2>/dev/null | head -1; }
+  python tools/pmc_summary.py $(f8 f) $(f8 w) $(f8 m) > $OUT/pmc_fp8.json
   $B --fp8 --batch 64 --steps 10 --warmup 3 2> $OUT/bench_fp8.err | tail -1 > $OUT/bench_fp8.json
   head -16 $OUT/kernel_stats_fp8.csv | cut -c1-180; python -c "
 import json; d=json.load(open('$OUT/bench_fp8.json')); print('fp8 bench', d['value'], d['ms_per_step'], d['roofline'])"
