@@ -55,6 +55,10 @@ def test_dispatch_rules():
     assert plan(lib, 1, "o") == 1285 and plan(lib, 1, "clip_out") == 1286
     # the fused-RoPE epilogue exists only in the 256^2 kernel: asking for it outside that kernel's domain is an error, not a re-route
     assert lib.vstar_op_gemm_plan(640, 12288, 4096, 0, 0, 1, 256) < 0
+    # rows that are no multiple of 256 (a prompt of another length): the LLaMA linears still take the 4-wave kernel (ragged last row
+    # tile, K >= 4096), the short-K ViT shapes stay where they were
+    assert all(lib.vstar_op_gemm_plan(32 * 623, N, K, e, r, ro, 256) == 25640
+               for (N, K, e, r, ro) in ((12288, 4096, 0, 0, 1), (4096, 4096, 0, 1, 0), (22016, 4096, 4, 0, 0), (4096, 11008, 0, 1, 0)))
     # explicit per-call tile requests are honoured or refused, never silently changed
     assert plan(lib, 32, "o", flags=_lib.EPI_TILE128) // 10 == 128
     assert plan(lib, 32, "o", flags=_lib.EPI_TILE256) == 2560

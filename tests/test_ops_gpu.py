@@ -375,6 +375,9 @@ def test_gemm128_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res, f32)
     (2048, 512, 11008, 0, False, True),         # long K (down_proj)
     (1024, 8192, 2048, 4, False, False),        # SiLU(gate)*up
     (20480, 4096, 4096, 0, True, True),         # the bench batch's o_proj rows: 1280 tiles, five per workgroup (persistent loop)
+    (1300, 512, 4096, 0, True, True),           # ragged last row tile (round 6: prompts whose rows are no multiple of 256): 20 of 256 rows
+    (2100, 768, 4096, 1, True, False),          # ragged + QUICK_GELU
+    (1111, 1024, 4096, 4, False, False),        # ragged (not even a multiple of 16) + SiLU(gate)*up
 ])
 def test_gemm4w_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res):
     """The 4-wave / AGPR 256^2 kernel (gemm4w.hip, hand-scheduled K loop) against the 8-wave gemm256 on the same operands: same k
@@ -396,7 +399,8 @@ def test_gemm4w_equals_gemm256(lib, cuda, M, N, K, epi, use_bias, use_res):
         assert bad == 0, (rep, bad)
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (2048, 4096, 4096, 0), (1280, 8192, 1024, 4), (20480, 4096, 11008, 0)])
+@pytest.mark.parametrize("M,N,K,epi", [(1024, 512, 256, 0), (2048, 4096, 4096, 0), (1280, 8192, 1024, 4), (20480, 4096, 11008, 0),
+                                       (1300, 512, 4096, 0), (2100, 1024, 4096, 4)])      # the last two: ragged last row tile
 def test_gemm4w_w8a8_equals_gemm256_w8a8(lib, cuda, M, N, K, epi):
     """Round 6: the W8A8 instantiation of the 4-wave kernel (v_mfma_scale_f32_16x16x128_f8f6f4 in its own generated K loop: two A
     fragment sets, W fragments refilled on a rolling basis) against gemm256's on the same quantised operands: same k order per
@@ -420,7 +424,7 @@ def test_gemm4w_w8a8_equals_gemm256_w8a8(lib, cuda, M, N, K, epi):
         assert torch.equal(c.view(torch.int16), outs[0].view(torch.int16))
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 4096, 256), (2048, 512, 1024)])
+@pytest.mark.parametrize("M,N,K", [(1024, 4096, 256), (2048, 512, 1024), (1300, 512, 4096)])
 def test_gemm4w_row_scale_and_statistics(lib, cuda, M, N, K):
     """Folded-norm row scale in, sum-of-squares partials out (the LLaMA o_proj / down / q|k|v forms): bit-identical to gemm256."""
     g = torch.Generator(device=cuda).manual_seed(M + N + K)
@@ -439,11 +443,33 @@ def test_gemm4w_row_scale_and_statistics(lib, cuda, M, N, K):
 
 
 def test_gemm4w_refuses_shapes_outside_its_domain(lib, cuda):
-    a = torch.randn(1100, 256, device=cuda).bfloat16()           # M % 256 != 0
-    w = torch.randn(256, 256, device=cuda).bfloat16()
+    a = torch.randn(1100, 256, device=cuda).bfloat16()           # M % 256 != 0 with a short K: gemm256's shape (a ragged last row tile is
+    w = torch.randn(256, 256, device=cuda).bfloat16()            # taken from K = 4096 up only)
     c = torch.empty(1100, 256, device=cuda, dtype=torch.bfloat16)
     rc = lib.vstar_op_gemm(None, P(a), 256, P(_pad_w(w)), None, None, 0, P(c), 256, 0, 1100, 256, 256, _lib.EPI_TILE4W)
     assert rc != 0
+
+
+@pytest.mark.parametrize("M", [1030, 1279])
+def test_gemm4w_ragged_tile_touches_nothing_past_the_matrix(lib, cuda, M):
+    """The last row tile of a ragged launch: rows >= M of the output, the residual and the statistics buffer stay untouched (the
+    epilogue skips them lane by lane), and A is read to the end of row M - 1 only — here it ends at the end of its allocation's
+    used part, with NaNs behind it that would poison the tile's valid rows if the DMA of the missing rows were not zero-filled."""
+    N, K = 512, 4096
+    g = torch.Generator(device=cuda).manual_seed(M)
+    abuf = torch.full((M + 256, K), float("nan"), dtype=torch.bfloat16, device=cuda)
+    abuf[:M] = torch.randn(M, K, generator=g, device=cuda).bfloat16()
+    w = (torch.randn(N, K, generator=g, device=cuda) / math.sqrt(K)).bfloat16()
+    cbuf = torch.full((M + 256, N), 123.0, dtype=torch.bfloat16, device=cuda)
+    rbuf = torch.randn(M + 256, N, generator=g, device=cuda).bfloat16()
+    rc = lib.vstar_op_gemm(None, P(abuf), K, P(_pad_w(w)), None, P(rbuf), N, P(cbuf), N, 0, M, N, K, _lib.EPI_TILE4W)
+    assert rc == 0, lib.vstar_last_error(None)
+    assert lib.vstar_op_gemm_last_tile() == _lib.TILE_4W
+    torch.cuda.synchronize()
+    assert (cbuf[M:] == 123.0).all()
+    ref = _gemm(lib, abuf[:M].contiguous(), w, None, rbuf[:M].contiguous(), tile=256)
+    assert not torch.isnan(cbuf[:M].float()).any()
+    assert torch.equal(cbuf[:M].view(torch.int16), ref.view(torch.int16))
 
 
 @pytest.mark.parametrize("name,M,N,K,epi,use_bias,use_res", [

@@ -26,7 +26,7 @@ def main():
         subprocess.check_call(cmd, cwd=CSRC, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     starts = [i for i, x in enumerate(lines) if re.match(r"^_ZN.*gemm4w_kernel.*:", x)]
-    want = 8 if extra else 16           # {NONE, QUICK_GELU, RELU, SILU_MUL} x {plain, prefetch} (+ the four W8A8 and the four block-scaled W8A8 kernels in the bf16 build)
+    want = 12 if extra else 22           # {NONE, QUICK_GELU, RELU, SILU_MUL} x {plain, prefetch} x {whole tiles, ragged last row tile} (+ eight W8A8 and four block-scaled W8A8 kernels in the bf16 build)
     assert len(starts) == want, f"expected {want} gemm4w kernels, found {len(starts)}"
     bad = 0
     for si, s in enumerate(starts):

@@ -206,7 +206,9 @@ def loop_text(shape, use_pf):
         # sit `stagger` MFMAs later, so the two halves of the CU do not hand their requests to the texture path in the same cycle
         sb = dict(shape, da=[x + stagger for x in shape["da"]], dw=[x + stagger for x in shape["dw"]])
         L += ["s_getreg_b32 m0, hwreg(HW_REG_HW_ID, 4, 1)", "s_cmp_eq_u32 m0, 0", "s_cbranch_scc0 .Lg4w_loopb_%="]
-    L += [".Lg4w_loop_%=:"]
+    # (the loop head on a 64-byte boundary: the text's speed must not depend on where the linker puts the kernel — adding kernels to the
+    # file moved the step by 0.2 %, MI355X guide: code-placement sensitivity of hand-written streams)
+    L += [".p2align 6", ".Lg4w_loop_%=:"]
     L += tile(0, True, True, shape) + tile(1, True, True, shape)
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%="]
     if stagger:
@@ -366,7 +368,7 @@ def loop_text_f8(use_pf, mx=False):
     L += ["s_waitcnt lgkmcnt(0)"]
     # first pair peeled off the loop?  No: tile 0 only differs in not re-reading W[7]; run it as the loop's first iteration with a flag
     # -> simpler: the text reads W[7] of tile 0 twice (prologue + slots 0, 1 of the tile): 2 redundant reads per OUTPUT tile.
-    L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%=", ".Lg4w_loop_%=:"]
+    L += ["s_cmp_eq_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_tail_%=", ".p2align 6", ".Lg4w_loop_%=:"]
     L += f8_tile(0, True, True, use_pf, mx=mx) + f8_tile(1, True, True, use_pf, mx=mx)
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 .Lg4w_loop_%=", ".Lg4w_tail_%=:"]
     L += f8_tile(0, True, False, use_pf, mx=mx) + f8_tile(1, False, False, use_pf, last=True, mx=mx)

@@ -29,7 +29,10 @@ template <int N, class F>
 __device__ __forceinline__ void gemm_static_for(F&& f) { gemm_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 
 // STATS: whether GemmParams::sumsq_out / stats_sum are honoured (not in the W8A8 instantiations)
-template <int EPI, bool STATS, class AccRow>
+// ROWGUARD (gemm4w, whose last row tile may be ragged — gemm256 sends its edge tiles through the LDS-transposed epilogue): rows >= M
+// are computed like any other (their A rows read as zero) but neither stored nor read — residual, RoPE position and statistics
+// accesses of such a row are skipped lane by lane.
+template <int EPI, bool STATS, bool ROWGUARD = false, class AccRow>
 __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq, AccRow&& acc_row) {
   constexpr bool SILU = (EPI == VSTAR_EPI_SILU_MUL);
   bool rope_tile = false;
@@ -50,7 +53,7 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
         v[e] = (short)f2lp(act_silu_bf16(rlp(a[0][e])) * rlp(a[1][e]));
         v[4 + e] = (short)f2lp(act_silu_bf16(rlp(a[2][e])) * rlp(a[3][e]));
       }
-      __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
+      if (!ROWGUARD || row0 + decltype(mc)::value * 16 < p.M) __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
       crow += 16 * p.ldc;
     });
   } else {
@@ -101,7 +104,7 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
         const int rope_d = (wc & 1) * 32 + fq * 8;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-          const int row = row0 + m * 16;
+          const int row = (!ROWGUARD || row0 + m * 16 < p.M) ? row0 + m * 16 : row0 & 15;      // (ragged tail: any valid row, result unused)
           int pos = row % p.rope_S;
           if (p.rope_R0 > 0 && pos >= p.rope_R0) pos = p.rope_Lc + ((pos - p.rope_R0) & 31);
           if (p.rope_tail > 0) pos = row >= p.rope_tail ? row - p.rope_tail : pos + p.rope_pos0;
@@ -129,8 +132,12 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
       const lp_t* rrow = p.res + (int64_t)row0 * p.ldr;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
-        ra[m] = *(const lpx8*)(rrow + col_a);
-        rb[m] = *(const lpx8*)(rrow + col_b);
+        if (!ROWGUARD || row0 + m * 16 < p.M) {
+          ra[m] = *(const lpx8*)(rrow + col_a);
+          rb[m] = *(const lpx8*)(rrow + col_b);
+        } else {
+          ra[m] = rb[m] = (lpx8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
         rrow += 16 * p.ldr;
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -149,7 +156,9 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       __builtin_amdgcn_sched_barrier(0);
-      if (p.sumsq_out) {          // the rows are the next linear's A operand right away: keep them cache-resident
+      const bool row_ok = !ROWGUARD || row0 + m * 16 < p.M;
+      if (!row_ok) {
+      } else if (p.sumsq_out) {          // the rows are the next linear's A operand right away: keep them cache-resident
         *(lpx8*)(crow + col_a) = pa[m];
         *(lpx8*)(crow + col_b) = pb[m];
       } else {
@@ -168,13 +177,13 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
                      (((fb[4] * fb[4] + fb[5] * fb[5]) + fb[6] * fb[6]) + fb[7] * fb[7]);
           qa += __shfl_xor(qa, 16, 64); qa += __shfl_xor(qa, 32, 64);
           qb += __shfl_xor(qb, 16, 64); qb += __shfl_xor(qb, 32, 64);
-          if (fq == 0) sq[0] = qa + qb;
+          if (fq == 0 && row_ok) sq[0] = qa + qb;
           if (p.stats_sum) {
             float sa = (((fa[0] + fa[1]) + fa[2]) + fa[3]) + (((fa[4] + fa[5]) + fa[6]) + fa[7]);
             float sb = (((fb[0] + fb[1]) + fb[2]) + fb[3]) + (((fb[4] + fb[5]) + fb[6]) + fb[7]);
             sa += __shfl_xor(sa, 16, 64); sa += __shfl_xor(sa, 32, 64);
             sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
-            if (fq == 0) sq[p.stats_sum] = sa + sb;
+            if (fq == 0 && row_ok) sq[p.stats_sum] = sa + sb;
           }
           sq += 16 * p.sumsq_ld;
         }

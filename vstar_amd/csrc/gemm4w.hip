@@ -10,8 +10,9 @@
 // 256x256x64 kernel does (facts read from its code object: DESIGN.md §5.1); the code is ours: same LDS image, same DMA
 // addressing, same permuted-W in-register epilogue and same k order as gemm256.hip, hence bit-identical results.
 //
-// Domain (everything else stays on gemm256.hip): bf16 / fp16 operands and output, M % 256 == 0, N % 256 == 0, K % 128 == 0,
-// identity row maps, 16-byte aligned C / residual / bias — i.e. launches made of interior tiles with the direct epilogue;
+// Domain (everything else stays on gemm256.hip): bf16 / fp16 operands and output, M % 256 == 0 — or any M >= 1024 when K >= 4096: the last
+// row tile may be ragged (template parameter RG) —, N % 256 == 0, K % 128 == 0, identity row maps, 16-byte aligned C / residual / bias —
+// i.e. launches whose tiles all take the direct epilogue;
 // epilogues NONE (+bias, +residual, fused RoPE, folded-norm row scale, sum-of-squares / sum statistics), QUICK_GELU, RELU, SILU_MUL.
 #include "common.hpp"
 #include "kernels.hpp"
@@ -78,14 +79,14 @@ __device__ __forceinline__ void load_acc_row(f32x4 (&a)[4]) {
 // The in-register epilogue of the 128 x 64 half H of the wave's tile = ONE virtual wave (wr, wc) of gemm256's 2 x 4 wave grid
 // (gemm256_direct_epilogue.hpp, shared with gemm256.hip).  The accumulators are read from the AGPRs ROW BY ROW where stage 1 consumes
 // them (16 registers at a time instead of the half's 128), with the folded-norm row scale applied on the way.
-template <int EPI, int H, bool F8, bool MX>
+template <int EPI, int H, bool F8, bool MX, bool RG>
 __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em0, int en0, int wr, int wc, int fr, int fq) {
   if constexpr (F8) {
     // W8A8: per-row activation scale x per-output-channel weight scale, the latter in the permuted-row order of the direct tile (gemm256.hip)
     // (MX: the activation's block scales were applied inside the MFMAs; a per-row scale is then optional — the folded RMSNorm's 1 / rms)
     float sa[8], sw[4][4];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) sa[m] = (MX && !p.a_scale) ? 1.0f : p.a_scale[em0 + wr * 128 + m * 16 + fr];
+    for (int m = 0; m < 8; ++m) sa[m] = (MX && !p.a_scale) ? 1.0f : p.a_scale[RG ? min(em0 + wr * 128 + m * 16 + fr, p.M - 1) : em0 + wr * 128 + m * 16 + fr];
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
       int sc;
@@ -96,7 +97,7 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
 #pragma unroll
       for (int e = 0; e < 4; ++e) sw[n][e] = t[e];
     }
-    gemm256_direct_epilogue<EPI, false>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
+    gemm256_direct_epilogue<EPI, false, RG>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
       // (no contraction: gemm256 dequantises in a loop of its own, far from the bias add; here the two meet after inlining and
       // `acc * scale + bias` as ONE fma rounds differently — 4 of 524288 outputs in the first W8A8 bias test)
 #pragma clang fp contract(off)
@@ -112,9 +113,9 @@ __device__ __forceinline__ void direct_epilogue_half(const GemmParams& p, int em
   float rs_v[8];            // RMSNorm / LayerNorm folded into this linear: rstd[row] * (x . (W * norm_w)^T)
   if (p.row_scale) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m) rs_v[m] = p.row_scale[em0 + wr * 128 + m * 16 + fr];
+    for (int m = 0; m < 8; ++m) rs_v[m] = p.row_scale[RG ? min(em0 + wr * 128 + m * 16 + fr, p.M - 1) : em0 + wr * 128 + m * 16 + fr];
   }
-  gemm256_direct_epilogue<EPI, true>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
+  gemm256_direct_epilogue<EPI, true, RG>(p, em0, en0, wr, wc, fr, fq, [&](auto mc, f32x4 (&a)[4]) {
 #pragma clang fp contract(off)      // (row scale x accumulator must not fuse with the bias add that follows after inlining, see the W8A8 branch)
     constexpr int m = decltype(mc)::value;
     load_acc_row<H, m>(a);
@@ -283,8 +284,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // bytes, a K-tile is still 128 bytes of every row (128 elements), one v_mfma_scale_f32_16x16x128_f8f6f4 replaces four bf16 MFMAs, the
 // accumulators are dequantised (per-row x per-output-channel scale) on their way out of the AGPRs.
 // MX (with F8): the A operand's E8M0 block scales (mx.hpp) ride along as a 17th DMA piece per K-tile and enter the MFMAs per lane.
-template <int EPI, bool PF, bool F8, bool MX>
+// RG: the launch's last row tile is ragged (M % 256 != 0): A is fetched through a bounded descriptor (rows past M read as zero) and the
+// epilogue skips those rows lane by lane; the interior-only instantiations keep the unguarded code (the guards cost 0.5 % of the step).
+template <int EPI, bool PF, bool F8, bool MX, bool RG>
 __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
+  static_assert(!(MX && RG), "block-scaled operands: whole 256-row tiles only");
   static_assert(!MX || F8, "block scales exist for the fp8 operands only");
   constexpr int ES = F8 ? 1 : 2;                       // bytes per operand element
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc2 = wave & 1;
-  const int tiles_m = p.M / BM, tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;      // the last row tile may be ragged (its missing A rows read as zero)
   const int nwg = tiles_m * tiles_n;
   const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
   const uint32_t ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
@@ -363,12 +367,29 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     if constexpr (MX) sbase = p.a_mx + (int64_t)(m0 >> 7) * 512;
   };
   // K-tiles 0 and 1 of the current tile -> LDS buffers 0 and 1 (32 DMA pieces per wave); the loop text starts behind a vmcnt(0)
+  // bytes of A that exist from the tile's first row on: everything a full tile touches, or — ragged last row tile — up to the end of
+  // row M - 1, so that the DMA of the missing rows is out of the descriptor's range and lands as ZEROS (never a read past the matrix)
+  auto a_span = [&]() -> int {
+    if constexpr (!RG) return -1;
+    const int rows_left = p.M - m0;
+    return rows_left >= BM ? -1 : (int)(((int64_t)rows_left - 1) * p.lda * ES + (int64_t)p.K * ES);
+  };
   auto issue_head = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t arsrc = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, a_span(), 0x00020000);
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(abase + va[i] + t * 128), (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, 0, 0);
+      for (int i = 0; i < 8; ++i) {
+        if constexpr (!RG) {
+          __builtin_amdgcn_global_load_lds((gptr_t)(abase + va[i] + t * 128), (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, 0, 0);
+        } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(arsrc, (lptr_t)(smem + t * 65536 + wave * 8192 + i * 1024), 16, va[i], t * 128, 0, 0);
+#endif
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(wbase + vw[i] + t * 128), (lptr_t)(smem + t * 65536 + 32768 + wave * 8192 + i * 1024), 16, 0, 0);
@@ -408,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
     uint32_t cnt = (uint32_t)(p.K * ES / 256 - 1);     // two K-tiles (of 128 bytes per row) per loop iteration, the last pair is peeled
     // buffer resource descriptors over the tile's rows (raw buffer: stride 0, no bound in practice, dword 3 = the gfx9 raw-buffer word)
     typedef __attribute__((ext_vector_type(4))) int i32x4;
-    const i32x4 srda = {(int)(uint32_t)(uintptr_t)abase, (int)(((uintptr_t)abase >> 32) & 0xffff), -1, 0x00020000};
+    const i32x4 srda = {(int)(uint32_t)(uintptr_t)abase, (int)(((uintptr_t)abase >> 32) & 0xffff), a_span(), 0x00020000};
     const i32x4 srdw = {(int)(uint32_t)(uintptr_t)wbase, (int)(((uintptr_t)wbase >> 32) & 0xffff), -1, 0x00020000};
     uint32_t koff = 256;                               // K-tiles 0 and 1 are in flight (issue_head): the loop's first pieces are K-tile 2
 #define G4W_OPERANDS(CLOB)                                                                                                           \
@@ -494,8 +515,8 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
       }
 #endif
       if (!done) {
-        direct_epilogue_half<EPI, 0, F8, MX>(p, em0, en0, wr, wc2 * 2, fr, fq);
-        direct_epilogue_half<EPI, 1, F8, MX>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
+        direct_epilogue_half<EPI, 0, F8, MX, RG>(p, em0, en0, wr, wc2 * 2, fr, fq);
+        direct_epilogue_half<EPI, 1, F8, MX, RG>(p, em0, en0, wr, wc2 * 2 + 1, fr, fq);
       }
     }
     G4W_STAMP(3);
@@ -508,11 +529,11 @@ __global__ __launch_bounds__(256, 1) void gemm4w_kernel(const GemmParams p) {
   }
 }
 
-template <int EPI, bool PF, bool F8 = false, bool MX = false>
-hipError_t launch(const GemmParams& p, hipStream_t s) {
+template <int EPI, bool PF, bool F8, bool MX, bool RG>
+hipError_t launch_rg(const GemmParams& p, hipStream_t s) {
   if (gemm_plan_only()) return hipSuccess;
   static bool attr_done = false;
-  auto kern = gemm4w_kernel<EPI, PF, F8, MX>;
+  auto kern = gemm4w_kernel<EPI, PF, F8, MX, RG>;
   constexpr int LDS_BYTES = LDS_TOTAL + (MX ? 2048 : 0);
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -520,9 +541,16 @@ hipError_t launch(const GemmParams& p, hipStream_t s) {
     attr_done = true;
   }
   const int n_cu = gemm_device_cus();
-  const int tiles = (p.M / BM) * (p.N / BN);
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   hipLaunchKernelGGL(kern, dim3(tiles < n_cu ? tiles : n_cu), dim3(256), LDS_BYTES, s, p);
   return hipGetLastError();
+}
+template <int EPI, bool PF, bool F8 = false, bool MX = false>
+hipError_t launch(const GemmParams& p, hipStream_t s) {
+  if constexpr (!MX) {      // ragged launches: the plain loop text (with the L2 prefetch duty down_proj measured 1384 instead of 1441 TFLOP/s)
+    if (p.M % BM) return launch_rg<EPI, false, F8, MX, true>(p, s);
+  }
+  return launch_rg<EPI, PF, F8, MX, false>(p, s);
 }
 
 }  // namespace
@@ -552,7 +580,10 @@ bool gemm4w_eligible(const GemmParams& p, int epilogue, bool out_f32) {
     if (!f8_on) return false;
   }
   if (epilogue != VSTAR_EPI_NONE && epilogue != VSTAR_EPI_QUICK_GELU && epilogue != VSTAR_EPI_RELU && epilogue != VSTAR_EPI_SILU_MUL) return false;
-  if (p.M < 1024 || p.M % BM || p.N % BN || p.K % 128 || p.K < 128) return false;
+  // a ragged last row tile is fine (A rows past M read as zero, the epilogue skips them) — except for the block-scaled operands, whose
+  // scale layout is per 128-row block, and for K < 4096 (the ViT shapes: gemm256 is the better kernel for them)
+  if (p.M % BM && (p.a_mx || p.c_mx || p.K < 4096)) return false;
+  if (p.M < 1024 || p.N % BN || p.K % 128 || p.K < 128) return false;
   if (p.a_group > 0 || p.c_group > 0 || (p.debug_flags & 5)) return false;
   if (((uintptr_t)p.C & 15) || (p.ldc % 8)) return false;
   if (p.res && (epilogue == VSTAR_EPI_SILU_MUL || ((uintptr_t)p.res & 15) || (p.ldr % 8))) return false;
