@@ -599,3 +599,15 @@ def test_entry_points_default_to_the_engine_collective_with_fallback():
     assert visual_search.parse_args(["--benchmark-folder", "x", "--engine-comm"]).engine_comm == "on"
     assert visual_search.parse_args(["--benchmark-folder", "x", "--engine-comm", "off", "--shard", "auto"]).shard == "auto"
     assert vstar_bench_eval.parse_args([]).engine_comm == "auto"
+
+
+def test_w8a8_prompt_padding_makes_full_batches_whole_tiles():
+    """vstar_amd/vsm.py::w8a8_padded_len: S = L - 1 + P becomes a multiple of 8 (so 32 x S and 64 x S are multiples of 256: the
+    block-scaled W8A8 chain's domain), never beyond max_text_len, never shorter."""
+    from vstar_amd.vsm import w8a8_padded_len
+    for P in (256, 576):
+        for L in range(20, 70):
+            Lp = w8a8_padded_len(L, P, 80)
+            assert L <= Lp <= L + 7 and (Lp - 1 + P) % 8 == 0 and (32 * (Lp - 1 + P)) % 256 == 0
+    assert w8a8_padded_len(64, 576, 65) == 65          # S = 639 -> 640
+    assert w8a8_padded_len(66, 576, 66) == 66          # no room: unchanged

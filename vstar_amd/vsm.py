@@ -61,6 +61,14 @@ class DeferredMismatch:
         return self._value
 
 
+def w8a8_padded_len(L: int, n_img_tokens: int, max_text_len: int) -> int:
+    """W8A8 (config 5): the block-scaled chain needs the step's rows to be a multiple of 256 (csrc/mx.hpp).  Right padding has no side
+    effects (causal mask: it cannot reach the scored positions), so the spliced length S = L - 1 + P is rounded up to a multiple of
+    8 — with the usual 32- / 64-crop batches the rows then ARE a multiple of 256, for at most 7 more positions per crop (1 %)."""
+    Lpad = L + (-(L - 1 + n_img_tokens)) % 8
+    return Lpad if Lpad <= max_text_len else L
+
+
 class VSM:
     def __init__(self, args=None, *, engine: Optional[VstarEngine] = None, tokenizer=None, cfg: Optional[VSMConfig] = None,
                  device: int = 0, synthetic_seed: Optional[int] = None, strict_template: Optional[bool] = None):
@@ -332,6 +340,8 @@ class VSM:
         Lmax = max(len(v[0]) for v in per_q.values())
         if Lmax > self.cfg.max_text_len:
             raise ValueError(f"prompt of {Lmax} tokens exceeds max_text_len={self.cfg.max_text_len}")
+        if getattr(self.cfg, "llm_w8a8", 0):
+            Lmax = w8a8_padded_len(Lmax, self.cfg.n_img_tokens, self.cfg.max_text_len)
         ids_rows = np.zeros((n_boxes, Lmax), np.int32)
         loc_rows = np.zeros((n_boxes,), np.int32)
         ver_rows = np.zeros((n_boxes, nv), np.int32)
