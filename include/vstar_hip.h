@@ -316,10 +316,11 @@ int vstar_op_gemm_fp8(void* stream, const uint16_t* dev_A, const uint16_t* dev_W
  * consecutive k (the smallest power of two that brings the block's largest magnitude to <= 448), applied inside
  * v_mfma_scale_f32_16x16x128_f8f6f4 per lane — so the PRODUCERS (attention epilogue, gate|up epilogue) quantise, and the two stand-alone
  * per-token passes of the round-3 scheme disappear.  The engine uses it when llm_w8a8 is set and the step's row count is a multiple of
- * 256.  Level 2 (default): the residual stream ALSO leaves o_proj / down_proj as a block-scaled fp8 copy with sum-of-squares partials,
- * q|k|v and gate|up consume it with their RMSNorm folded (weight into the fp8 W, 1 / rms as the per-row scale) — no activation
- * quantisation pass is left.  VSTAR_W8A8_MX=1 / 0 in the environment: only o_proj / down_proj inputs / the per-token scheme;
- * vstar_w8a8_mx_active returns the level the last step ran (0 / 1 / 2).
+ * 256 (level 1, the default).  Level 2 (VSTAR_W8A8_MX=2 in the environment): the residual stream ALSO leaves o_proj / down_proj as a
+ * block-scaled fp8 copy with sum-of-squares partials, q|k|v and gate|up consume it with their RMSNorm folded (weight into the fp8 W,
+ * 1 / rms as the per-row scale) — no activation quantisation pass is left; +1 % speed, but it moved the search on the config-5 leg
+ * (another final box), hence opt-in.  VSTAR_W8A8_MX=0: the per-token scheme.  vstar_w8a8_mx_active returns the level the last step
+ * ran (0 / 1 / 2).
  * Scale bytes are TILE-MAJOR (vstar_op_mx_scale_offset(row, k / 32, rows)); rows % 128 == 0, cols % 128 == 0.  The reference has no
  * fp8 path: oracle/vsm_oracle.py::mx_fake_quant restates the arithmetic.  Op-level doors (device pointers, synchronous):
  *   vstar_op_quantize_mx     X [rows, cols] bf16 -> q [rows, cols] fp8 + scales (the stand-alone form the fused producers must equal)

@@ -404,6 +404,17 @@ def test_w8a8_mode_matches_fake_quant_oracle(cuda):
     assert rep["logits: engine8 vs oracle8"] <= 6e-2 and rep["masks: engine8 vs oracle8"] <= 8e-2
 
 
+def test_w8a8_whole_chain_block_scaled_in_a_process_of_its_own(cuda):
+    """VSTAR_W8A8_MX=2 (opt-in: the residual stream block-scaled too, RMSNorms folded) is read once per process: the real-width test
+    below in a subprocess with the level set — engine vs the oracle's restatement of THAT scheme (linear_w8a8_mx_folded)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, VSTAR_W8A8_MX="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-m", "gpu", "-k", "test_w8a8_real_widths", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
 def test_w8a8_real_widths(cuda):
     """W8A8 at the real 7B widths (K = 4096 / 11008, S = 640; 3 LLaMA layers): engine vs the fake-quant oracle, and what
     the quantisation costs against the bf16 engine on the same inputs."""
@@ -428,7 +439,7 @@ def test_w8a8_real_widths(cuda):
         res[name] = (eng.debug_read("llm_hidden_loc", B * cfg.llm_hidden).reshape(B, -1), out)
         mx = eng.w8a8_mx_active()
         eng.close()
-    assert mx == int(os.environ.get("VSTAR_W8A8_MX", "2"))              # 2 x 640 rows: the fully block-scaled chain (round 6) unless switched down
+    assert mx == int(os.environ.get("VSTAR_W8A8_MX", "1"))              # 2 x 640 rows: block-scaled o_proj / down_proj inputs (round 6; 2 = the whole chain, opt-in)
     sd32 = {k: v.float() for k, v in sd.items()}
     ref8 = vsm_oracle.vsm_forward(sd32, cfg8, clip.float(), owl.float(), ids, loc_id, w8a8_mx=mx)
     rep = {"hidden w8a8 vs fake-quant oracle": rel_l2(res["w8a8"][0], ref8["llm_hidden_loc"].numpy()),

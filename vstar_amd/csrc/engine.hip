@@ -596,10 +596,12 @@ int vstar_engine::llm_forward(int nseq, int S, int nsel) {
     q.a_scale = lsa; q.w_scale = b0.gate_up8.s; q.c_mx = lmx;
     mx = mx && gemm_mx_supported(q, VSTAR_EPI_SILU_MUL);
   }
-  // Fully block-scaled chain (VSTAR_W8A8_MX=1 stops at the step above; default 2): the residual stream ALSO leaves o_proj / down_proj
+  // Fully block-scaled chain (opt-in: VSTAR_W8A8_MX=2; the default, 1, stops at the step above): the residual stream ALSO leaves o_proj / down_proj
   // as a block-scaled fp8 copy with sum-of-squares partials (mx_none_epilogue), q|k|v and gate|up consume it with the RMSNorm folded
   // (weight into their fp8 W, 1 / rms as the per-row scale) — no rmsnorm_quant pass either.
-  static const int mx_level = [] { const char* e = getenv("VSTAR_W8A8_MX"); return e ? atoi(e) : 2; }();
+  // Opt-in because it moves the search: on the config-5 search leg (bench.py, one 341-node tree) levels 0 / 1 / 2 follow the bf16 visit
+  // order for 25 / 20 / 3 nodes and level 2 ends in another final box, at +1 % speed over level 1 (profiles/r06_w8a8_levels.txt).
+  static const int mx_level = [] { const char* e = getenv("VSTAR_W8A8_MX"); return e ? atoi(e) : 1; }();
   bool chain = false;
   if (mx && mx_level >= 2 && H % 256 == 0) {
     GemmParams q{};
