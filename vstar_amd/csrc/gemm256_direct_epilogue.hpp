@@ -48,11 +48,32 @@ __device__ __forceinline__ void gemm256_direct_epilogue(const GemmParams& p, int
       f32x4 a[4];
       acc_row(mc, a);
       lpx8 v;
+#if !defined(VSTAR_LP_F16) && !defined(VSTAR_EXACT_SIGMOID) && !defined(VSTAR_SCALAR_GELU)
+      {   // two neighbouring outputs per step on the packed fp32 pipes; operations and rounding points of the scalar form below
+        typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+        typedef __attribute__((ext_vector_type(2))) float f2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+        auto rnd = [](f2_t x) {
+          const uint32_t b = __builtin_bit_cast(uint32_t, __builtin_convertvector(x, bf2_t));
+          return (f2_t){__uint_as_float(b << 16), __uint_as_float(b & 0xffff0000u)};
+        };
+        u32x4 w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int n = (k >> 1) * 2, e = (k & 1) * 2;
+          const f2_t g = rnd((f2_t){a[n][e], a[n][e + 1]}), u = rnd((f2_t){a[n + 1][e], a[n + 1][e + 1]});
+          const f2_t sg = {__builtin_amdgcn_rcpf(1.0f + __expf(-g[0])), __builtin_amdgcn_rcpf(1.0f + __expf(-g[1]))};
+          w[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rnd(g * sg) * u, bf2_t));
+        }
+        v = __builtin_bit_cast(lpx8, w);
+      }
+#else
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = (short)f2lp(act_silu_bf16(rlp(a[0][e])) * rlp(a[1][e]));
         v[4 + e] = (short)f2lp(act_silu_bf16(rlp(a[2][e])) * rlp(a[3][e]));
       }
+#endif
       if (!ROWGUARD || row0 + decltype(mc)::value * 16 < p.M) __builtin_nontemporal_store(v, (lpx8*)(crow + col_a));
       crow += 16 * p.ldc;
     });

@@ -107,8 +107,28 @@ __device__ __forceinline__ void gemm_epilogue_store(const GemmParams& p, int64_t
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue_act8(lpx8& v) {
   if (EPI == VSTAR_EPI_QUICK_GELU) {
+#if !defined(VSTAR_LP_F16) && !defined(VSTAR_EXACT_SIGMOID) && !defined(VSTAR_SCALAR_GELU)
+    // two neighbouring elements per step on the packed fp32 pipes: the operations, constants and rounding points of
+    // act_quick_gelu_bf16 (u = round(1.702 t); s = round(rcp(1 + exp(-u))); out = round(t s)) — only v_exp_f32 / v_rcp_f32 stay scalar
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    u32x4 w = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f2_t t = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xffff0000u)};
+      const uint32_t ub = __builtin_bit_cast(uint32_t, __builtin_convertvector(t * 1.702f, bf2_t));
+      const f2_t u = {__uint_as_float(ub << 16), __uint_as_float(ub & 0xffff0000u)};
+      f2_t s = {__builtin_amdgcn_rcpf(1.0f + __expf(-u[0])), __builtin_amdgcn_rcpf(1.0f + __expf(-u[1]))};
+      const uint32_t sb = __builtin_bit_cast(uint32_t, __builtin_convertvector(s, bf2_t));
+      s = (f2_t){__uint_as_float(sb << 16), __uint_as_float(sb & 0xffff0000u)};
+      w[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(t * s, bf2_t));
+    }
+    v = __builtin_bit_cast(lpx8, w);
+#else
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(act_quick_gelu_bf16(lp2f((lp_t)v[e])));
+#endif
   } else if (EPI == VSTAR_EPI_GELU) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (short)f2lp(act_gelu_erf(lp2f((lp_t)v[e])));
